@@ -171,6 +171,10 @@ typedef struct
 
 typedef struct { u32 sym, freq; } hfreq_t;
 
+/* set when the input drives the reference into undefined behaviour:
+ * the caller then reports ORC_E_UNSUPPORTED instead of pretending to know the reference's bytes */
+static __thread int g_ref_ub;
+
 static int hf_less(const hfreq_t* a, const hfreq_t* b)   /* a pops before b */
 {
 	return a->freq < b->freq || (a->freq == b->freq && a->sym < b->sym);
@@ -192,6 +196,7 @@ static void huff_build(huff_t* h, const u32* freqs, u32 n_in)
 	for (u32 i = 0; i < n; ++i) { heap[i].sym = i; heap[i].freq = freqs[i]; }
 	if (n < 2)          /* Appendix B.4: reference reads a stale slot here; do-not-test zone */
 	{
+		g_ref_ub = 1;
 		heap[1].sym = 1; heap[1].freq = 0;
 		if (n == 0) { heap[0].sym = 0; heap[0].freq = 0; }
 		n = 2;
@@ -567,7 +572,8 @@ static void dna_store(block_t* b, bw_t* w)
 		for (u32 j = 0; j < r->seq_len; ++j)
 		{
 			u32 sym = b->mem[r->seq + j];
-			row_encode(tab + hash * n, n, &rc, sym & (n - 1));   /* sym >= n is reference UB (Appendix B.3) */
+			if (sym >= n) g_ref_ub = 1;                          /* reference UB (Appendix B.3) */
+			row_encode(tab + hash * n, n, &rc, sym & (n - 1));
 			hash = ((hash << abits) | sym) & mask;
 		}
 	}
@@ -1365,7 +1371,9 @@ int orc_compress_block_state(const orc_config* cfg, uint32_t* fields_cap, const 
 							 uint8_t* out, uint64_t cap, uint64_t* out_size, uint64_t raw[4], uint64_t comp[4])
 {
 	bw_t w; bw_init(&w, size / 2 + 4096);
+	g_ref_ub = 0;
 	int rc = block_run(cfg, in, size, &w, raw, comp, NULL, fields_cap);
+	if (rc == ORC_OK && g_ref_ub) rc = ORC_E_UNSUPPORTED;
 	bw_flush(&w);
 	*out_size = w.pos;
 	if (rc == ORC_OK)
