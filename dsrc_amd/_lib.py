@@ -1,0 +1,168 @@
+"""ctypes binding of libdsrc_gpu.so (include/dsrc_gpu.h).
+
+The product path has exactly one implementation -- the HIP library.  If it has not been built, or
+there is no GPU, loading / creating a handle fails loudly; nothing here falls back to a CPU codec.
+
+``DSRC_GPU_LIB`` may point at another build of the same C ABI (the test-suite uses it to load the
+emulator build under tests/emu for kernel-logic tests on GPU-less machines).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "csrc", "libdsrc_gpu.so")
+
+EXPORTS = [
+    "dsrcgpu_create", "dsrcgpu_destroy", "dsrcgpu_last_error", "dsrcgpu_compress_block", "dsrcgpu_compress_batch",
+    "dsrcgpu_compress_batch_device", "dsrcgpu_submit", "dsrcgpu_flush", "dsrcgpu_collect", "dsrcgpu_release",
+    "dsrcgpu_last_timing", "dsrcgpu_synth_illumina", "dsrcgpu_dev_alloc", "dsrcgpu_dev_free", "dsrcgpu_dev_upload",
+    "dsrcgpu_dev_download",
+]
+
+
+class Settings(C.Structure):
+    _fields_ = [("dna_order", C.c_uint32), ("quality_order", C.c_uint32), ("tag_preserve_flags", C.c_uint64),
+                ("lossy", C.c_uint8), ("calculate_crc32", C.c_uint8), ("reserved", C.c_uint8 * 6)]
+
+
+class Dataset(C.Structure):
+    _fields_ = [("quality_offset", C.c_uint32), ("plus_repetition", C.c_uint8), ("color_space", C.c_uint8),
+                ("reserved", C.c_uint8 * 2)]
+
+
+class DsrcGpuError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"dsrc_gpu error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return os.environ.get("DSRC_GPU_LIB", DEFAULT_LIB)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          f"(hipcc --offload-arch=gfx950). The DSRC GPU path has no CPU fallback.")
+    L = C.CDLL(path)
+    L.dsrcgpu_last_error.restype = C.c_char_p
+    L.dsrcgpu_last_error.argtypes = [C.c_void_p]
+    L.dsrcgpu_destroy.restype = None
+    L.dsrcgpu_destroy.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+class Handle:
+    """One GPU block scheduler (replaces the reference's pool of BlockCompressor worker threads)."""
+
+    def __init__(self, dna_order=0, quality_order=0, lossy=False, crc=False, quality_offset=33,
+                 plus_repetition=False, color_space=False, tag_flags=0, device=0, arena_bytes=0):
+        self.L = load()
+        self.h = C.c_void_p()
+        s = Settings(dna_order, quality_order, tag_flags, int(lossy), int(crc))
+        d = Dataset(quality_offset, int(plus_repetition), int(color_space))
+        rc = self.L.dsrcgpu_create(C.byref(s), C.byref(d), device, C.c_uint64(arena_bytes), C.byref(self.h))
+        if rc != 0:
+            msg = self.L.dsrcgpu_last_error(self.h).decode() if self.h else "create failed"
+            if self.h:
+                self.L.dsrcgpu_destroy(self.h)
+                self.h = None
+            raise DsrcGpuError(rc, msg)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.dsrcgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise DsrcGpuError(rc, self.L.dsrcgpu_last_error(self.h).decode())
+        return rc
+
+    def compress_block(self, data: bytes):
+        cap = len(data) + (1 << 16)
+        out = (C.c_uint8 * cap)()
+        osz = C.c_uint64()
+        raw = (C.c_uint64 * 4)(); comp = (C.c_uint64 * 4)()
+        self._chk(self.L.dsrcgpu_compress_block(self.h, data, C.c_uint64(len(data)), out, C.c_uint64(cap), C.byref(osz), raw, comp))
+        return bytes(out[: osz.value]), list(raw), list(comp)
+
+    def compress_batch(self, chunks):
+        n = len(chunks)
+        ptrs = (C.c_char_p * n)(*chunks)
+        sizes = (C.c_uint64 * n)(*[len(c) for c in chunks])
+        cap = sum(len(c) for c in chunks) + n * (1 << 16)
+        out = (C.c_uint8 * cap)()
+        offs = (C.c_uint64 * n)(); osz = (C.c_uint64 * n)()
+        raw = (C.c_uint64 * (4 * n))(); comp = (C.c_uint64 * (4 * n))()
+        self._chk(self.L.dsrcgpu_compress_batch(self.h, n, ptrs, sizes, out, C.c_uint64(cap), offs, osz, raw, comp))
+        mv = memoryview(out)
+        return [(bytes(mv[offs[i]: offs[i] + osz[i]]), list(raw[4 * i: 4 * i + 4]), list(comp[4 * i: 4 * i + 4])) for i in range(n)]
+
+    def compress_batch_device(self, d_in: int, offs, sizes, d_out: int, out_cap: int):
+        n = len(offs)
+        a_offs = (C.c_uint64 * n)(*offs); a_sizes = (C.c_uint64 * n)(*sizes)
+        o_offs = (C.c_uint64 * n)(); o_sizes = (C.c_uint64 * n)()
+        raw = (C.c_uint64 * (4 * n))(); comp = (C.c_uint64 * (4 * n))()
+        self._chk(self.L.dsrcgpu_compress_batch_device(self.h, n, C.c_void_p(d_in), a_offs, a_sizes, C.c_void_p(d_out),
+                                                       C.c_uint64(out_cap), o_offs, o_sizes, raw, comp))
+        return list(o_offs), list(o_sizes), list(raw), list(comp)
+
+    def submit(self, part_id: int, data: bytes):
+        self._chk(self.L.dsrcgpu_submit(self.h, C.c_int64(part_id), data, C.c_uint64(len(data))))
+
+    def flush(self):
+        self._chk(self.L.dsrcgpu_flush(self.h))
+
+    def collect(self):
+        pid = C.c_int64(); blk = C.POINTER(C.c_uint8)(); sz = C.c_uint64()
+        raw = (C.c_uint64 * 4)(); comp = (C.c_uint64 * 4)()
+        rc = self._chk(self.L.dsrcgpu_collect(self.h, C.byref(pid), C.byref(blk), C.byref(sz), raw, comp))
+        if rc == 0:
+            return None
+        data = bytes(C.cast(blk, C.POINTER(C.c_uint8 * sz.value)).contents) if sz.value else b""
+        self.L.dsrcgpu_release(self.h, blk)
+        return pid.value, data, list(raw), list(comp)
+
+    def last_timing(self):
+        ms = C.c_float(); rc_ms = C.c_float(); n = C.c_uint32()
+        self.L.dsrcgpu_last_timing(self.h, C.byref(ms), C.byref(rc_ms), C.byref(n))
+        return ms.value, rc_ms.value, n.value
+
+    # device helpers -------------------------------------------------
+    def dev_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._chk(self.L.dsrcgpu_dev_alloc(self.h, C.c_uint64(nbytes), C.byref(p)))
+        return p.value
+
+    def dev_free(self, ptr: int):
+        self._chk(self.L.dsrcgpu_dev_free(self.h, C.c_void_p(ptr)))
+
+    def dev_upload(self, d_dst: int, data: bytes):
+        self._chk(self.L.dsrcgpu_dev_upload(self.h, C.c_void_p(d_dst), data, C.c_uint64(len(data))))
+
+    def dev_download(self, d_src: int, nbytes: int) -> bytes:
+        buf = (C.c_uint8 * nbytes)()
+        self._chk(self.L.dsrcgpu_dev_download(self.h, buf, C.c_void_p(d_src), C.c_uint64(nbytes)))
+        return bytes(buf)
+
+    def synth_illumina(self, first: int, count: int, d_out: int, cap: int) -> int:
+        n = C.c_uint64()
+        self._chk(self.L.dsrcgpu_synth_illumina(self.h, C.c_uint64(first), C.c_uint64(count), C.c_void_p(d_out), C.c_uint64(cap), C.byref(n)))
+        return n.value

@@ -1,0 +1,742 @@
+// libdsrc_gpu.so -- the GPU block scheduler behind include/dsrc_gpu.h.
+//
+// It replaces the reference's pool of DsrcCompressor worker threads (src/DsrcWorker.cpp:30-73):
+// a *batch* of FASTQ chunks is pushed through a fixed sequence of kernels, each owning whole
+// blocks, with four small device->host readbacks where the reference takes data-dependent
+// decisions (record counts, stream schemes, tag field kinds, final sizes).  All per-symbol and
+// per-record work is in the kernels (k_*.h); the host only sizes buffers and picks scheme ids
+// from block statistics exactly as the reference's *ModelerProxy::SelectSchemeId do.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "../../include/dsrc_gpu.h"
+#include "dsrc_types.h"
+#include "k_common.h"
+#include "k_parse.h"
+#include "k_rc.h"
+#include "k_huff.h"
+#include "k_tags.h"
+#include "k_block.h"
+#include "k_synth.h"
+
+namespace
+{
+
+struct Arena
+{
+	u8* base = nullptr;
+	size_t cap = 0, top = 0;
+	bool failed = false;
+	size_t alloc(size_t bytes, size_t align = 256)
+	{
+		top = (top + align - 1) / align * align;
+		const size_t off = top;
+		top += bytes;
+		if (top > cap) failed = true;
+		return off;
+	}
+};
+
+struct Pending { int64_t part_id; std::vector<u8> data; };
+struct Done { int64_t part_id; u8* block; u64 size; u64 raw[4]; u64 comp[4]; };
+
+} // namespace
+
+struct dsrcgpu_handle
+{
+	dsrcgpu_settings set;
+	dsrcgpu_dataset ds;
+	int device = 0;
+	hipStream_t stream = nullptr;
+	Arena arena;
+	u64 arena_fixed = 0;
+	u32 fields_cap = 0;              // capacity of the reference's TagStats::fields vector, carried block to block
+	u32* d_crc_tab = nullptr;
+	std::string err;
+	std::vector<Pending> pending;
+	std::deque<Done> done;
+	float batch_ms = 0.f, rc_ms = 0.f;
+	u32 rc_launches = 0;
+	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+namespace
+{
+
+int fail(dsrcgpu_handle* h, int code, const char* fmt, ...)
+{
+	char buf[512];
+	va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+	if (h) h->err = buf;
+	return code;
+}
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(h, DSRCGPU_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+#define KCHK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail(h, DSRCGPU_E_HIP, "kernel launch failed (%s:%d): %s", __FILE__, __LINE__, hipGetErrorString(e_)); } while (0)
+
+int ensure_arena(dsrcgpu_handle* h, size_t need)
+{
+	if (h->arena.cap >= need) { h->arena.top = 0; h->arena.failed = false; return 0; }
+	if (h->arena_fixed && need > h->arena_fixed)
+		return fail(h, DSRCGPU_E_NOMEM, "batch needs %zu bytes of HBM scratch, arena is fixed at %llu", need, (unsigned long long)h->arena_fixed);
+	if (h->arena.base) { HIPCHK(hipFree(h->arena.base)); h->arena.base = nullptr; h->arena.cap = 0; }
+	size_t want = h->arena_fixed ? (size_t)h->arena_fixed : need + need / 8;
+	hipError_t e = hipMalloc((void**)&h->arena.base, want);
+	if (e != hipSuccess) return fail(h, DSRCGPU_E_NOMEM, "hipMalloc(%zu) for the batch arena failed: %s", want, hipGetErrorString(e));
+	h->arena.cap = want; h->arena.top = 0; h->arena.failed = false;
+	return 0;
+}
+
+u32 bitlen(u64 x) { for (u32 i = 0; i < 32; ++i) if (x < (1ull << i)) return i; return 64; }
+u32 log2u(u32 x) { u32 r = 0; while (x > 1) { x >>= 1; ++r; } return r; }
+u32 h_huff_ws_words(u32 n) { const u32 m = n < 2 ? 2 : n; return 10 * m; }
+u32 h_huff_tree_cap(u32 n) { const u32 m = n < 2 ? 2 : n; return (16 + (2 * m + m * 10) / 8 + 8 + 3) & ~3u; }
+size_t al(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// how much arena a batch may need, from the input sizes alone (checked again while carving)
+size_t estimate_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
+{
+	const bool rc = h->set.dna_order > 0 || h->set.quality_order > 0;
+	size_t tot = 0, mx = 0;
+	for (u32 i = 0; i < n; ++i) { tot += (size_t)sizes[i] + 4096; mx = std::max(mx, (size_t)sizes[i]); }
+	return tot * (rc ? 34 : 14) + (size_t)n * (6u << 20) + (64u << 20);
+}
+
+struct BatchIO
+{
+	const u8* d_in; const u64* offs; const u64* sizes; u32 n;
+	u8* d_out; u64 out_cap;          // device output (nullptr => arena-allocated, copied to host_out)
+	u8* host_out; u64 host_cap;
+	u64* out_offs; u64* out_sizes; u64* raw; u64* comp;
+};
+
+template <typename T> T* AP(dsrcgpu_handle* h, size_t off) { return (T*)(h->arena.base + off); }
+
+int run_batch(dsrcgpu_handle* h, BatchIO io)
+{
+	const u32 B = io.n;
+	if (B == 0) return DSRCGPU_OK;
+	hipStream_t s = h->stream;
+	Arena& A = h->arena;
+	const u32 dna_order = h->set.dna_order, qo = h->set.quality_order;
+	const bool lossy = h->set.lossy != 0, crc = h->set.calculate_crc32 != 0;
+
+	DsrcParams prm;
+	prm.dna_order = dna_order; prm.quality_order = qo; prm.lossy = lossy; prm.crc = crc;
+	prm.quality_offset = h->ds.quality_offset; prm.n_blocks = B; prm.max_tiles = 1;
+
+	std::vector<BlkDesc> desc(B);
+	std::vector<BlkState> st(B);
+	memset(desc.data(), 0, sizeof(BlkDesc) * B);
+	size_t in_total = 0;
+	for (u32 b = 0; b < B; ++b)
+	{
+		if (io.sizes[b] == 0 || io.sizes[b] >= (1ull << 31)) return fail(h, DSRCGPU_E_ARG, "chunk %u: size %llu out of range", b, (unsigned long long)io.sizes[b]);
+		desc[b].in_off = io.offs[b]; desc[b].in_size = (u32)io.sizes[b];
+		desc[b].n_tiles = (u32)((io.sizes[b] + DSRC_TILE_BYTES - 1) / DSRC_TILE_BYTES);
+		prm.max_tiles = std::max(prm.max_tiles, desc[b].n_tiles);
+		in_total += io.sizes[b];
+	}
+	const u8* d_in = io.d_in;
+
+	HIPCHK(hipEventRecord(h->ev[0], s));
+
+	// ---- phase 1: line counts ------------------------------------------------------------------
+	const size_t o_desc = A.alloc(sizeof(BlkDesc) * B), o_state = A.alloc(sizeof(BlkState) * B);
+	const size_t o_tiles = A.alloc((size_t)B * prm.max_tiles * 4);
+	if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (phase 1)");
+	BlkDesc* d_desc = AP<BlkDesc>(h, o_desc); BlkState* d_state = AP<BlkState>(h, o_state); u32* d_tiles = AP<u32>(h, o_tiles);
+	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(BlkDesc) * B, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemsetAsync(d_state, 0, sizeof(BlkState) * B, s));
+	hipLaunchKernelGGL(k_init_state, dim3((B + 63) / 64), dim3(64), 0, s, d_state, B); KCHK();
+	hipLaunchKernelGGL(k_count_lines, dim3(prm.max_tiles, B), dim3(WG), 0, s, d_in, d_desc, d_state, d_tiles, prm); KCHK();
+	hipLaunchKernelGGL(k_scan_tiles, dim3(B), dim3(WG), 0, s, d_desc, d_tiles, prm); KCHK();
+	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+
+	// ---- phase 2: index, statistics, symbol streams --------------------------------------------------
+	u64 lines = 0, recs = 0, qbytes = 0; u32 max_rec_cap = 1;
+	for (u32 b = 0; b < B; ++b)
+	{
+		const u32 n_lines = st[b].n_term + 1;
+		desc[b].line_base = (u32)lines; lines += n_lines + 2;
+		desc[b].rec_cap = (n_lines + 3) / 4;
+		desc[b].rec_base = (u32)recs; recs += desc[b].rec_cap + 1;
+		max_rec_cap = std::max(max_rec_cap, desc[b].rec_cap);
+		desc[b].q_base = qbytes; desc[b].d_base = qbytes; qbytes += al(desc[b].in_size / 2 + 64, 64);
+		if (lines >= (1ull << 32) || recs >= (1ull << 32)) return fail(h, DSRCGPU_E_ARG, "batch too large for 32-bit record indices; submit fewer chunks per batch");
+	}
+	const size_t o_lines = A.alloc(lines * 4);
+	RecPools rp;
+	rp.title_off = AP<u32>(h, A.alloc(recs * 4)); rp.seq_off = AP<u32>(h, A.alloc(recs * 4)); rp.qual_off = AP<u32>(h, A.alloc(recs * 4));
+	rp.title_len = AP<u16>(h, A.alloc(recs * 2)); rp.len = AP<u16>(h, A.alloc(recs * 2));
+	rp.kept = AP<u16>(h, A.alloc(recs * 2)); rp.trunc = AP<u16>(h, A.alloc(recs * 2));
+	rp.q_off = AP<u32>(h, A.alloc(recs * 4)); rp.d_off = AP<u32>(h, A.alloc(recs * 4));
+	const size_t o_q = A.alloc(qbytes), o_qp = A.alloc(qbytes), o_d = A.alloc(qbytes);
+	if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (phase 2): need > %zu bytes", A.top);
+	u32* d_lines = AP<u32>(h, o_lines);
+	u8* d_q = AP<u8>(h, o_q); u8* d_qp = AP<u8>(h, o_qp); u8* d_d = AP<u8>(h, o_d);
+	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(BlkDesc) * B, hipMemcpyHostToDevice, s));
+	hipLaunchKernelGGL(k_index_lines, dim3(prm.max_tiles, B), dim3(WG), 0, s, d_in, d_desc, d_tiles, d_lines, prm); KCHK();
+	hipLaunchKernelGGL(k_records, dim3((max_rec_cap + WG - 1) / WG, B), dim3(WG), 0, s, d_in, d_desc, d_state, d_lines, rp); KCHK();
+	hipLaunchKernelGGL(k_prep_stats, dim3(B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, prm); KCHK();
+	hipLaunchKernelGGL(k_rec_offsets, dim3(B), dim3(WG), 0, s, d_desc, d_state, rp); KCHK();
+	{
+		const u32 gx = std::max(1u, std::min(64u, (max_rec_cap + 4 * WAVES - 1) / (4 * WAVES)));
+		hipLaunchKernelGGL(k_prep_write, dim3(gx, B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, d_q, d_qp, d_d, prm); KCHK();
+	}
+	hipLaunchKernelGGL(k_tag_template, dim3((B + 63) / 64), dim3(64), 0, s, d_in, d_desc, d_state, rp, B); KCHK();
+	if (crc) { hipLaunchKernelGGL(k_crc, dim3(B, 3), dim3(WG), 0, s, d_in, d_desc, d_state, rp, h->d_crc_tab, prm); KCHK(); }
+	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+
+	// ---- phase 3: scheme selection and buffer carving (host) -------------------------------------------
+	for (u32 b = 0; b < B; ++b)
+		if (st[b].err) return fail(h, DSRCGPU_E_INPUT, "chunk %u cannot be coded (error bits 0x%x, %u records)", b, st[b].err, st[b].n_recs);
+
+	std::vector<TagPlan> tplan(B);
+	std::vector<QuaPlan> qplan(B), dplan(B);
+	memset(tplan.data(), 0, sizeof(TagPlan) * B); memset(qplan.data(), 0, sizeof(QuaPlan) * B); memset(dplan.data(), 0, sizeof(QuaPlan) * B);
+	std::vector<CtxJob> jobs;
+	std::vector<CtxJob> qjobs, djobs;
+
+	static const u32 QN[8] = {16, 32, 64, 128, 16, 32, 64, 128};
+	static const u32 ORD1[4] = {3, 2, 1, 1}, ORD2[4] = {4, 3, 2, 1};
+
+	for (u32 b = 0; b < B; ++b)
+	{
+		const BlkState& S = st[b];
+		BlkDesc& D = desc[b];
+		// TagStats::fields capacity emulation (see oracle/dsrc_oracle.c tags_init)
+		{
+			u32 cap = h->fields_cap; int last = -1;
+			for (u32 i = 0; i < S.n_fields; ++i) if (i == cap) { last = (int)i; cap = cap ? cap * 2 : 1; }
+			D.fields_keep_from = last < 0 ? 0u : (u32)last;
+			h->fields_cap = cap;
+		}
+		// DNA scheme: DnaNormalModelerProxy / DnaOrderModelerProxy::SelectSchemeId (src/DnaModelerProxy.h:88-123,160-172)
+		if (S.d_count == 0) D.d_scheme = 255;
+		else if (dna_order == 0) D.d_scheme = S.d_count <= 4 ? 0 : 1;
+		else
+		{
+			D.d_scheme = S.d_count <= 4 ? 0 : 1;
+			if (S.d_count > 8) return fail(h, DSRCGPU_E_INPUT, "chunk %u: %u DNA symbols with an order model is undefined in the reference", b, S.d_count);
+		}
+		// quality scheme
+		if (qo == 0)
+		{	// QualityNormalModelerProxy::SelectSchemeId (src/QualityModelerProxy.h:113-122)
+			if ((float)S.th_len / (float)S.rle_len > 1.25f) D.q_scheme = 2;
+			else if ((float)S.raw_len / (float)S.th_len > 1.10f) D.q_scheme = 1;
+			else D.q_scheme = 0;
+		}
+		else if (lossy) D.q_scheme = 0;
+		else
+		{	// QualityOrderModelerProxyLossless::SelectSchemeId (src/QualityModelerProxy.h:257-283)
+			u32 scheme = 255;
+			for (u32 i = 0; i < 8; ++i) if ((16u << i) >= S.q_count) { scheme = i; break; }
+			if (scheme != 255 && qo == 2)
+			{
+				const double ratio = (double)S.raw_len / (double)S.rle_len;
+				if (S.max_len == S.min_len && ratio > 1.175) scheme += 4;
+			}
+			if (scheme > 7 || (scheme > 3 && S.q_count > 128)) return fail(h, DSRCGPU_E_INPUT, "chunk %u: %u quality symbols is undefined in the reference's order model", b, S.q_count);
+			D.q_scheme = scheme;
+		}
+	}
+
+	// tag value / run arrays
+	for (u32 b = 0; b < B; ++b)
+	{
+		const BlkState& S = st[b];
+		tplan[b].val = A.alloc((size_t)std::max(1u, S.n_num0) * S.n_recs * 4) / 4;
+		tplan[b].rl = A.alloc((size_t)std::max(1u, S.n_num0) * 2 * S.n_recs * 2) / 2;
+	}
+	const size_t o_tplan = A.alloc(sizeof(TagPlan) * B), o_tres = A.alloc(sizeof(TagFieldRes) * B * DSRC_MAX_FIELDS);
+	const size_t o_qplan = A.alloc(sizeof(QuaPlan) * B), o_dplan = A.alloc(sizeof(QuaPlan) * B);
+	if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (phase 3a)");
+	TagPlan* d_tplan = AP<TagPlan>(h, o_tplan); TagFieldRes* d_tres = AP<TagFieldRes>(h, o_tres);
+	QuaPlan* d_qplan = AP<QuaPlan>(h, o_qplan); QuaPlan* d_dplan = AP<QuaPlan>(h, o_dplan);
+	u32* wpool = AP<u32>(h, 0); u64* lpool = AP<u64>(h, 0); u16* spool = AP<u16>(h, 0);
+
+	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(BlkDesc) * B, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(d_tplan, tplan.data(), sizeof(TagPlan) * B, hipMemcpyHostToDevice, s));
+	hipLaunchKernelGGL(k_tag_scan, dim3(B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, wpool, d_tplan); KCHK();
+	hipLaunchKernelGGL(k_tag_numeric, dim3(B), dim3(WG), 0, s, d_desc, d_state, wpool, spool, d_tplan); KCHK();
+	hipLaunchKernelGGL(k_tag_finalize, dim3(B), dim3(64), 0, s, d_state); KCHK();
+
+	// ---- quality / DNA streams -------------------------------------------------------------------------
+	// staging: zeroed region (bit-emitted streams) and plain region (byte-written range-coder output)
+	size_t zero_lo = al(A.top, 256); A.top = zero_lo;
+	for (u32 b = 0; b < B; ++b)
+	{
+		const BlkState& S = st[b]; BlkDesc& D = desc[b];
+		if (qo == 0)
+		{
+			QuaPlan& P = qplan[b];
+			P.scheme = D.q_scheme; P.blk = b;
+			size_t cap_bytes;
+			if (D.q_scheme <= 1)
+			{
+				const u32 hw = S.max_len * S.q_count;
+				P.hist_words = hw; P.code_off = hw; P.len_off = 2 * hw;
+				P.tree_slot = 4 + h_huff_tree_cap(S.q_count); P.tree_off = 3 * hw;
+				P.n_trees = S.max_len;
+				const u32 tree_words = (u32)(((size_t)S.max_len * P.tree_slot + 3) / 4);
+				P.ws_slot = h_huff_ws_words(S.q_count); P.ws_off = P.tree_off + tree_words;
+				P.aux_off = P.ws_off + S.max_len * P.ws_slot;
+				const size_t words = (size_t)P.aux_off + S.n_recs + 4;
+				P.scr = A.alloc(words * 4) / 4;
+				cap_bytes = 64 + (size_t)S.max_len * P.tree_slot + ((size_t)S.q_total * (bitlen(S.q_count) + 1) + 7) / 8 + (size_t)S.n_recs * 3;
+			}
+			else
+			{
+				const u32 qn = S.q_count, hw = qn * qn + qn * 256;
+				P.hist_words = hw; P.code_off = hw; P.len_off = 2 * hw; P.lf_off = 3 * hw;
+				P.tree_slot = 4 + h_huff_tree_cap(256); P.tree_off = P.lf_off + 256; P.n_trees = 2 * qn;
+				const u32 tree_words = (u32)(((size_t)2 * qn * P.tree_slot + 3) / 4);
+				P.ws_slot = h_huff_ws_words(256); P.ws_off = P.tree_off + tree_words;
+				const size_t words = (size_t)P.ws_off + (size_t)2 * qn * P.ws_slot + 4;
+				P.scr = A.alloc(words * 4) / 4;
+				cap_bytes = 128 + (size_t)2 * qn * P.tree_slot + ((size_t)S.q_total * 20 + 7) / 8;
+			}
+			D.qua_cap = (u32)(al(cap_bytes, 16) / 4 + 4);
+			D.qua_out = A.alloc((size_t)D.qua_cap * 4) / 4;
+		}
+		if (dna_order == 0 && D.d_scheme == 1)
+		{
+			QuaPlan& P = dplan[b];
+			P.scheme = 1; P.blk = b; P.hist_words = 0;
+			P.ws_off = 32; P.ws_slot = h_huff_ws_words(20); P.tree_off = P.ws_off + P.ws_slot; P.tree_slot = 4 + h_huff_tree_cap(20);
+			const size_t words = P.tree_off + P.tree_slot / 4 + 8;
+			P.scr = A.alloc(words * 4) / 4;
+			D.dna_cap = (u32)((8 + h_huff_tree_cap(20) + ((size_t)S.d_total * 6 + 7) / 8 + 16) / 4 + 4);
+			D.dna_out = A.alloc((size_t)D.dna_cap * 4) / 4;
+		}
+	}
+	size_t zero_hi = al(A.top, 256); A.top = zero_hi;
+	// plain (not zeroed) staging + work buffers
+	for (u32 b = 0; b < B; ++b)
+	{
+		const BlkState& S = st[b]; BlkDesc& D = desc[b];
+		if (qo == 0 && D.q_scheme == 2)
+		{
+			const size_t off = A.alloc(((size_t)S.q_total + 2) * 4) / 4;
+			qplan[b].run_start = off;
+		}
+		if (qo > 0)
+		{
+			D.qua_cap = (u32)((64 + (size_t)S.q_total * 2) / 4 + 4);
+			D.qua_out = A.alloc((size_t)D.qua_cap * 4) / 4;
+		}
+		if (dna_order == 0 && D.d_scheme == 0) { D.dna_cap = (u32)((S.d_total / 4 + 16) / 4 + 4); D.dna_out = A.alloc((size_t)D.dna_cap * 4) / 4; }
+		if (dna_order > 0 || D.d_scheme == 255)
+		{
+			D.dna_cap = (u32)((64 + (size_t)S.d_total * 2) / 4 + 4);
+			D.dna_out = A.alloc((size_t)D.dna_cap * 4) / 4;
+		}
+	}
+	// range-coder jobs
+	if (qo > 0)
+		for (u32 b = 0; b < B; ++b)
+		{
+			const BlkState& S = st[b]; const BlkDesc& D = desc[b];
+			CtxJob j; memset(&j, 0, sizeof(j));
+			j.blk = b; j.n = S.q_total; j.src_off = D.q_base; j.is_dna = 0;
+			if (lossy) { j.n_alpha = 8; j.order = qo; j.rescale_shift = 4; j.translate = 0; j.out_byte0 = 0; j.scheme = 0; }
+			else
+			{
+				j.n_alpha = QN[D.q_scheme]; j.order = (qo == 1) ? ORD1[D.q_scheme & 3] : ORD2[D.q_scheme & 3];
+				const u32 rescale = D.q_scheme < 4 ? 8 : j.n_alpha;
+				j.rescale_shift = 7 - log2u(rescale); j.translate = 1; j.out_byte0 = 33; j.scheme = D.q_scheme;
+			}
+			if (j.order > 7) return fail(h, DSRCGPU_E_ARG, "quality order %u not supported", j.order);
+			j.alpha_bits = log2u(j.n_alpha); j.key_bits = j.alpha_bits * (j.order + 1);
+			j.out_words = D.qua_out; j.out_cap = D.qua_cap * 4 - j.out_byte0;
+			qjobs.push_back(j);
+		}
+	if (dna_order > 0)
+		for (u32 b = 0; b < B; ++b)
+		{
+			const BlkState& S = st[b]; const BlkDesc& D = desc[b];
+			if (D.d_scheme == 255) continue;
+			CtxJob j; memset(&j, 0, sizeof(j));
+			j.blk = b; j.n = S.d_total; j.src_off = D.d_base; j.is_dna = 1;
+			j.n_alpha = D.d_scheme ? 8 : 4; j.alpha_bits = D.d_scheme ? 3 : 2;
+			j.order = D.d_scheme ? std::min(dna_order, 7u) : dna_order;
+			j.key_bits = j.alpha_bits * j.order; j.scheme = D.d_scheme; j.out_byte0 = 1;
+			j.out_words = D.dna_out; j.out_cap = D.dna_cap * 4 - 1;
+			djobs.push_back(j);
+		}
+	// order jobs by (kind, alphabet) so that replay launches and 64-chain groups are homogeneous
+	std::stable_sort(qjobs.begin(), qjobs.end(), [](const CtxJob& a, const CtxJob& b) { return a.n_alpha < b.n_alpha; });
+	std::stable_sort(djobs.begin(), djobs.end(), [](const CtxJob& a, const CtxJob& b) { return a.n_alpha < b.n_alpha; });
+	jobs = qjobs; jobs.insert(jobs.end(), djobs.begin(), djobs.end());
+	const u32 NJ = (u32)jobs.size();
+	std::vector<RcChain> chains(NJ);
+	{
+		size_t trip_words = 0;
+		std::vector<size_t> gbase((NJ + 63) / 64 + 1, 0);
+		for (u32 g = 0; g * 64 < NJ; ++g)
+		{
+			u32 mx = 0;
+			for (u32 i = g * 64; i < std::min(NJ, g * 64 + 64); ++i) mx = std::max(mx, jobs[i].n);
+			gbase[g] = trip_words; trip_words += (size_t)mx * 64;
+		}
+		const size_t o_trip = A.alloc(trip_words * 8 + 64);
+		for (u32 i = 0; i < NJ; ++i)
+		{
+			CtxJob& j = jobs[i];
+			j.passes = (j.key_bits + 7) / 8; if (j.passes == 0) j.passes = 1;
+			j.dbits = (j.key_bits + j.passes - 1) / j.passes; if (j.dbits == 0) j.dbits = 1;
+			j.sorted_in_b = j.passes & 1;
+			j.elems = A.alloc((size_t)j.n * 8 + 64) / 8; j.elems_b = A.alloc((size_t)j.n * 8 + 64) / 8;
+			j.trip = o_trip / 8 + gbase[i / 64] + (i % 64);
+			RcChain& c = chains[i];
+			c.trip = j.trip; c.out_words = j.out_words; c.n = j.n; c.out_byte0 = j.out_byte0; c.out_cap = j.out_cap; c.blk = j.blk; c.is_dna = j.is_dna; c.pad = 0;
+		}
+	}
+	const size_t o_jobs = A.alloc(sizeof(CtxJob) * std::max(1u, NJ)), o_chains = A.alloc(sizeof(RcChain) * std::max(1u, NJ));
+	if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (phase 3b): batch needs > %zu bytes of HBM scratch", A.top);
+	CtxJob* d_jobs = AP<CtxJob>(h, o_jobs); RcChain* d_chains = AP<RcChain>(h, o_chains);
+
+	// ---- tags: dictionary resources are sized from the finalized field kinds ----------------------------------
+	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	std::vector<TagFieldRes> tres((size_t)B * DSRC_MAX_FIELDS);
+	memset(tres.data(), 0, sizeof(TagFieldRes) * tres.size());
+	size_t tz_lo = al(A.top, 256); A.top = tz_lo;
+	for (u32 b = 0; b < B; ++b)
+	{
+		const BlkState& S = st[b]; BlkDesc& D = desc[b];
+		size_t words = 0, hdr = 64;
+		tplan[b].rbits_off = (u32)words; words += S.n_recs + 4;
+		tplan[b].raw_hist_off = (u32)words; words += 128 + h_huff_ws_words(128) + h_huff_tree_cap(128) / 4 + 16;
+		for (u32 fi = 0; fi < S.n_fields && !S.mixed; ++fi)
+		{
+			const TagField& f = S.fld[fi];
+			TagFieldRes& R = tres[(size_t)b * DSRC_MAX_FIELDS + fi];
+			hdr += 32 + f.len0 + f.len0 / 8;
+			if (f.is_string)
+			{
+				R.hist_off = (u32)words; words += 129 * 256;
+				R.ham_off = (u32)words; words += f.len0 + 4;
+				R.code_off = (u32)words; words += 129 * 256;
+				R.len_off = (u32)words; words += 129 * 256;
+				R.tree_slot = 4 + h_huff_tree_cap(256);
+				R.tree_off = (u32)(words * 4); words += ((size_t)129 * R.tree_slot + 3) / 4;
+				R.ws_slot = h_huff_ws_words(256); R.ws_off = (u32)words; words += (size_t)129 * R.ws_slot;
+				hdr += (size_t)129 * R.tree_slot;
+			}
+			else if (f.is_numeric && !f.is_constant && f.var_stat_encode)
+			{
+				R.hist_off = (u32)words; words += 512;
+				R.code_off = (u32)words; words += 512;
+				R.len_off = (u32)words; words += 512;
+				R.tree_slot = 4 + h_huff_tree_cap(512);
+				R.tree_off = (u32)(words * 4); words += (R.tree_slot + 3) / 4;
+				R.ws_slot = h_huff_ws_words(512); R.ws_off = (u32)words; words += R.ws_slot;
+				hdr += R.tree_slot;
+			}
+		}
+		if (S.mixed) hdr += 64 + h_huff_tree_cap(128);
+		tplan[b].scr = A.alloc(words * 4) / 4;
+		const size_t cap_bytes = hdr + ((size_t)S.raw_tag * 9 + 7) / 8 + (size_t)S.n_recs * ((size_t)S.n_fields * 5 + 8) + 64;
+		D.tag_cap = (u32)(al(cap_bytes, 16) / 4 + 4);
+		D.tag_out = A.alloc((size_t)D.tag_cap * 4) / 4;
+	}
+	size_t tz_hi = al(A.top, 256); A.top = tz_hi;
+	if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (tags): batch needs > %zu bytes of HBM scratch", A.top);
+	HIPCHK(hipMemsetAsync(h->arena.base + tz_lo, 0, tz_hi - tz_lo, s));
+	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(BlkDesc) * B, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(d_tplan, tplan.data(), sizeof(TagPlan) * B, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(d_tres, tres.data(), sizeof(TagFieldRes) * tres.size(), hipMemcpyHostToDevice, s));
+	hipLaunchKernelGGL(k_tag_hist, dim3(B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, wpool, wpool, d_tplan, d_tres); KCHK();
+	hipLaunchKernelGGL(k_tag_trees, dim3((DSRC_MAX_FIELDS * DSRC_MAX_STRF + 63) / 64, B), dim3(64), 0, s, d_state, wpool, d_tplan, d_tres); KCHK();
+	hipLaunchKernelGGL(k_tag_emit, dim3(B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, wpool, spool, wpool, wpool, d_tplan, d_tres); KCHK();
+	hipLaunchKernelGGL(k_tag_raw, dim3(B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, wpool, wpool, d_tplan); KCHK();
+
+	// ---- quality / DNA stream kernels (queued behind the tag kernels on the same stream) -----------------
+	if (zero_hi > zero_lo) HIPCHK(hipMemsetAsync(h->arena.base + zero_lo, 0, zero_hi - zero_lo, s));
+	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(BlkDesc) * B, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(d_qplan, qplan.data(), sizeof(QuaPlan) * B, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(d_dplan, dplan.data(), sizeof(QuaPlan) * B, hipMemcpyHostToDevice, s));
+	if (NJ)
+	{
+		HIPCHK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(CtxJob) * NJ, hipMemcpyHostToDevice, s));
+		HIPCHK(hipMemcpyAsync(d_chains, chains.data(), sizeof(RcChain) * NJ, hipMemcpyHostToDevice, s));
+	}
+
+	u32 maxq = 1, maxd = 1, max_len = 1, max_qn = 1;
+	for (u32 b = 0; b < B; ++b) { maxq = std::max(maxq, st[b].q_total); maxd = std::max(maxd, st[b].d_total); max_len = std::max(max_len, st[b].max_len); max_qn = std::max(max_qn, st[b].q_count); }
+
+	if (qo == 0)
+	{
+		hipLaunchKernelGGL(k_qpos_hist, dim3(B), dim3(WG), 0, s, d_desc, d_state, rp, d_q, wpool, d_qplan); KCHK();
+		hipLaunchKernelGGL(k_qpos_trees, dim3((max_len + 63) / 64, B), dim3(64), 0, s, d_state, wpool, d_qplan); KCHK();
+		hipLaunchKernelGGL(k_qpos_emit, dim3(B), dim3(WG), 0, s, d_desc, d_state, rp, d_q, wpool, wpool, d_qplan); KCHK();
+		hipLaunchKernelGGL(k_qrle_runs, dim3(B), dim3(WG), 0, s, d_desc, d_state, d_q, wpool, d_qplan); KCHK();
+		hipLaunchKernelGGL(k_qrle_hist, dim3(B), dim3(WG), 0, s, d_desc, d_state, d_q, wpool, d_qplan); KCHK();
+		hipLaunchKernelGGL(k_qrle_trees, dim3((2 * max_qn + 63) / 64, B), dim3(64), 0, s, d_state, wpool, d_qplan); KCHK();
+		hipLaunchKernelGGL(k_qrle_emit, dim3(B), dim3(WG), 0, s, d_desc, d_state, d_q, wpool, wpool, d_qplan); KCHK();
+	}
+	if (dna_order == 0)
+	{
+		const u32 gx = std::max(1u, std::min(64u, (maxd / 4 + WG - 1) / WG));
+		hipLaunchKernelGGL(k_dna_b2, dim3(gx, B), dim3(WG), 0, s, d_desc, d_state, d_d, wpool); KCHK();
+		hipLaunchKernelGGL(k_dna_huff, dim3(B), dim3(WG), 0, s, d_desc, d_state, d_d, wpool, wpool, d_dplan); KCHK();
+	}
+	hipLaunchKernelGGL(k_dna_none, dim3((B + 63) / 64), dim3(64), 0, s, d_desc, d_state, wpool, B); KCHK();
+	h->rc_launches = 0;
+	if (NJ)
+	{
+		const u32 nq = (u32)qjobs.size(), nd = (u32)djobs.size();
+		hipLaunchKernelGGL(k_rc_headers, dim3((NJ + 63) / 64), dim3(64), 0, s, d_jobs, NJ, d_state, wpool); KCHK();
+		if (nq) { const u32 gx = std::max(1u, std::min(32u, (maxq + WG * 8 - 1) / (WG * 8))); hipLaunchKernelGGL(k_ctx_qua, dim3(gx, nq), dim3(WG), 0, s, d_jobs, d_q, d_qp, lpool, d_state); KCHK(); }
+		if (nd) { const u32 gx = std::max(1u, std::min(32u, (maxd + WG * 8 - 1) / (WG * 8))); hipLaunchKernelGGL(k_ctx_dna, dim3(gx, nd), dim3(WG), 0, s, d_jobs + nq, d_d, lpool, d_state); KCHK(); }
+		hipLaunchKernelGGL(k_sort, dim3(NJ), dim3(WG), 0, s, d_jobs, lpool); KCHK();
+		for (u32 lo = 0; lo < NJ;)
+		{
+			u32 hi = lo;
+			while (hi < NJ && jobs[hi].n_alpha == jobs[lo].n_alpha) ++hi;
+			const u32 cnt = hi - lo;
+			switch (jobs[lo].n_alpha)
+			{
+			case 4:   hipLaunchKernelGGL(k_replay<4>,   dim3(cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
+			case 8:   hipLaunchKernelGGL(k_replay<8>,   dim3(cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
+			case 16:  hipLaunchKernelGGL(k_replay<16>,  dim3(cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
+			case 32:  hipLaunchKernelGGL(k_replay<32>,  dim3(cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
+			case 64:  hipLaunchKernelGGL(k_replay<64>,  dim3(cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
+			default:  hipLaunchKernelGGL(k_replay<128>, dim3(cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
+			}
+			KCHK();
+			lo = hi;
+		}
+		HIPCHK(hipEventRecord(h->ev[2], s));
+		hipLaunchKernelGGL(k_rc, dim3((NJ + 63) / 64), dim3(64), 0, s, d_chains, NJ, lpool, wpool, d_state); KCHK();
+		HIPCHK(hipEventRecord(h->ev[3], s));
+		h->rc_launches = 1;
+	}
+
+	hipLaunchKernelGGL(k_meta_plan, dim3((B + 63) / 64), dim3(64), 0, s, d_state, prm); KCHK();
+
+	// ---- sizes -> output layout -> assembly -----------------------------------------------------------------------
+	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	u64 total = 0;
+	for (u32 b = 0; b < B; ++b)
+	{
+		const BlkState& S = st[b];
+		if (S.err) return fail(h, DSRCGPU_E_INPUT, "chunk %u cannot be coded (error bits 0x%x)", b, S.err);
+		if (S.tag_bytes > (u64)desc[b].tag_cap * 4 || S.qua_bytes > (u64)desc[b].qua_cap * 4 || S.dna_bytes > (u64)desc[b].dna_cap * 4)
+			return fail(h, DSRCGPU_E_INPUT, "chunk %u: staging overflow (tag %u/%u qua %u/%u dna %u/%u)", b, S.tag_bytes, desc[b].tag_cap * 4, S.qua_bytes, desc[b].qua_cap * 4, S.dna_bytes, desc[b].dna_cap * 4);
+		desc[b].out_off = total;
+		const u64 sz = (u64)S.meta_bytes + S.tag_bytes + S.qua_bytes + S.dna_bytes;
+		io.out_offs[b] = total; io.out_sizes[b] = sz;
+		io.raw[4 * b + 0] = 0; io.raw[4 * b + 1] = S.raw_tag; io.raw[4 * b + 2] = S.raw_dna; io.raw[4 * b + 3] = S.raw_qua;
+		io.comp[4 * b + 0] = S.meta_bytes; io.comp[4 * b + 1] = S.tag_bytes; io.comp[4 * b + 2] = S.dna_bytes; io.comp[4 * b + 3] = S.qua_bytes;
+		total += sz;
+	}
+	u8* d_out = io.d_out;
+	if (!d_out)
+	{
+		const size_t o_out = A.alloc(total + 64);
+		if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (output)");
+		d_out = AP<u8>(h, o_out);
+		if (total > io.host_cap) return fail(h, DSRCGPU_E_CAPACITY, "output needs %llu bytes, caller gave %llu", (unsigned long long)total, (unsigned long long)io.host_cap);
+	}
+	else if (total > io.out_cap) return fail(h, DSRCGPU_E_CAPACITY, "output needs %llu bytes, caller gave %llu", (unsigned long long)total, (unsigned long long)io.out_cap);
+	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(BlkDesc) * B, hipMemcpyHostToDevice, s));
+	hipLaunchKernelGGL(k_assemble, dim3(16, B), dim3(WG), 0, s, d_desc, d_state, wpool, d_out, prm); KCHK();
+	HIPCHK(hipEventRecord(h->ev[1], s));
+	if (io.host_out) HIPCHK(hipMemcpyAsync(io.host_out, d_out, total, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	hipEventElapsedTime(&h->batch_ms, h->ev[0], h->ev[1]);
+	if (h->rc_launches) hipEventElapsedTime(&h->rc_ms, h->ev[2], h->ev[3]); else h->rc_ms = 0.f;
+	return DSRCGPU_OK;
+}
+
+int check_settings(dsrcgpu_handle* h, const dsrcgpu_settings* s, const dsrcgpu_dataset* d)
+{
+	if (!s || !d) return fail(h, DSRCGPU_E_ARG, "null settings/dataset");
+	if (s->tag_preserve_flags != 0) return fail(h, DSRCGPU_E_ARG, "tag field filter (-f) is not supported on the GPU path");
+	if (d->color_space) return fail(h, DSRCGPU_E_ARG, "colour-space data sets are not supported on the GPU path");
+	if (d->quality_offset < 33 || d->quality_offset > 64) return fail(h, DSRCGPU_E_ARG, "quality offset %u outside [33,64]", d->quality_offset);
+	if (s->dna_order > 9) return fail(h, DSRCGPU_E_ARG, "dna_order %u > 9", s->dna_order);
+	if (!s->lossy && s->quality_order > 2) return fail(h, DSRCGPU_E_ARG, "lossless quality_order %u > 2", s->quality_order);
+	if (s->lossy && s->quality_order > 6) return fail(h, DSRCGPU_E_ARG, "lossy quality_order %u > 6", s->quality_order);
+	return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int dsrcgpu_create(const dsrcgpu_settings* settings, const dsrcgpu_dataset* dataset, int device, uint64_t arena_bytes, dsrcgpu_handle** out)
+{
+	if (!out) return DSRCGPU_E_ARG;
+	*out = nullptr;
+	dsrcgpu_handle* h = new dsrcgpu_handle();
+	*out = h;                       // returned even on failure so that the caller can read last_error
+	int rc = check_settings(h, settings, dataset);
+	if (rc) return rc;
+	h->set = *settings; h->ds = *dataset; h->device = device;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(h, DSRCGPU_E_HIP, "no HIP device available: the DSRC GPU path requires an MI355X-class GPU (there is no CPU fallback)");
+	if (device < 0 || device >= ndev) return fail(h, DSRCGPU_E_ARG, "device %d out of range (%d devices)", device, ndev);
+	HIPCHK(hipSetDevice(device));
+	HIPCHK(hipStreamCreate(&h->stream));
+	for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
+	h->arena_fixed = arena_bytes;
+	{	// CRC tables: 256 byte-table entries + x^(2^k) mod P, k = 0..31
+		u32 tab[288];
+		for (u32 i = 0; i < 256; ++i) { u32 c = i; for (int j = 0; j < 8; ++j) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; tab[i] = c; }
+		auto mul = [](u32 a, u32 b) { u32 m = 1u << 31, p = 0; for (;;) { if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; } m >>= 1; b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1; } return p; };
+		u32 p = 1u << 30; tab[256] = p;
+		for (u32 k = 1; k < 32; ++k) { p = mul(p, p); tab[256 + k] = p; }
+		HIPCHK(hipMalloc((void**)&h->d_crc_tab, sizeof(tab)));
+		HIPCHK(hipMemcpy(h->d_crc_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
+	}
+	if (arena_bytes) { rc = ensure_arena(h, (size_t)arena_bytes); if (rc) return rc; }
+	return DSRCGPU_OK;
+}
+
+void dsrcgpu_destroy(dsrcgpu_handle* h)
+{
+	if (!h) return;
+	for (auto& d : h->done) free(d.block);
+	if (h->arena.base) hipFree(h->arena.base);
+	if (h->d_crc_tab) hipFree(h->d_crc_tab);
+	for (int i = 0; i < 4; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+	if (h->stream) hipStreamDestroy(h->stream);
+	delete h;
+}
+
+const char* dsrcgpu_last_error(const dsrcgpu_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int dsrcgpu_compress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_fastq, const uint64_t* offs, const uint64_t* sizes,
+								  void* d_blocks, uint64_t blocks_cap, uint64_t* block_offs, uint64_t* block_sizes,
+								  uint64_t* raw_sizes, uint64_t* comp_sizes)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	if (!d_fastq || !offs || !sizes || !d_blocks || !block_offs || !block_sizes || !raw_sizes || !comp_sizes) return fail(h, DSRCGPU_E_ARG, "null argument");
+	for (u32 i = 0; i < n; ++i) if (offs[i] % 16) return fail(h, DSRCGPU_E_ARG, "chunk %u: offset %llu is not 16-byte aligned", i, (unsigned long long)offs[i]);
+	HIPCHK(hipSetDevice(h->device));
+	int rc = ensure_arena(h, estimate_arena(h, n, sizes));
+	if (rc) return rc;
+	BatchIO io{(const u8*)d_fastq, offs, sizes, n, (u8*)d_blocks, blocks_cap, nullptr, 0, block_offs, block_sizes, raw_sizes, comp_sizes};
+	return run_batch(h, io);
+}
+
+int dsrcgpu_compress_batch(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* fastq, const uint64_t* sizes,
+						   uint8_t* blocks, uint64_t blocks_cap, uint64_t* block_offs, uint64_t* block_sizes,
+						   uint64_t* raw_sizes, uint64_t* comp_sizes)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	if (!fastq || !sizes || !blocks || !block_offs || !block_sizes || !raw_sizes || !comp_sizes) return fail(h, DSRCGPU_E_ARG, "null argument");
+	if (n == 0) return DSRCGPU_OK;
+	HIPCHK(hipSetDevice(h->device));
+	std::vector<u64> offs(n);
+	size_t in_bytes = 0;
+	for (u32 i = 0; i < n; ++i) { offs[i] = in_bytes; in_bytes += al((size_t)sizes[i] + 16, 256); }
+	int rc = ensure_arena(h, estimate_arena(h, n, sizes) + in_bytes);
+	if (rc) return rc;
+	const size_t o_in = h->arena.alloc(in_bytes + 256);
+	if (h->arena.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (input)");
+	u8* d_in = h->arena.base + o_in;
+	for (u32 i = 0; i < n; ++i) HIPCHK(hipMemcpyAsync(d_in + offs[i], fastq[i], sizes[i], hipMemcpyHostToDevice, h->stream));
+	BatchIO io{d_in, offs.data(), sizes, n, nullptr, 0, blocks, blocks_cap, block_offs, block_sizes, raw_sizes, comp_sizes};
+	return run_batch(h, io);
+}
+
+int dsrcgpu_compress_block(dsrcgpu_handle* h, const uint8_t* fastq, uint64_t size, uint8_t* block, uint64_t block_cap, uint64_t* block_size,
+						   uint64_t raw_sizes[4], uint64_t comp_sizes[4])
+{
+	if (!h) return DSRCGPU_E_ARG;
+	if (!block_size) return fail(h, DSRCGPU_E_ARG, "null argument");
+	u64 off = 0;
+	const uint8_t* ins[1] = {fastq};
+	return dsrcgpu_compress_batch(h, 1, ins, &size, block, block_cap, &off, block_size, raw_sizes, comp_sizes);
+}
+
+int dsrcgpu_submit(dsrcgpu_handle* h, int64_t part_id, const uint8_t* fastq, uint64_t size)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	if (!fastq || size == 0) return fail(h, DSRCGPU_E_ARG, "empty chunk");
+	Pending p; p.part_id = part_id; p.data.assign(fastq, fastq + size);
+	h->pending.push_back(std::move(p));
+	return DSRCGPU_OK;
+}
+
+int dsrcgpu_flush(dsrcgpu_handle* h)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	const u32 n = (u32)h->pending.size();
+	if (n == 0) return DSRCGPU_OK;
+	std::vector<const uint8_t*> ins(n); std::vector<u64> sizes(n), offs(n), osz(n), raw(4 * n), comp(4 * n);
+	u64 cap = 0;
+	for (u32 i = 0; i < n; ++i) { ins[i] = h->pending[i].data.data(); sizes[i] = h->pending[i].data.size(); cap += sizes[i] + (1u << 16); }
+	std::vector<u8> out(cap);
+	int rc = dsrcgpu_compress_batch(h, n, ins.data(), sizes.data(), out.data(), cap, offs.data(), osz.data(), raw.data(), comp.data());
+	if (rc) return rc;
+	for (u32 i = 0; i < n; ++i)
+	{
+		Done d; d.part_id = h->pending[i].part_id; d.size = osz[i];
+		d.block = (u8*)malloc(osz[i] ? osz[i] : 1);
+		memcpy(d.block, out.data() + offs[i], osz[i]);
+		for (int k = 0; k < 4; ++k) { d.raw[k] = raw[4 * i + k]; d.comp[k] = comp[4 * i + k]; }
+		h->done.push_back(d);
+	}
+	h->pending.clear();
+	return DSRCGPU_OK;
+}
+
+int dsrcgpu_collect(dsrcgpu_handle* h, int64_t* part_id, uint8_t** block, uint64_t* block_size, uint64_t raw_sizes[4], uint64_t comp_sizes[4])
+{
+	if (!h) return DSRCGPU_E_ARG;
+	if (!part_id || !block || !block_size) return fail(h, DSRCGPU_E_ARG, "null argument");
+	if (h->done.empty()) return 0;
+	Done d = h->done.front(); h->done.pop_front();
+	*part_id = d.part_id; *block = d.block; *block_size = d.size;
+	for (int k = 0; k < 4; ++k) { if (raw_sizes) raw_sizes[k] = d.raw[k]; if (comp_sizes) comp_sizes[k] = d.comp[k]; }
+	return 1;
+}
+
+int dsrcgpu_release(dsrcgpu_handle* h, uint8_t* block) { (void)h; free(block); return DSRCGPU_OK; }
+
+int dsrcgpu_last_timing(const dsrcgpu_handle* h, float* batch_ms, float* rc_ms, uint32_t* rc_launches)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	if (batch_ms) *batch_ms = h->batch_ms;
+	if (rc_ms) *rc_ms = h->rc_ms;
+	if (rc_launches) *rc_launches = h->rc_launches;
+	return DSRCGPU_OK;
+}
+
+int dsrcgpu_synth_illumina(dsrcgpu_handle* h, uint64_t first, uint64_t count, void* d_out, uint64_t cap, uint64_t* bytes)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	if (!d_out || !bytes) return fail(h, DSRCGPU_E_ARG, "null argument");
+	HIPCHK(hipSetDevice(h->device));
+	return synth_illumina_device(h->stream, first, count, (u8*)d_out, cap, bytes) ? fail(h, DSRCGPU_E_CAPACITY, "synthetic FASTQ does not fit in %llu bytes", (unsigned long long)cap) : DSRCGPU_OK;
+}
+
+int dsrcgpu_dev_alloc(dsrcgpu_handle* h, uint64_t bytes, void** d_ptr)
+{
+	if (!h || !d_ptr) return DSRCGPU_E_ARG;
+	HIPCHK(hipSetDevice(h->device));
+	hipError_t e = hipMalloc(d_ptr, bytes);
+	if (e != hipSuccess) return fail(h, DSRCGPU_E_NOMEM, "hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+	return DSRCGPU_OK;
+}
+int dsrcgpu_dev_free(dsrcgpu_handle* h, void* d_ptr) { if (!h) return DSRCGPU_E_ARG; HIPCHK(hipFree(d_ptr)); return DSRCGPU_OK; }
+int dsrcgpu_dev_upload(dsrcgpu_handle* h, void* d_dst, const void* src, uint64_t bytes) { if (!h) return DSRCGPU_E_ARG; HIPCHK(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice)); return DSRCGPU_OK; }
+int dsrcgpu_dev_download(dsrcgpu_handle* h, void* dst, const void* d_src, uint64_t bytes) { if (!h) return DSRCGPU_E_ARG; HIPCHK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost)); return DSRCGPU_OK; }
+
+} // extern "C"

@@ -1,0 +1,86 @@
+// Wave / workgroup primitives shared by every kernel of the block-compression path.
+// gfx950: 64-lane wavefronts; a workgroup of DSRC_WG threads owns one FASTQ block.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dsrc_types.h"
+
+#define WG DSRC_WG
+#define WAVES DSRC_WAVES
+
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ u32 wave_id() { return threadIdx.x >> 6; }
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+__device__ __forceinline__ u32 wave_incl_scan(u32 v)
+{
+	const u32 l = lane_id();
+	for (u32 d = 1; d < 64; d <<= 1)
+	{
+		u32 t = __shfl_up(v, d);
+		if (l >= d) v += t;
+	}
+	return v;
+}
+
+__device__ __forceinline__ u32 wave_max(u32 v)
+{
+	for (u32 d = 32; d >= 1; d >>= 1) { u32 t = __shfl_xor(v, (int)d); v = t > v ? t : v; }
+	return v;
+}
+
+__device__ __forceinline__ u32 wave_sum(u32 v)
+{
+	for (u32 d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, (int)d);
+	return v;
+}
+
+// exclusive scan over the workgroup (must be called by every thread); *total = sum of all v
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32* total)
+{
+	__shared__ u32 s_w[WAVES];
+	const u32 inc = wave_incl_scan(v);
+	if (lane_id() == 63) s_w[wave_id()] = inc;
+	__syncthreads();
+	u32 base = 0, tot = 0;
+	for (u32 i = 0; i < (blockDim.x >> 6); ++i)
+	{
+		const u32 x = s_w[i];
+		if (i < wave_id()) base += x;
+		tot += x;
+	}
+	__syncthreads();
+	*total = tot;
+	return base + inc - v;
+}
+
+// ---- compressed-stream staging ---------------------------------------------------------
+// A stream is staged as u32 words holding the MSB-first bit stream "logically big-endian":
+// stream byte k lives at ((u8*)words)[k ^ 3]; k_assemble undoes that when it copies the
+// four streams of a block into place.  Bit writers OR into zero-initialised words.
+__device__ __forceinline__ void put_bits(u32* words, u64 bitpos, u32 code, u32 len)
+{
+	if (len == 0) return;
+	if (len < 32) code &= (1u << len) - 1u;
+	const u64 w = bitpos >> 5;
+	const u32 sh = (u32)bitpos & 31u;
+	const u64 v = (u64)code << (64u - len - sh);
+	atomicOr(&words[w], (u32)(v >> 32));
+	const u32 lo = (u32)v;
+	if (lo) atomicOr(&words[w + 1], lo);
+}
+
+__device__ __forceinline__ void put_byte(u32* words, u64 k, u32 v) { ((u8*)words)[k ^ 3ull] = (u8)v; }
+__device__ __forceinline__ void put_be32(u32* words, u64 k, u32 v)
+{
+	put_byte(words, k, v >> 24); put_byte(words, k + 1, v >> 16); put_byte(words, k + 2, v >> 8); put_byte(words, k + 3, v);
+}
+
+// core::bit_length (src/utils.h:181-189)
+__device__ __forceinline__ u32 bit_length32(u64 x)
+{
+	for (u32 i = 0; i < 32; ++i)
+		if (x < (1ull << i)) return i;
+	return 64;
+}
+
+__device__ __forceinline__ u32 ilog2_floor(u32 x) { u32 r = 0; while (x > 1) { x >>= 1; ++r; } return r; }

@@ -1,0 +1,323 @@
+// k_index: FASTQ chunk -> record index            (FastqParser::ParseFrom, src/FastqParser.cpp:140-164)
+// k_prep : per-base transform + block statistics   (Lossless/LossyRecordsProcessor::ProcessForward,
+//                                                    src/RecordsProcessor.cpp:209-267,344-408; FinalizeStats :112-133)
+//
+// Layout: the raw chunk text stays where the host put it (read twice, coalesced 16 B/lane);
+// the index is SoA (line starts, per-record offsets/lengths); the transformed symbols go to
+// two dense per-block streams (quality, DNA) so that every later stage is a flat array pass.
+#pragma once
+#include "k_common.h"
+
+// A byte is the LAST byte of a line terminator iff it is '\n', or a '\r' not followed by '\n'
+// (SkipLine, src/FastqParser.h:93-115: "\r\n", "\n" and a lone "\r" all end a line).
+__device__ __forceinline__ bool is_term_last(const u8* p, u64 i, u64 size)
+{
+	const u8 c = p[i];
+	if (c == '\n') return true;
+	if (c == '\r') return !(i + 1 < size && p[i + 1] == '\n');
+	return false;
+}
+
+// ---- pass 1: count terminators per 16 KiB tile -------------------------------------------
+__global__ void __launch_bounds__(WG) k_count_lines(const u8* in, const BlkDesc* desc, BlkState* st, u32* tile_cnt, DsrcParams prm)
+{
+	const u32 b = blockIdx.y, tile = blockIdx.x;
+	const BlkDesc d = desc[b];
+	if (tile >= d.n_tiles) return;
+	const u8* p = in + d.in_off;
+	const u64 size = d.in_size;
+	const u64 base = (u64)tile * DSRC_TILE_BYTES + (u64)threadIdx.x * 16;
+	u32 cnt = 0, crlf = 0;
+	for (u32 k = 0; k < 16; ++k)
+	{
+		const u64 i = base + k;
+		if (i < size)
+		{
+			cnt += is_term_last(p, i, size) ? 1u : 0u;
+			crlf += (p[i] == '\n' && i > 0 && p[i - 1] == '\r') ? 1u : 0u;
+		}
+	}
+	u32 total;
+	block_excl_scan(cnt, &total);
+	u32 total_crlf;
+	block_excl_scan(crlf, &total_crlf);
+	if (threadIdx.x == 0)
+	{
+		tile_cnt[(u64)b * prm.max_tiles + tile] = total;
+		atomicAdd(&st[b].n_term, total);
+		if (total_crlf) atomicAdd(&st[b].n_crlf, total_crlf);
+	}
+}
+
+// ---- pass 2: exclusive scan of the tile counts of one block (in place) --------------------
+__global__ void __launch_bounds__(WG) k_scan_tiles(const BlkDesc* desc, u32* tile_cnt, DsrcParams prm)
+{
+	const u32 b = blockIdx.x;
+	const u32 n = desc[b].n_tiles;
+	u32* t = tile_cnt + (u64)b * prm.max_tiles;
+	u32 carry = 0;
+	for (u32 base = 0; base < n; base += blockDim.x)
+	{
+		const u32 i = base + threadIdx.x;
+		const u32 v = i < n ? t[i] : 0;
+		u32 tot;
+		const u32 ex = block_excl_scan(v, &tot);
+		if (i < n) t[i] = carry + ex;
+		carry += tot;
+	}
+}
+
+// ---- pass 3: line starts ------------------------------------------------------------------
+__global__ void __launch_bounds__(WG) k_index_lines(const u8* in, const BlkDesc* desc, const u32* tile_base, u32* line_start, DsrcParams prm)
+{
+	const u32 b = blockIdx.y, tile = blockIdx.x;
+	const BlkDesc d = desc[b];
+	if (tile >= d.n_tiles) return;
+	const u8* p = in + d.in_off;
+	const u64 size = d.in_size;
+	const u64 base = (u64)tile * DSRC_TILE_BYTES + (u64)threadIdx.x * 16;
+	u32 mask = 0;
+	for (u32 k = 0; k < 16; ++k)
+	{
+		const u64 i = base + k;
+		if (i < size && is_term_last(p, i, size)) mask |= 1u << k;
+	}
+	u32 total;
+	u32 rank = block_excl_scan((u32)__popc(mask), &total) + tile_base[(u64)b * prm.max_tiles + tile];
+	u32* ls = line_start + d.line_base;
+	if (tile == 0 && threadIdx.x == 0) ls[0] = 0;
+	while (mask)
+	{
+		const u32 k = (u32)__ffs((int)mask) - 1;
+		mask &= mask - 1;
+		ls[++rank] = (u32)(base + k + 1);
+	}
+}
+
+// per-record SoA index
+struct RecPools
+{
+	u32* title_off; u32* seq_off; u32* qual_off;
+	u16* title_len; u16* len;            // sequenceLen == qualityLen for every valid record
+	u16* kept; u16* trunc;               // after preprocessing: kept bases, truncatedLen
+	u32* q_off; u32* d_off;              // exclusive prefix of len / kept inside the block's streams
+};
+
+__device__ __forceinline__ void line_extent(const u8* p, const u32* ls, u32 n_term, u32 size, u32 i, u32* start, u32* len)
+{
+	if (i > n_term) { *start = size; *len = 0; return; }
+	const u32 s = ls[i];
+	*start = s;
+	if (i == n_term) { *len = size - s; return; }           // last line: no terminator (chunk.size excludes it)
+	const u32 ns = ls[i + 1];
+	u32 e = ns - 1;                                            // last byte of the terminator
+	if (p[e] == '\n' && e > s && p[e - 1] == '\r') e -= 1;     // "\r\n"
+	*len = e - s;
+}
+
+// ---- pass 4: records = 4 lines; validate like ReadNextRecord (src/FastqParser.h:40-60) -----
+__global__ void __launch_bounds__(WG) k_records(const u8* in, const BlkDesc* desc, BlkState* st, const u32* line_start, RecPools rp)
+{
+	const u32 b = blockIdx.y;
+	const BlkDesc d = desc[b];
+	const u32 n_term = st[b].n_term;
+	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+	const u32 n_cand = (n_term + 1 + 3) / 4;
+	if (r >= n_cand || r >= d.rec_cap) return;
+	const u8* p = in + d.in_off;
+	const u32* ls = line_start + d.line_base;
+	u32 s0, l0, s1, l1, s2, l2, s3, l3;
+	line_extent(p, ls, n_term, d.in_size, 4 * r + 0, &s0, &l0);
+	line_extent(p, ls, n_term, d.in_size, 4 * r + 1, &s1, &l1);
+	line_extent(p, ls, n_term, d.in_size, 4 * r + 2, &s2, &l2);
+	line_extent(p, ls, n_term, d.in_size, 4 * r + 3, &s3, &l3);
+	const bool ok = s0 < d.in_size && l0 > 0 && p[s0] == '@' && l2 > 0 && l1 == l3;
+	if (!ok) atomicMin(&st[b].first_bad, r);
+	if (l0 > 65535u || l1 > 65535u || l3 > 65535u) atomicOr(&st[b].err, (u32)DSRC_ERR_LONG_LINE);
+	const u64 g = (u64)d.rec_base + r;
+	rp.title_off[g] = s0; rp.title_len[g] = (u16)l0;
+	rp.seq_off[g] = s1;   rp.len[g] = (u16)l1;
+	rp.qual_off[g] = s3;
+}
+
+// base -> index LUT (src/RecordsProcessor.cpp:186-206): A0 G1 C2 T3 N4 R5 W6 S7 K8 M9 D10 V11 H12 B13 Y14 X15 U16 .17 -18
+__device__ __forceinline__ u32 dna_index(u32 c)
+{
+	switch (c)
+	{
+	case 'A': return 0; case 'G': return 1; case 'C': return 2; case 'T': return 3; case 'N': return 4;
+	case 'R': return 5; case 'W': return 6; case 'S': return 7; case 'K': return 8; case 'M': return 9;
+	case 'D': return 10; case 'V': return 11; case 'H': return 12; case 'B': return 13; case 'Y': return 14;
+	case 'X': return 15; case 'U': return 16; case '.': return 17; case '-': return 18;
+	default: return 255;
+	}
+}
+
+// lossy Illumina 8-bin quantiser (src/RecordsProcessor.cpp:318-341)
+__device__ __forceinline__ u32 lossy_bin(u32 q)
+{
+	if (q < 2) return 0; if (q < 10) return 1; if (q < 20) return 2; if (q < 25) return 3;
+	if (q < 30) return 4; if (q < 35) return 5; if (q < 40) return 6; if (q < 64) return 7;
+	return 255;
+}
+
+// one base: returns transformed quality, sets *keep / *sidx
+__device__ __forceinline__ u32 transform_base(u32 base, u32 qual, u32 qoff, u32 lossy, u32* sidx, bool* keep)
+{
+	const u32 s = dna_index(base);
+	*sidx = s;
+	u32 q;
+	if (!lossy)
+	{
+		q = (qual - qoff) & 255u;
+		if (s > 3 && q < 7) { q = (q + 128u + ((s - 2u) << 3) - 16u) & 255u; *keep = false; }
+		else *keep = true;
+	}
+	else
+	{
+		q = lossy_bin((qual - qoff) & 255u);
+		if (s >= 4) { q = 0; *keep = false; }
+		else { if (q == 0) q = 1; *keep = true; }
+	}
+	return q;
+}
+
+// ---- pass 5: statistics, one workgroup per block, one wave per record ------------------------
+__global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* desc, BlkState* st, RecPools rp, DsrcParams prm)
+{
+	__shared__ u32 s_qf[256];
+	__shared__ u32 s_df[20];
+	__shared__ u32 s_acc[8];      // rle, th, raw(qual), min, max, raw_tag, raw_dna, bad_base
+	const u32 b = blockIdx.x;
+	const BlkDesc d = desc[b];
+	const u8* p = in + d.in_off;
+	u32 n_cand = (st[b].n_term + 1 + 3) / 4;
+	if (n_cand > d.rec_cap) n_cand = d.rec_cap;
+	const u32 n_recs = st[b].first_bad < n_cand ? st[b].first_bad : n_cand;
+
+	for (u32 i = threadIdx.x; i < 256; i += blockDim.x) s_qf[i] = 0;
+	if (threadIdx.x < 20) s_df[threadIdx.x] = 0;
+	if (threadIdx.x < 8) s_acc[threadIdx.x] = (threadIdx.x == 3) ? 0xFFFFFFFFu : 0u;
+	__syncthreads();
+
+	const u32 lane = lane_id();
+	u32 a_rle = 0, a_th = 0, a_raw = 0, a_min = 0xFFFFFFFFu, a_max = 0, a_tag = 0, a_bad = 0;
+	for (u32 r = wave_id(); r < n_recs; r += (blockDim.x >> 6))
+	{
+		const u64 g = (u64)d.rec_base + r;
+		const u32 len = rp.len[g], so = rp.seq_off[g], qo = rp.qual_off[g];
+		u32 kept = 0, th = 0, rle = 0, carry = 255, lastq = 255;
+		for (u32 j0 = 0; j0 < len; j0 += 64)
+		{
+			const u32 j = j0 + lane;
+			const bool in_r = j < len;
+			u32 sidx = 0, q = 0; bool keep = false;
+			if (in_r) q = transform_base(p[so + j], p[qo + j], prm.quality_offset, prm.lossy, &sidx, &keep);
+			const bool k2 = in_r && keep;
+			if (in_r) atomicAdd(&s_qf[q], 1u);
+			if (in_r && sidx >= 20) a_bad = 1;
+			if (k2 && sidx < 20) atomicAdd(&s_df[sidx], 1u);
+			kept += (u32)__popcll(__ballot(k2));
+			u32 prev = __shfl_up(q, 1);
+			if (lane == 0) prev = carry;
+			rle += (u32)__popcll(__ballot(in_r && q != prev));
+			const u64 m2 = __ballot(in_r && q != 2);
+			if (m2) th = j0 + 63u - (u32)__clzll((long long)m2);
+			carry = __shfl(q, 63);
+			const u32 last_lane = (len - 1 - j0) < 64u ? (len - 1 - j0) : 63u;
+			lastq = __shfl(q, (int)last_lane);
+		}
+		if (len > 0 && lastq == 2 && rle > 0) rle -= 1;     // per-record decrement (Appendix B.13)
+		if (lane == 0)
+		{
+			rp.kept[g] = (u16)kept;
+			rp.trunc[g] = (u16)(th + (len > 0 ? 1u : 0u));
+			a_rle += rle; a_th += th; a_raw += len; a_tag += rp.title_len[g];
+			a_min = len < a_min ? len : a_min; a_max = len > a_max ? len : a_max;
+		}
+	}
+	if (lane == 0)
+	{
+		atomicAdd(&s_acc[0], a_rle); atomicAdd(&s_acc[1], a_th); atomicAdd(&s_acc[2], a_raw);
+		atomicMin(&s_acc[3], a_min); atomicMax(&s_acc[4], a_max); atomicAdd(&s_acc[5], a_tag);
+	}
+	if (a_bad) atomicOr(&s_acc[7], 1u);
+	__syncthreads();
+
+	BlkState* S = &st[b];
+	for (u32 i = threadIdx.x; i < 256; i += blockDim.x) S->q_freq[i] = s_qf[i];
+	if (threadIdx.x < 20) S->d_freq[threadIdx.x] = s_df[threadIdx.x];
+	if (threadIdx.x == 0)
+	{
+		S->n_recs = n_recs;
+		S->n_lines = S->n_term + 1;
+		S->rle_len = s_acc[0]; S->th_len = s_acc[1]; S->raw_len = s_acc[2];
+		S->min_len = s_acc[3]; S->max_len = s_acc[4];
+		S->raw_tag = s_acc[5]; S->raw_dna = s_acc[2]; S->raw_qua = s_acc[2];
+		u32 e = 0;
+		if (n_recs == 0) e |= DSRC_ERR_NO_RECORDS;
+		if (s_acc[7]) e |= DSRC_ERR_BAD_BASE;
+		if (e) atomicOr(&S->err, e);
+		// FinalizeStats (src/RecordsProcessor.cpp:112-133): dense ranks of the present symbols
+		u32 dc = 0, qc = 0;
+		for (u32 i = 0; i < 20; ++i) S->d_sym[i] = s_df[i] ? (u8)dc++ : (u8)255;
+		for (u32 i = 0; i < 256; ++i) S->q_sym[i] = s_qf[i] ? (u8)qc++ : (u8)255;
+		S->d_count = dc; S->q_count = qc;
+	}
+}
+
+// ---- pass 6: per-record stream offsets (exclusive scans of len / kept) ----------------------
+__global__ void __launch_bounds__(WG) k_rec_offsets(const BlkDesc* desc, BlkState* st, RecPools rp)
+{
+	const u32 b = blockIdx.x;
+	const BlkDesc d = desc[b];
+	const u32 n = st[b].n_recs;
+	u32 cq = 0, cd = 0;
+	for (u32 base = 0; base < n; base += blockDim.x)
+	{
+		const u32 r = base + threadIdx.x;
+		const u64 g = (u64)d.rec_base + r;
+		const u32 vq = r < n ? rp.len[g] : 0, vd = r < n ? rp.kept[g] : 0;
+		u32 tq, td;
+		const u32 eq = block_excl_scan(vq, &tq);
+		const u32 ed = block_excl_scan(vd, &td);
+		if (r < n) { rp.q_off[g] = cq + eq; rp.d_off[g] = cd + ed; }
+		cq += tq; cd += td;
+	}
+	if (threadIdx.x == 0) { st[b].q_total = cq; st[b].d_total = cd; }
+}
+
+// ---- pass 7: write the dense symbol streams --------------------------------------------------
+// q_stream: transformed quality value per base; qp_stream: floor(j*128/len) (position context,
+// any power-of-two rescale R is qp >> (7 - log2 R)); d_stream: kept base indices, compacted.
+__global__ void __launch_bounds__(WG) k_prep_write(const u8* in, const BlkDesc* desc, const BlkState* st, RecPools rp,
+												   u8* q_stream, u8* qp_stream, u8* d_stream, DsrcParams prm)
+{
+	const u32 b = blockIdx.y;
+	const BlkDesc d = desc[b];
+	const u8* p = in + d.in_off;
+	const u32 n_recs = st[b].n_recs;
+	const u32 lane = lane_id();
+	const u32 waves_total = gridDim.x * (blockDim.x >> 6);
+	for (u32 r = blockIdx.x * (blockDim.x >> 6) + wave_id(); r < n_recs; r += waves_total)
+	{
+		const u64 g = (u64)d.rec_base + r;
+		const u32 len = rp.len[g], so = rp.seq_off[g], qo = rp.qual_off[g];
+		u8* qs = q_stream + d.q_base + rp.q_off[g];
+		u8* qps = qp_stream + d.q_base + rp.q_off[g];
+		u8* ds = d_stream + d.d_base + rp.d_off[g];
+		u32 run = 0;
+		for (u32 j0 = 0; j0 < len; j0 += 64)
+		{
+			const u32 j = j0 + lane;
+			const bool in_r = j < len;
+			u32 sidx = 0, q = 0; bool keep = false;
+			if (in_r) q = transform_base(p[so + j], p[qo + j], prm.quality_offset, prm.lossy, &sidx, &keep);
+			const bool k2 = in_r && keep;
+			const u64 km = __ballot(k2);
+			if (in_r) { qs[j] = (u8)q; qps[j] = (u8)((j * 128u) / len); }
+			if (k2) ds[run + (u32)__popcll(km & lanemask_lt())] = (u8)sidx;
+			run += (u32)__popcll(km);
+		}
+	}
+}

@@ -1,0 +1,119 @@
+/*
+ * dsrc_gpu.h -- C ABI of the MI355X-native DSRC block-compression path (libdsrc_gpu.so).
+ *
+ * This is the drop-in boundary: plain C, opaque handle, pointers and sizes only.  It replaces the
+ * reference's CPU worker pool -- N threads each running
+ *     BlockCompressor(datasetType, compSettings)                  (src/BlockCompressor.h:66)
+ *     BlockCompressor::Store(BitMemoryWriter&, StreamsInfo& raw,
+ *                            StreamsInfo& comp, const FastqDataChunk&)   (src/BlockCompressor.h:69)
+ * inside DsrcCompressor::Process (src/DsrcWorker.cpp:30-73) -- by one GPU block scheduler.  Every
+ * function returns 0 on success or a negative DSRCGPU_E_* code; dsrcgpu_last_error() gives the text.
+ * Output blocks are bit-identical to what BlockCompressor::Store writes for the same chunk.
+ *
+ * INTEGRATION.md shows the binding a reference maintainer would add on top of this header.
+ */
+#ifndef DSRC_GPU_H
+#define DSRC_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dsrcgpu_handle dsrcgpu_handle;
+
+/* comp::CompressionSettings (src/Common.h:110-147).  Orders, not CLI levels:
+ * dna_order = 3*level; quality_order = level (lossless) or 3*level (lossy) -- IDsrcOperator::GetCompressionSettings
+ * (src/DsrcOperator.h:74-90). */
+typedef struct dsrcgpu_settings
+{
+	uint32_t dna_order;
+	uint32_t quality_order;
+	uint64_t tag_preserve_flags;   /* must be 0: the -f field filter (FastqParserExt) is not on the GPU path */
+	uint8_t  lossy;
+	uint8_t  calculate_crc32;
+	uint8_t  reserved[6];
+} dsrcgpu_settings;
+
+/* fq::FastqDatasetType (src/Common.h:56-80), decided once per file by FastqParser::Analyze on chunk 0. */
+typedef struct dsrcgpu_dataset
+{
+	uint32_t quality_offset;       /* 33..64, already resolved (not 0/auto) */
+	uint8_t  plus_repetition;
+	uint8_t  color_space;          /* must be 0: SOLiD colour space is not on the GPU path */
+	uint8_t  reserved[2];
+} dsrcgpu_dataset;
+
+enum
+{
+	DSRCGPU_OK            =  0,
+	DSRCGPU_E_ARG         = -1,   /* bad argument / unsupported setting */
+	DSRCGPU_E_HIP         = -2,   /* HIP runtime failure (text in last_error) */
+	DSRCGPU_E_NOMEM       = -3,
+	DSRCGPU_E_CAPACITY    = -4,   /* caller's output buffer too small */
+	DSRCGPU_E_INPUT       = -5,   /* a chunk could not be coded (no records, invalid bases, reference-UB input ...) */
+	DSRCGPU_E_STATE       = -6
+};
+
+/* Replaces: BlockCompressor::BlockCompressor (src/BlockCompressor.cpp:53-94) x worker threads.
+ * device: HIP device ordinal.  arena_bytes: HBM to reserve for batch scratch, 0 = grow on demand. */
+int dsrcgpu_create(const dsrcgpu_settings* settings, const dsrcgpu_dataset* dataset, int device,
+				   uint64_t arena_bytes, dsrcgpu_handle** out);
+void dsrcgpu_destroy(dsrcgpu_handle* h);
+const char* dsrcgpu_last_error(const dsrcgpu_handle* h);
+
+/* Replaces one call of BlockCompressor::Store (src/BlockCompressor.cpp:208-220) + bitMemory.Flush()
+ * (src/DsrcWorker.cpp:48-51): chunk (host memory, size = FastqDataChunk::size, i.e. without the final newline)
+ * -> block bytes.  raw_sizes/comp_sizes are fq::StreamsInfo::sizes in enum order Meta, Tag, Dna, Quality
+ * (src/Common.h:82-105).  Synchronous. */
+int dsrcgpu_compress_block(dsrcgpu_handle* h, const uint8_t* fastq, uint64_t size,
+						   uint8_t* block, uint64_t block_cap, uint64_t* block_size,
+						   uint64_t raw_sizes[4], uint64_t comp_sizes[4]);
+
+/* The same for n chunks in one scheduler pass (this is what keeps the GPU full).  Blocks are written back to
+ * back into `blocks` in chunk order; block_offs/block_sizes get n entries, raw_sizes/comp_sizes 4*n.
+ * Compressor state that the reference carries from block to block inside one BlockCompressor (the capacity of
+ * TagStats::fields) advances in chunk order, as with `dsrc c -t1`. */
+int dsrcgpu_compress_batch(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* fastq, const uint64_t* sizes,
+						   uint8_t* blocks, uint64_t blocks_cap, uint64_t* block_offs, uint64_t* block_sizes,
+						   uint64_t* raw_sizes, uint64_t* comp_sizes);
+
+/* Device-resident variant: d_fastq is a HIP device pointer; chunk i is [offs[i], offs[i]+sizes[i]) with
+ * offs[i] % 16 == 0.  d_blocks (device, blocks_cap bytes) receives the blocks back to back.  No host<->device
+ * payload copies happen inside this call; it is what bench.py times. */
+int dsrcgpu_compress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_fastq, const uint64_t* offs,
+								  const uint64_t* sizes, void* d_blocks, uint64_t blocks_cap,
+								  uint64_t* block_offs, uint64_t* block_sizes,
+								  uint64_t* raw_sizes, uint64_t* comp_sizes);
+
+/* Queue form of DsrcCompressor::Process (src/DsrcWorker.cpp:39-70):
+ *   fastqQueue.Pop(partId, chunk)            -> dsrcgpu_submit(partId, chunk)      (chunk bytes are copied)
+ *   ... Store ... dsrcQueue.Push(partId, blk) -> dsrcgpu_collect(&partId, &blk, ...)
+ *   dsrcPool.Release(blk)                    -> dsrcgpu_release(blk)
+ * dsrcgpu_flush runs everything submitted so far; dsrcgpu_collect returns 1 and a block while results are
+ * pending (in partId order of submission), 0 when drained. */
+int dsrcgpu_submit(dsrcgpu_handle* h, int64_t part_id, const uint8_t* fastq, uint64_t size);
+int dsrcgpu_flush(dsrcgpu_handle* h);
+int dsrcgpu_collect(dsrcgpu_handle* h, int64_t* part_id, uint8_t** block, uint64_t* block_size,
+					uint64_t raw_sizes[4], uint64_t comp_sizes[4]);
+int dsrcgpu_release(dsrcgpu_handle* h, uint8_t* block);
+
+/* Timing of the last batch measured with HIP events on the scheduler's stream: total ms of the batch's
+ * kernels, ms of the range-coder kernel (k_rc), number of k_rc launches. */
+int dsrcgpu_last_timing(const dsrcgpu_handle* h, float* batch_ms, float* rc_ms, uint32_t* rc_launches);
+
+/* Counter-based synthetic Illumina-like FASTQ generated directly in HBM (bench input; same bytes as
+ * dsrc_amd/synth.py illumina_fastq).  Writes records first..first+count-1, returns the byte count. */
+int dsrcgpu_synth_illumina(dsrcgpu_handle* h, uint64_t first, uint64_t count, void* d_out, uint64_t cap, uint64_t* bytes);
+
+/* small HBM helpers so that non-HIP hosts (Python/ctypes, JNI ...) can stage device-resident batches */
+int dsrcgpu_dev_alloc(dsrcgpu_handle* h, uint64_t bytes, void** d_ptr);
+int dsrcgpu_dev_free(dsrcgpu_handle* h, void* d_ptr);
+int dsrcgpu_dev_upload(dsrcgpu_handle* h, void* d_dst, const void* src, uint64_t bytes);
+int dsrcgpu_dev_download(dsrcgpu_handle* h, void* dst, const void* d_src, uint64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSRC_GPU_H */
