@@ -626,7 +626,6 @@ int dsrcgpu_compress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_f
 {
 	if (!h) return DSRCGPU_E_ARG;
 	if (!d_fastq || !offs || !sizes || !d_blocks || !block_offs || !block_sizes || !raw_sizes || !comp_sizes) return fail(h, DSRCGPU_E_ARG, "null argument");
-	for (u32 i = 0; i < n; ++i) if (offs[i] % 16) return fail(h, DSRCGPU_E_ARG, "chunk %u: offset %llu is not 16-byte aligned", i, (unsigned long long)offs[i]);
 	HIPCHK(hipSetDevice(h->device));
 	int rc = ensure_arena(h, estimate_arena(h, n, sizes));
 	if (rc) return rc;

@@ -79,8 +79,8 @@ int dsrcgpu_compress_batch(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* 
 						   uint8_t* blocks, uint64_t blocks_cap, uint64_t* block_offs, uint64_t* block_sizes,
 						   uint64_t* raw_sizes, uint64_t* comp_sizes);
 
-/* Device-resident variant: d_fastq is a HIP device pointer; chunk i is [offs[i], offs[i]+sizes[i]) with
- * offs[i] % 16 == 0.  d_blocks (device, blocks_cap bytes) receives the blocks back to back.  No host<->device
+/* Device-resident variant: d_fastq is a HIP device pointer; chunk i is [offs[i], offs[i]+sizes[i]).
+ * d_blocks (device, blocks_cap bytes) receives the blocks back to back.  No host<->device
  * payload copies happen inside this call; it is what bench.py times. */
 int dsrcgpu_compress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_fastq, const uint64_t* offs,
 								  const uint64_t* sizes, void* d_blocks, uint64_t blocks_cap,

@@ -1,0 +1,68 @@
+"""Shared parity cases: (name, d, q, lossy, crc, generator) used by the emulator tests (CPU) and the GPU tests."""
+from __future__ import annotations
+
+import random
+
+from dsrc_amd import synth
+
+TINY = (b"@SEQ.1 lane:1:10:100\nACGTACGTAC\n+\nIIIIHHGG##\n@SEQ.2 lane:1:12:205\nTTGCANNGTA\n+\nIIFF##!!CC\n"
+        b"@SEQ.3 lane:1:15:317\nGGGGCCCCAA\n+\nABCDEFGHII\n@SEQ.4 lane:2:11:90\nACACACACGT\n+\nIIIIIIII##")
+
+LEVELS = [(0, 0, False, False), (3, 2, False, False), (2, 1, True, False), (0, 0, False, True), (1, 1, False, False),
+          (0, 0, True, False), (3, 2, True, False), (2, 2, False, True), (0, 2, False, False), (3, 0, False, False)]
+
+
+def fuzz_fastq(seed: int, nrec: int | None = None):
+    """Diverse small FASTQ chunks: every quality/DNA/tag scheme of the reference is reachable.
+    Returns (chunk_bytes_without_final_newline, description)."""
+    rng = random.Random(seed)
+    if nrec is None:
+        nrec = rng.choice([2, 3, 10, 300, 1200])
+    style = rng.choice(['illumina', 'casava', 'sra', 'weird', 'mixed', 'strlen'])
+    varlen = rng.random() < 0.4
+    L0 = rng.choice([1, 5, 36, 76, 100, 151, 250])
+    qmode = rng.choice(['wide', 'binned', 'tails', 'runs', 'const', 'few'])
+    nmode = rng.choice(['none', 'lowq', 'highq', 'iupac'])
+    crlf = rng.random() < 0.15
+    nl = b'\r\n' if crlf else b'\n'
+    out = []
+    x = rng.randrange(1000); lane = 1
+    for i in range(nrec):
+        L = rng.randrange(max(1, L0 // 2), L0 + 1) if varlen else L0
+        if style == 'illumina':
+            if rng.random() < 0.3: x = rng.randrange(20000)
+            if rng.random() < 0.01: lane += 1
+            t = b"@HWI-ST%d:%d:FC:%d:%d:%d:%d 1:N:0:%s" % (700, 33, lane, 1101 + i // 50, x, (i * 37) % 5000, rng.choice([b'ACGT', b'ACGT', b'TTAG']))
+        elif style == 'casava':
+            t = b"@M00123_%d/%d" % (i * 3 + 7, 1 + (i & 1))
+        elif style == 'sra':
+            t = b"@SRR%d.%d %d length=%d" % (1234, i + 1, i + 1, L)
+        elif style == 'weird':
+            t = b"@r%04d#%s=%d,%d" % (i, rng.choice([b'a', b'bb', b'ccc']), rng.randrange(3), 1000000 + rng.randrange(600))
+        elif style == 'strlen':
+            t = b"@id_%s %d %s" % (bytes(rng.choice(b'abcdefgh') for _ in range(rng.randrange(1, 9))), rng.randrange(40, 60), rng.choice([b'x:y', b'x:yy', b'xq:z']))
+        else:
+            t = rng.choice([b"@a.%d b" % i, b"@a.%d" % i, b"@a_%d b:c" % i]) if i > 3 else b"@a.%d b" % i
+        alpha = b'ACGTNRWS' if nmode == 'iupac' else b'ACGT'
+        seq = bytearray(rng.choice(alpha) for _ in range(L))
+        if qmode == 'wide': q = [rng.randrange(2, 41) for _ in range(L)]
+        elif qmode == 'binned': q = [rng.choice([2, 11, 25, 37]) for _ in range(L)]
+        elif qmode == 'few': q = [rng.choice([30, 31]) for _ in range(L)]
+        elif qmode == 'const': q = [40] * L
+        elif qmode == 'runs':
+            q = []
+            while len(q) < L: q += [rng.choice([2, 15, 30, 40])] * rng.randrange(1, 400)
+            q = q[:L]
+        else:
+            k = rng.randrange(0, L + 1) if rng.random() < 0.7 else L
+            q = [rng.randrange(20, 41) for _ in range(k)] + [2] * (L - k)
+        if nmode in ('lowq', 'highq', 'iupac'):
+            for j in range(L):
+                if rng.random() < 0.03:
+                    if nmode != 'iupac': seq[j] = ord('N')
+                    q[j] = rng.randrange(0, 7) if nmode == 'lowq' else rng.randrange(0, 41)
+                elif nmode == 'iupac' and seq[j] in b'NRWS' and rng.random() < 0.5:
+                    q[j] = rng.randrange(0, 7)
+        out += [t, nl, bytes(seq), nl, b'+', nl, bytes(v + 33 for v in q), nl]
+    data = b''.join(out)
+    return data[:-len(nl)], (style, varlen, L0, qmode, nmode, crlf)

@@ -1,0 +1,101 @@
+"""GPU parity: blocks from the HIP path (through the C ABI) must be bit-identical to the oracle's.
+
+Bit-exact bar: integer/byte work only, no tolerance.  Sizes are what the oracle finishes in seconds;
+full-size properties are in test_gpu_properties.py."""
+import os
+
+import pytest
+
+from dsrc_amd import synth
+from tests.cases import LEVELS, TINY, fuzz_fastq
+from tests._oracle import Config
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    os.environ.pop("DSRC_GPU_LIB", None)
+    from dsrc_amd import _lib
+    _lib._lib = None
+    return _lib
+
+
+def _check(gpu, oracle, cfg, chunks):
+    h = gpu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
+    got = h.compress_batch(chunks)
+    h.close()
+    cap = 0
+    for i, c in enumerate(chunks):
+        want = oracle.compress_block(cfg, c) if i == 0 else None
+        if i == 0:
+            assert got[0][0] == want[0], "block bytes differ"
+            assert got[0][1] == want[1] and got[0][2] == want[2], "stream sizes differ"
+    return got
+
+
+@pytest.mark.parametrize("d,q,lossy,crc", LEVELS)
+def test_tiny(gpu, oracle, d, q, lossy, crc):
+    _check(gpu, oracle, Config.from_levels(d, q, lossy, crc), [TINY])
+
+
+@pytest.mark.parametrize("d,q,lossy,crc", LEVELS)
+def test_illumina_20k(gpu, oracle, d, q, lossy, crc):
+    data = synth.illumina_fastq(20000)[:-1]
+    _check(gpu, oracle, Config.from_levels(d, q, lossy, crc), [data])
+
+
+@pytest.mark.parametrize("d,q,lossy,crc", [(2, 1, True, False), (0, 0, False, False), (0, 2, False, False), (0, 1, False, True)])
+def test_iontorrent_5k(gpu, oracle, d, q, lossy, crc):
+    data = synth.iontorrent_fastq(5000)[:-1]
+    _check(gpu, oracle, Config.from_levels(d, q, lossy, crc), [data])
+
+
+def test_batch_of_blocks_with_state(gpu, oracle):
+    """Several chunks in one scheduler pass; compressor state advances in chunk order like `dsrc c -t1`."""
+    import ctypes as C
+    from tests._oracle import _orc_cfg
+    chunks = [synth.illumina_fastq(3000, first=1 + 3000 * k)[:-1] for k in range(5)] + [synth.iontorrent_fastq(800)[:-1]]
+    for d, q in ((3, 2), (0, 0)):
+        cfg = Config.from_levels(d, q)
+        h = gpu.Handle(cfg.dna_order, cfg.quality_order)
+        got = h.compress_batch(chunks)
+        h.close()
+        cap = C.c_uint32(0)
+        c = _orc_cfg(cfg)
+        for i, ch in enumerate(chunks):
+            out = (C.c_uint8 * (len(ch) + 65536))(); osz = C.c_uint64(); raw = (C.c_uint64 * 4)(); comp = (C.c_uint64 * 4)()
+            rc = oracle.lib.orc_compress_block_state(C.byref(c), C.byref(cap), ch, C.c_uint64(len(ch)), out, C.c_uint64(len(out)), C.byref(osz), raw, comp)
+            assert rc == 0
+            assert got[i][0] == bytes(out[:osz.value]), f"chunk {i} differs at -d{d} -q{q}"
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz(gpu, oracle, seed):
+    data, desc = fuzz_fastq(seed)
+    for d, q, lossy, crc in [(0, 0, False, False), (3, 2, False, True), (2, 1, True, False), (1, 1, False, False), (0, 0, True, False)]:
+        cfg = Config.from_levels(d, q, lossy, crc)
+        try:
+            want = oracle.compress_block(cfg, data)
+        except RuntimeError as e:
+            if "rc=-2" in str(e):      # input is undefined behaviour in the reference: the GPU path must refuse it too
+                h = gpu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc)
+                with pytest.raises(gpu.DsrcGpuError):
+                    h.compress_block(data)
+                h.close()
+                continue
+            raise
+        h = gpu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc)
+        got = h.compress_block(data)
+        h.close()
+        assert got == want, f"seed {seed} {desc} -d{d} -q{q} lossy={lossy} crc={crc}"
+
+
+def test_device_synth_matches_host(gpu):
+    h = gpu.Handle()
+    cap = 2 << 20
+    d = h.dev_alloc(cap)
+    n = h.synth_illumina(1, 3000, d, cap)
+    got = h.dev_download(d, n)
+    h.dev_free(d); h.close()
+    assert got == synth.illumina_fastq(3000)
