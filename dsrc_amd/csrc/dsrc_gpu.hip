@@ -59,6 +59,7 @@ struct dsrcgpu_handle
 	u64 arena_fixed = 0;
 	u32 fields_cap = 0;              // capacity of the reference's TagStats::fields vector, carried block to block
 	u32* d_crc_tab = nullptr;
+	u64* d_rc_magic = nullptr;      // ceil(2^48 / d), d < 65536 (k_rc)
 	std::string err;
 	std::vector<Pending> pending;
 	std::deque<Done> done;
@@ -106,7 +107,7 @@ size_t estimate_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
 	const bool rc = h->set.dna_order > 0 || h->set.quality_order > 0;
 	size_t tot = 0, mx = 0;
 	for (u32 i = 0; i < n; ++i) { tot += (size_t)sizes[i] + 4096; mx = std::max(mx, (size_t)sizes[i]); }
-	return tot * (rc ? 34 : 14) + (size_t)n * (6u << 20) + (64u << 20);
+	return tot * (rc ? 34 : 14) + (size_t)n * (2u << 20) + (16u << 20);
 }
 
 struct BatchIO
@@ -387,7 +388,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		{
 			u32 mx = 0;
 			for (u32 i = g * 64; i < std::min(NJ, g * 64 + 64); ++i) mx = std::max(mx, jobs[i].n);
-			gbase[g] = trip_words; trip_words += (size_t)mx * 64;
+			gbase[g] = trip_words; trip_words += (size_t)mx * (std::min(NJ, g * 64 + 64) - g * 64);
 		}
 		const size_t o_trip = A.alloc(trip_words * 8 + 64);
 		for (u32 i = 0; i < NJ; ++i)
@@ -398,8 +399,9 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			j.sorted_in_b = j.passes & 1;
 			j.elems = A.alloc((size_t)j.n * 8 + 64) / 8; j.elems_b = A.alloc((size_t)j.n * 8 + 64) / 8;
 			j.trip = o_trip / 8 + gbase[i / 64] + (i % 64);
+			j.trip_stride = std::min(NJ, (i / 64) * 64 + 64) - (i / 64) * 64;
 			RcChain& c = chains[i];
-			c.trip = j.trip; c.out_words = j.out_words; c.n = j.n; c.out_byte0 = j.out_byte0; c.out_cap = j.out_cap; c.blk = j.blk; c.is_dna = j.is_dna; c.pad = 0;
+			c.trip = j.trip; c.out_words = j.out_words; c.n = j.n; c.out_byte0 = j.out_byte0; c.out_cap = j.out_cap; c.blk = j.blk; c.is_dna = j.is_dna; c.stride = j.trip_stride;
 		}
 	}
 	const size_t o_jobs = A.alloc(sizeof(CtxJob) * std::max(1u, NJ)), o_chains = A.alloc(sizeof(RcChain) * std::max(1u, NJ));
@@ -506,20 +508,22 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			u32 hi = lo;
 			while (hi < NJ && jobs[hi].n_alpha == jobs[lo].n_alpha) ++hi;
 			const u32 cnt = hi - lo;
+			u32 mxn = 1; for (u32 i = lo; i < hi; ++i) mxn = std::max(mxn, jobs[i].n);
+			const u32 parts = std::max(1u, std::min(32u, mxn / 16384u));   // REPLAY_WG/64 waves each; >= 4k symbols per wave
 			switch (jobs[lo].n_alpha)
 			{
-			case 4:   hipLaunchKernelGGL(k_replay<4>,   dim3(cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
-			case 8:   hipLaunchKernelGGL(k_replay<8>,   dim3(cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
-			case 16:  hipLaunchKernelGGL(k_replay<16>,  dim3(cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
-			case 32:  hipLaunchKernelGGL(k_replay<32>,  dim3(cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
-			case 64:  hipLaunchKernelGGL(k_replay<64>,  dim3(cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
-			default:  hipLaunchKernelGGL(k_replay<128>, dim3(cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
+			case 4:   hipLaunchKernelGGL(k_replay<4>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
+			case 8:   hipLaunchKernelGGL(k_replay<8>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
+			case 16:  hipLaunchKernelGGL(k_replay<16>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
+			case 32:  hipLaunchKernelGGL(k_replay<32>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
+			case 64:  hipLaunchKernelGGL(k_replay<64>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
+			default:  hipLaunchKernelGGL(k_replay<128>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool); break;
 			}
 			KCHK();
 			lo = hi;
 		}
 		HIPCHK(hipEventRecord(h->ev[2], s));
-		hipLaunchKernelGGL(k_rc, dim3((NJ + 63) / 64), dim3(64), 0, s, d_chains, NJ, lpool, wpool, d_state); KCHK();
+		hipLaunchKernelGGL(k_rc, dim3((NJ + 63) / 64), dim3(64), 0, s, d_chains, NJ, lpool, wpool, d_state, h->d_rc_magic); KCHK();
 		HIPCHK(hipEventRecord(h->ev[3], s));
 		h->rc_launches = 1;
 	}
@@ -560,6 +564,24 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	hipEventElapsedTime(&h->batch_ms, h->ev[0], h->ev[1]);
 	if (h->rc_launches) hipEventElapsedTime(&h->rc_ms, h->ev[2], h->ev[3]); else h->rc_ms = 0.f;
 	return DSRCGPU_OK;
+}
+
+// Arena sizes are estimated from the input sizes; if carving runs out (A.failed) the batch is simply
+// re-run with a larger arena.  Compressor state is restored so that the retry is invisible.
+template <typename F> int with_arena_retry(dsrcgpu_handle* h, size_t initial, F&& body)
+{
+	size_t need = initial;
+	const u32 saved_cap = h->fields_cap;
+	for (int attempt = 0; attempt < 5; ++attempt)
+	{
+		int rc = ensure_arena(h, need);
+		if (rc) return rc;
+		rc = body();
+		if (rc != DSRCGPU_E_NOMEM || h->arena_fixed || !h->arena.failed) return rc;
+		need = std::max(h->arena.top + h->arena.top / 4, need * 2);
+		h->fields_cap = saved_cap;
+	}
+	return fail(h, DSRCGPU_E_NOMEM, "batch does not fit in HBM scratch after 5 attempts");
 }
 
 int check_settings(dsrcgpu_handle* h, const dsrcgpu_settings* s, const dsrcgpu_dataset* d)
@@ -603,6 +625,12 @@ int dsrcgpu_create(const dsrcgpu_settings* settings, const dsrcgpu_dataset* data
 		HIPCHK(hipMalloc((void**)&h->d_crc_tab, sizeof(tab)));
 		HIPCHK(hipMemcpy(h->d_crc_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
 	}
+	{
+		std::vector<u64> mg(65536, 0);
+		for (u32 d = 1; d < 65536; ++d) mg[d] = ((1ull << 48) + d - 1) / d;
+		HIPCHK(hipMalloc((void**)&h->d_rc_magic, mg.size() * 8));
+		HIPCHK(hipMemcpy(h->d_rc_magic, mg.data(), mg.size() * 8, hipMemcpyHostToDevice));
+	}
 	if (arena_bytes) { rc = ensure_arena(h, (size_t)arena_bytes); if (rc) return rc; }
 	return DSRCGPU_OK;
 }
@@ -613,6 +641,7 @@ void dsrcgpu_destroy(dsrcgpu_handle* h)
 	for (auto& d : h->done) free(d.block);
 	if (h->arena.base) hipFree(h->arena.base);
 	if (h->d_crc_tab) hipFree(h->d_crc_tab);
+	if (h->d_rc_magic) hipFree(h->d_rc_magic);
 	for (int i = 0; i < 4; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
 	if (h->stream) hipStreamDestroy(h->stream);
 	delete h;
@@ -627,10 +656,10 @@ int dsrcgpu_compress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_f
 	if (!h) return DSRCGPU_E_ARG;
 	if (!d_fastq || !offs || !sizes || !d_blocks || !block_offs || !block_sizes || !raw_sizes || !comp_sizes) return fail(h, DSRCGPU_E_ARG, "null argument");
 	HIPCHK(hipSetDevice(h->device));
-	int rc = ensure_arena(h, estimate_arena(h, n, sizes));
-	if (rc) return rc;
-	BatchIO io{(const u8*)d_fastq, offs, sizes, n, (u8*)d_blocks, blocks_cap, nullptr, 0, block_offs, block_sizes, raw_sizes, comp_sizes};
-	return run_batch(h, io);
+	return with_arena_retry(h, estimate_arena(h, n, sizes), [&]() {
+		BatchIO io{(const u8*)d_fastq, offs, sizes, n, (u8*)d_blocks, blocks_cap, nullptr, 0, block_offs, block_sizes, raw_sizes, comp_sizes};
+		return run_batch(h, io);
+	});
 }
 
 int dsrcgpu_compress_batch(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* fastq, const uint64_t* sizes,
@@ -644,14 +673,14 @@ int dsrcgpu_compress_batch(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* 
 	std::vector<u64> offs(n);
 	size_t in_bytes = 0;
 	for (u32 i = 0; i < n; ++i) { offs[i] = in_bytes; in_bytes += al((size_t)sizes[i] + 16, 256); }
-	int rc = ensure_arena(h, estimate_arena(h, n, sizes) + in_bytes);
-	if (rc) return rc;
-	const size_t o_in = h->arena.alloc(in_bytes + 256);
-	if (h->arena.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (input)");
-	u8* d_in = h->arena.base + o_in;
-	for (u32 i = 0; i < n; ++i) HIPCHK(hipMemcpyAsync(d_in + offs[i], fastq[i], sizes[i], hipMemcpyHostToDevice, h->stream));
-	BatchIO io{d_in, offs.data(), sizes, n, nullptr, 0, blocks, blocks_cap, block_offs, block_sizes, raw_sizes, comp_sizes};
-	return run_batch(h, io);
+	return with_arena_retry(h, estimate_arena(h, n, sizes) + in_bytes, [&]() {
+		const size_t o_in = h->arena.alloc(in_bytes + 256);
+		if (h->arena.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (input)");
+		u8* d_in = h->arena.base + o_in;
+		for (u32 i = 0; i < n; ++i) HIPCHK(hipMemcpyAsync(d_in + offs[i], fastq[i], sizes[i], hipMemcpyHostToDevice, h->stream));
+		BatchIO io{d_in, offs.data(), sizes, n, nullptr, 0, blocks, blocks_cap, block_offs, block_sizes, raw_sizes, comp_sizes};
+		return run_batch(h, io);
+	});
 }
 
 int dsrcgpu_compress_block(dsrcgpu_handle* h, const uint8_t* fastq, uint64_t size, uint8_t* block, uint64_t block_cap, uint64_t* block_size,

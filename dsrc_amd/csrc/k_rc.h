@@ -42,7 +42,7 @@ struct CtxJob     // one (block, stream)
 	u32 is_dna;
 	u32 scheme;         // scheme byte of the stream prologue
 	u32 n_alpha;        // alphabet size (replay template selector)
-	u32 pad;
+	u32 trip_stride;    // chains in this chain's group (<= 64): triples of symbol t live at trip + t*stride
 };
 
 // ---- DNA context: hash of the previous `order` symbols, carried across records --------------
@@ -170,119 +170,280 @@ __global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool)
 }
 
 // ---- model replay ---------------------------------------------------------------------------
+// After the sort every context's history is a contiguous *segment*.  One wave walks a range of
+// the sorted array 64 elements at a time and replays all segments inside the window at once:
+// inside one adaptive epoch (between two Rescale() calls, src/SymbolCoderRC.h:69-90) the counter
+// row is   stats[v] = base[v] + 2 * (#earlier v in the epoch)   so for the symbol in lane i
+//     freq  = base[s] + 2 * #{earlier lanes of my segment with the same symbol}
+//     cum   = cumbase[s] + 2 * #{earlier lanes of my segment with a smaller symbol}
+//     total = T0 + 2 * (symbols coded so far in the epoch)
+// which are popcounts of per-symbol ballots masked to the lane's segment.  Only the segment that
+// is still open at the end of a window carries state (lane v keeps base[v] / cnt[v]); a window is
+// cut short where that segment hits its rescale point.  A wave owns the segments whose heads fall
+// into its slice of the array, so any number of waves can work on one stream.
 #define REPLAY_WG 256
-#define REPLAY_TILE (REPLAY_WG * 8)
+
+template <int N> struct ReplayRow
+{
+	// lane v holds entry v (and v + 64 when N == 128)
+	u32 a, b;
+	__device__ __forceinline__ u32 get(u32 sym) const
+	{
+		const u32 lo = __shfl(a, (int)(sym & 63u));
+		if (N <= 64) return lo;
+		const u32 hi = __shfl(b, (int)(sym & 63u));
+		return sym < 64 ? lo : hi;
+	}
+};
+
+template <int N> __device__ __forceinline__ void replay_prefix(const ReplayRow<N>& r, ReplayRow<N>& ex, u32* total)
+{
+	const u32 ia = wave_incl_scan(r.a);
+	const u32 ta = __shfl(ia, 63);
+	ex.a = ia - r.a;
+	u32 tb = 0; ex.b = 0;
+	if (N > 64) { const u32 ib = wave_incl_scan(r.b); tb = __shfl(ib, 63); ex.b = ta + ib - r.b; }
+	*total = ta + tb;
+}
 
 template <int N>
 __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const u64* pool, u64* trip_pool)
 {
-	__shared__ u16 s_row[N][REPLAY_WG];
-	__shared__ u32 s_heads[REPLAY_TILE];
-	__shared__ u32 s_nheads;
-	const CtxJob j = jobs[blockIdx.x];
+	const CtxJob j = jobs[blockIdx.y];
 	const u64* src = pool + (j.sorted_in_b ? j.elems_b : j.elems);
 	u64* trip = trip_pool + j.trip;
-	const u32 n = j.n, tid = threadIdx.x;
+	const u32 n = j.n, stride = j.trip_stride;
+	const u32 lane = lane_id();
 	const u32 limit = (1u << 16) - 2u * N;                   // MaxAccumulatedValue (src/SymbolCoderRC.h:67)
-
-	for (u32 tile = 0; tile < n; tile += REPLAY_TILE)
+	const u32 n_ranges = gridDim.x * (REPLAY_WG / 64);
+	const u32 per = ((n + n_ranges - 1) / n_ranges + 63u) & ~63u;
+	const u64 r_lo = (u64)(blockIdx.x * (REPLAY_WG / 64) + wave_id()) * per;
+	if (r_lo >= n) return;
+	const u32 hi = (u32)(r_lo + per < n ? r_lo + per : n);
+	u32 pos = (u32)r_lo;
+	// first segment head at or after the nominal start belongs to this wave
+	if (pos > 0)
 	{
-		if (tid == 0) s_nheads = 0;
-		__syncthreads();
-		for (u32 k = 0; k < 8; ++k)
+		for (;;)
 		{
-			const u32 i = tile + k * REPLAY_WG + tid;
-			if (i < n && (i == 0 || (src[i] >> ELEM_CTX_SHIFT) != (src[i - 1] >> ELEM_CTX_SHIFT)))
-				s_heads[atomicAdd(&s_nheads, 1u)] = i;
+			const u32 i = pos + lane;
+			const bool hd = i < n && (src[i] >> ELEM_CTX_SHIFT) != (src[i - 1] >> ELEM_CTX_SHIFT);
+			const u64 m = __ballot(hd);
+			if (m) { pos += (u32)__ffsll((long long)m) - 1; break; }
+			pos += 64;
+			if (pos >= hi) return;
 		}
-		__syncthreads();
-		const u32 nh = s_nheads;
-		for (u32 h = tid; h < nh; h += REPLAY_WG)
+		if (pos >= hi) return;
+	}
+
+	ReplayRow<N> base, cnt, cumbase, cntpre;
+	base.a = base.b = 1; cnt.a = cnt.b = 0; cumbase.a = cumbase.b = 0; cntpre.a = cntpre.b = 0;
+	bool open = false;                      // a segment continues from the previous window
+	u32 T0 = N, epoch_cnt = 0, epoch_left = 0;
+	const u32 E0 = (limit - N + 1) / 2;     // symbols a fresh row codes before its first rescale
+
+	for (;;)
+	{
+		if (pos >= n) break;
+		const u32 idx = pos + lane;
+		const bool valid = idx < n;
+		const u64 el = valid ? src[idx] : 0;
+		const u64 ctx = el >> ELEM_CTX_SHIFT;
+		u64 pctx = __shfl_up(ctx, 1);
+		if (lane == 0) pctx = pos > 0 ? (src[pos - 1] >> ELEM_CTX_SHIFT) : ~0ull;
+		const bool head = valid && ctx != pctx;
+		const u64 hm_all = __ballot(head);
+		u32 tile_len = (u32)__popcll(__ballot(valid));
+		bool last = false;
+		const u64 stop = hm_all & __ballot(idx >= hi);
+		if (stop) { const u32 c = (u32)__ffsll((long long)stop) - 1; if (c < tile_len) tile_len = c; last = true; }
+		if (!(hm_all & 1ull) && !open) { /* cannot happen: windows start on a head unless a segment is open */ }
+		bool rescale_after = false;
+		const bool cont = open && !(hm_all & 1ull);          // lane 0 continues the open segment
+		if (cont)
 		{
-			u32 i = s_heads[h];
-			const u64 ctx = src[i] >> ELEM_CTX_SHIFT;
-			for (int k = 0; k < N; ++k) s_row[k][tid] = 1;
-			u32 total = N;
-			for (;;)
+			u32 c = hm_all ? (u32)__ffsll((long long)hm_all) - 1 : 64u;
+			if (c > tile_len) c = tile_len;
+			if (c > epoch_left) { tile_len = epoch_left; rescale_after = true; last = false; }
+			else if (c == epoch_left && c == tile_len && !last) { /* boundary falls on the window end: rescale lazily below */ }
+		}
+		const u64 tmask = tile_len >= 64 ? ~0ull : ((1ull << tile_len) - 1ull);
+		const bool active = lane < tile_len;
+		const u64 hm = hm_all & tmask;
+		const u64 heads_le = hm & (lanemask_lt() | (1ull << lane));
+		const u32 seg_start = heads_le ? 63u - (u32)__clzll((long long)heads_le) : 0u;
+		const bool in_cont = cont && heads_le == 0;
+		const u64 segmask_lt = lanemask_lt() & ~((1ull << seg_start) - 1ull);
+		const u32 sym = (u32)(el >> ELEM_SYM_SHIFT) & 0xFFu;
+		// the segment that stays open after this window = the one containing lane tile_len-1
+		const u32 last_start = hm ? 63u - (u32)__clzll((long long)hm) : 0u;
+		const bool last_is_cont = cont && hm == 0;
+		const u64 lastmask = tmask & ~((1ull << last_start) - 1ull);
+
+		u32 same = 0, less = 0, add_a = 0, add_b = 0;
+#pragma unroll 4
+		for (u32 v = 0; v < (u32)N; ++v)
+		{
+			const u64 m = __ballot(active && sym == v);
+			const u32 pm = (u32)__popcll(m & segmask_lt);
+			if (v < sym) less += pm;
+			if (v == sym) same = pm;
+			const u32 tail = (u32)__popcll(m & lastmask);
+			if (v == lane) add_a = tail;
+			if (N > 64 && v == lane + 64) add_b = tail;
+		}
+		const u32 in_seg = (u32)__popcll(segmask_lt & tmask);
+		u32 f, cum, tot;
+		{
+			const u32 b0 = base.get(sym), cb = cumbase.get(sym), cc = cnt.get(sym), cp = cntpre.get(sym);
+			if (in_cont) { f = b0 + 2 * (cc + same); cum = cb + 2 * (cp + less); tot = T0 + 2 * (epoch_cnt + in_seg); }
+			else { f = 1 + 2 * same; cum = sym + 2 * less; tot = N + 2 * in_seg; }
+		}
+		if (active) trip[(u64)(u32)el * stride] = ((u64)tot << 32) | ((u64)cum << 16) | f;
+
+		// carry the segment that is open at the end of the window
+		if (tile_len > 0)
+		{
+			if (last_is_cont) { cnt.a += add_a; cnt.b += add_b; epoch_cnt += tile_len; epoch_left -= tile_len; }
+			else
 			{
-				const u64 el = src[i];
-				const u32 sym = (u32)(el >> ELEM_SYM_SHIFT) & 0xFFu;
-				const u32 t = (u32)el;
-				if (total >= limit)                          // Rescale (src/SymbolCoderRC.h:69-90)
-				{
-					total = 0;
-					for (int k = 0; k < N; ++k) { u32 x = s_row[k][tid]; x -= x >> 1; s_row[k][tid] = (u16)x; total += x; }
-				}
-				u32 cum = 0;
-				for (u32 k = 0; k < sym; ++k) cum += s_row[k][tid];
-				const u32 f = s_row[sym][tid];
-				trip[(u64)t * 64] = ((u64)total << 32) | ((u64)cum << 16) | f;
-				s_row[sym][tid] = (u16)(f + 2);
-				total += 2;
-				++i;
-				if (i >= n || (src[i] >> ELEM_CTX_SHIFT) != ctx) break;
+				base.a = (lane < (u32)N) ? 1u : 0u; base.b = (N > 64) ? 1u : 0u;
+				cnt.a = add_a; cnt.b = add_b;
+				T0 = N; epoch_cnt = tile_len - last_start; epoch_left = E0 - epoch_cnt;
+				u32 t; replay_prefix<N>(base, cumbase, &t);
+				open = true;
 			}
 		}
-		__syncthreads();
+		if (rescale_after || (open && epoch_left == 0))
+		{	// Rescale(): stats[i] -= stats[i] >> 1 on stats = base + 2*cnt
+			u32 x = base.a + 2 * cnt.a; base.a = (lane < (u32)N) ? x - (x >> 1) : 0u;
+			if (N > 64) { x = base.b + 2 * cnt.b; base.b = x - (x >> 1); }
+			cnt.a = cnt.b = 0;
+			replay_prefix<N>(base, cumbase, &T0);
+			epoch_cnt = 0; epoch_left = (limit - T0 + 1) / 2;
+		}
+		{ u32 t; replay_prefix<N>(cnt, cntpre, &t); }
+		pos += tile_len;
+		if (last) break;
 	}
 }
 
 // ---- range coder: one lane = one stream ---------------------------------------------------------
+// The only serial part of the path.  Per symbol the dependent chain is
+//   range -> floor(range / total) -> * freq -> renormalise
+// so everything else is kept off it: triples (and the reciprocal of `total`) are prefetched RC_AHEAD
+// symbols ahead (the loads do not depend on the coder state), the renormalisation count comes from
+// clz, the (astronomically rare) carry clamp of RangeEncoder::EncodeFrequency takes a slow path,
+// and output bytes are packed into 32-bit words before they are stored.
 struct RcChain
 {
-	u64 trip;          // u64 index of the chain's first triple (stride 64)
+	u64 trip;          // u64 index of the chain's first triple
 	u64 out_words;     // u32 index of the staging stream
 	u32 n;
 	u32 out_byte0, out_cap;
 	u32 blk, is_dna;
-	u32 pad;
+	u32 stride;
 };
 
-__global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, const u64* trip_pool, u32* word_pool, BlkState* st)
+#define RC_AHEAD 16
+
+struct RcState { u64 low; u32 range; u64 acc; u32 nacc; u32 pos; u32 cap; bool ovf; };
+
+// exact floor(range / total) without a divide on the serial chain: magic[d] = ceil(2^48 / d);
+// floor(n * magic / 2^48) == floor(n / d) for every n < 2^32, d <= 2^16 (the error term n*e/2^48 < 2^-16
+// cannot carry the fraction (<= 1 - 1/d) over an integer).  The table (512 KiB, L2-resident) is built once
+// per handle; its entry is fetched together with the triple, RC_AHEAD symbols ahead of the coder.
+__device__ __forceinline__ u32 rc_div(u32 range, u64 magic)
+{
+	const u32 t = __umulhi(range, (u32)magic);
+	return (u32)(((u64)range * (u32)(magic >> 32) + t) >> 16);
+}
+
+__device__ __forceinline__ void rc_flush_word(RcState& s, u32* out)
+{
+	const u32 sh = 8 * (s.nacc - 4);
+	if (s.pos + 4 <= s.cap) out[s.pos >> 2] = (u32)(s.acc >> sh); else s.ovf = true;
+	s.pos += 4; s.nacc -= 4;
+}
+
+__device__ __forceinline__ void rc_step(RcState& s, u32* out, u64 e, u64 magic)
+{
+	const u32 f = (u32)e & 0xFFFFu, cum = (u32)(e >> 16) & 0xFFFFu;
+	const u32 r = rc_div(s.range, magic);
+	u64 low = s.low + (u32)(r * cum);
+	u32 range = r * f;
+	const u32 k = range > 0x00FFFFFFu ? 0u : (u32)__clz((int)range) >> 3;      // bytes leaving the coder (0..3)
+	const u64 x = low ^ (low + range);
+	if (k && ((u32)(x >> 40) >> (24 - 8 * k)))
+	{	// carry clamp of RangeEncoder::EncodeFrequency (src/RangeCoder.h:64-74) -- astronomically rare, verbatim
+		while (range <= 0x00FFFFFFu)
+		{
+			if ((low ^ (low + range)) & 0xFF00000000000000ull) { const u32 rr = (u32)low; range = (rr | 0x00FFFFFFu) - rr; }
+			s.acc = (s.acc << 8) | (low >> 56); s.nacc++;
+			if (s.nacc >= 4) rc_flush_word(s, out);
+			low <<= 8; range <<= 8;
+		}
+		s.low = low; s.range = range;
+		return;
+	}
+	// the top k bytes of low are final
+	const u32 bytes = ((u32)(low >> 40) >> (24 - 8 * k)) & ((1u << (8 * k)) - 1u);
+	s.acc = (s.acc << (8 * k)) | bytes;
+	s.nacc += k;
+	s.low = low << (8 * k);
+	s.range = range << (8 * k);
+	if (s.nacc >= 4) rc_flush_word(s, out);
+}
+
+__global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, const u64* trip_pool, u32* word_pool, BlkState* st, const u64* magic_tab)
 {
 	const u32 id = blockIdx.x * 64 + threadIdx.x;
-	const bool live = id < n_chains;
-	RcChain c;
-	if (live) c = chains[id]; else { c.n = 0; c.trip = 0; c.out_words = 0; c.out_byte0 = 0; c.out_cap = 0; c.blk = 0; c.is_dna = 0; }
-	const u32 nmax = wave_max(c.n);
+	if (id >= n_chains) return;
+	const RcChain c = chains[id];
 	const u64* trip = trip_pool + c.trip;
 	u32* out = word_pool + c.out_words;
-	u64 low = 0; u32 range = 0xFFFFFFFFu;
-	u32 pos = c.out_byte0;
-	const u32 cap = c.out_byte0 + c.out_cap;
-	bool ovf = false;
-	for (u32 t = 0; t < nmax; ++t)
+	RcState s;
+	s.low = 0; s.range = 0xFFFFFFFFu; s.ovf = false;
+	s.cap = (c.out_byte0 + c.out_cap) & ~3u;
+	// the prologue bytes (scheme byte / presence map) share the first word with the coder output
+	const u32 m = c.out_byte0 & 3u;
+	s.pos = c.out_byte0 - m; s.nacc = m;
+	s.acc = m ? (u64)(out[s.pos >> 2] >> (8 * (4 - m))) : 0;
+
+	const u32 n = c.n, stride = c.stride;
+	u64 buf[RC_AHEAD], mg[RC_AHEAD];
+#pragma unroll
+	for (u32 i = 0; i < RC_AHEAD; ++i) buf[i] = i < n ? trip[(u64)i * stride] : 0;
+#pragma unroll
+	for (u32 i = 0; i < RC_AHEAD; ++i) mg[i] = magic_tab[(u32)(buf[i] >> 32) & 0xFFFFu];
+	u32 t0 = 0;
+	for (; t0 + RC_AHEAD <= n; t0 += RC_AHEAD)
 	{
-		if (t < c.n)
-		{
-			const u64 e = trip[(u64)t * 64];
-			const u32 f = (u32)e & 0xFFFFu, cum = (u32)(e >> 16) & 0xFFFFu, tot = (u32)(e >> 32);
-			range /= tot;
-			low += (u32)(range * cum);
-			range *= f;
-			while (range <= 0x00FFFFFFu)
-			{
-				if ((low ^ (low + range)) & 0xFF00000000000000ull)
-				{
-					const u32 r = (u32)low;
-					range = (r | 0x00FFFFFFu) - r;
-				}
-				if (pos < cap) put_byte(out, pos, (u32)(low >> 56)); else ovf = true;
-				++pos;
-				low <<= 8; range <<= 8;
-			}
-		}
+		u64 nb[RC_AHEAD], nm[RC_AHEAD];
+#pragma unroll
+		for (u32 i = 0; i < RC_AHEAD; ++i) { const u32 t = t0 + RC_AHEAD + i; nb[i] = t < n ? trip[(u64)t * stride] : 0; }
+#pragma unroll
+		for (u32 i = 0; i < RC_AHEAD; ++i) rc_step(s, out, buf[i], mg[i]);
+#pragma unroll
+		for (u32 i = 0; i < RC_AHEAD; ++i) nm[i] = magic_tab[(u32)(nb[i] >> 32) & 0xFFFFu];
+#pragma unroll
+		for (u32 i = 0; i < RC_AHEAD; ++i) { buf[i] = nb[i]; mg[i] = nm[i]; }
 	}
-	if (live)
+#pragma unroll
+	for (u32 i = 0; i < RC_AHEAD; ++i) if (t0 + i < n) rc_step(s, out, buf[i], mg[i]);
+
+	for (u32 k = 0; k < 8; ++k)                                                    // RangeEncoder::End
 	{
-		for (u32 k = 0; k < 8; ++k)
-		{
-			if (pos < cap) put_byte(out, pos, (u32)(low >> 56)); else ovf = true;
-			++pos; low <<= 8;
-		}
-		if (c.is_dna) st[c.blk].dna_bytes = pos; else st[c.blk].qua_bytes = pos;
-		if (ovf) atomicOr(&st[c.blk].err, (u32)DSRC_ERR_OUT_OVERFLOW);
+		s.acc = (s.acc << 8) | (s.low >> 56); s.nacc++; s.low <<= 8;
+		if (s.nacc >= 4) rc_flush_word(s, out);
 	}
+	const u32 total = s.pos + s.nacc;
+	for (u32 k = 0; k < s.nacc; ++k)
+	{
+		if (s.pos + k < c.out_byte0 + c.out_cap) put_byte(out, s.pos + k, (u32)(s.acc >> (8 * (s.nacc - 1 - k)))); else s.ovf = true;
+	}
+	if (c.is_dna) st[c.blk].dna_bytes = total; else st[c.blk].qua_bytes = total;
+	if (s.ovf) atomicOr(&st[c.blk].err, (u32)DSRC_ERR_OUT_OVERFLOW);
 }
 
 // ---- stream prologues ---------------------------------------------------------------------------

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/golden.json from the UNMODIFIED reference (oracle/_ref, built from
+/root/reference by oracle/Makefile).  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+The file holds data only: generator specs / small inputs, and the reference's outputs for them
+(block bytes or their SHA-256, per-stream sizes, statistics, primitive known-answer vectors,
+whole-archive digests)."""
+import hashlib
+import json
+import os
+import random
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from dsrc_amd import synth                       # noqa: E402
+from tests._oracle import Config, Ref, Oracle    # noqa: E402
+from tests.cases import LEVELS, TINY, fuzz_fastq  # noqa: E402
+
+
+def sha(b: bytes) -> str:
+    return hashlib.sha256(b).hexdigest()
+
+
+def main():
+    r = Ref()
+    o = Oracle()          # only used to skip inputs that are undefined behaviour in the reference
+    g = {"primitives": {}, "blocks": [], "stats": [], "archives": [], "chunks": []}
+
+    # ---- primitives (SURVEY Appendix E.1 and more) ------------------------------------------------
+    scripts = [
+        [(2, 5, 3), (0, 1, 0), (1, 2, 0), (2, 0x1FF, 9), (5, 0, 0), (4, 0x01020304, 0), (2, 3, 2)],
+        [(2, 0, 0), (2, 1, 1), (2, 0x7FFFFFFF, 31), (0, 1, 0), (5, 0, 0), (3, 0xAB, 0)],
+        [(1, k & 3, 0) for k in range(37)],
+        [(2, (k * 2654435761) & 0xFFFFFF, 1 + k % 24) for k in range(200)],
+    ]
+    g["primitives"]["bitwriter"] = [{"ops": s, "hex": r.bitwriter_script(s).hex()} for s in scripts]
+    rng = random.Random(7)
+    huff = [[5, 1, 1, 3, 0, 0], [0, 0], [0, 0, 0, 0, 0], [1, 0], [0, 7], [3, 3], [1] * 16, list(range(20)), [0] * 100 + [9] + [0] * 27 + [1] * 128]
+    for _ in range(12):
+        n = rng.choice([2, 3, 7, 20, 41, 64, 128, 256, 400])
+        fr = [0] * n
+        for i in rng.sample(range(n), rng.randrange(0, n + 1)):
+            fr[i] = rng.choice([1, 1, 2, 3, 50, 1000, 7])
+        huff.append(fr)
+    g["primitives"]["huffman"] = []
+    for fr in huff:
+        codes, lens, tree = r.huffman(fr)
+        g["primitives"]["huffman"].append({"freqs": fr, "codes": codes, "lens": lens, "tree": tree.hex()})
+    rcs = []
+    for seed in range(4):
+        rng = random.Random(100 + seed)
+        fct = []
+        for _ in range(500 + 3000 * seed):
+            tot = rng.randrange(2, 65000)
+            f = rng.randrange(1, tot)
+            c = rng.randrange(0, tot - f + 1)
+            fct.append((f, c, tot))
+        rcs.append({"seed": 100 + seed, "n": len(fct), "sha256": sha(r.rc_script(fct)), "head": r.rc_script(fct)[:24].hex()})
+    g["primitives"]["rc_script"] = rcs
+    syms = bytes(3 if i % 97 == 0 else 0 for i in range(40000))
+    out = r.rc_adaptive4(syms)
+    g["primitives"]["rc_adaptive4"] = {"desc": "3 if i%97==0 else 0, i<40000", "len": len(out), "sha256": sha(out), "head": out[:16].hex()}
+    g["primitives"]["crc32"] = [{"text": t, "crc": r.crc32(t.encode())} for t in ["123456789", "", "a", "DSRC" * 1000]]
+
+    # ---- blocks -------------------------------------------------------------------------------------
+    inputs = [("tiny", {"kind": "tiny"}, TINY),
+              ("illumina300", {"kind": "illumina", "n": 300, "first": 1}, synth.illumina_fastq(300)[:-1]),
+              ("illumina300_crlf", {"kind": "illumina", "n": 300, "first": 77, "crlf": True}, synth.illumina_fastq(300, first=77, crlf=True)[:-2]),
+              ("iontorrent200", {"kind": "iontorrent", "n": 200, "first": 1}, synth.iontorrent_fastq(200)[:-1])]
+    for seed in range(48):
+        data, desc = fuzz_fastq(seed, nrec=None if seed % 3 else 60)
+        inputs.append((f"fuzz{seed}", {"kind": "fuzz", "seed": seed, "nrec": None if seed % 3 else 60, "desc": list(desc)}, data))
+    for name, spec, data in inputs:
+        for d, q, lossy, crc in LEVELS:
+            cfg = Config.from_levels(d, q, lossy, crc)
+            try:
+                o.compress_block(cfg, data)
+            except RuntimeError as e:
+                if "rc=-2" in str(e):
+                    g["blocks"].append({"name": name, "spec": spec, "in_sha256": sha(data), "levels": [d, q, lossy, crc], "ref_ub": True})
+                    continue
+                raise
+            blk, raw, comp = r.compress_block(cfg, data)
+            e = {"name": name, "spec": spec, "in_sha256": sha(data), "levels": [d, q, lossy, crc],
+                 "raw": raw, "comp": comp, "sha256": sha(blk), "size": len(blk)}
+            if len(blk) <= 700:
+                e["hex"] = blk.hex()
+            g["blocks"].append(e)
+        if name in ("tiny", "illumina300", "iontorrent200", "fuzz1", "fuzz2", "fuzz5"):
+            for lossy in (False, True):
+                dst, qst, recs, cs, raw = r.block_stats(Config(lossy=lossy), data)
+                g["stats"].append({"name": name, "spec": spec, "lossy": lossy, "dna": dst, "qua": qst, "recs": recs, "chunk_size": cs, "raw": raw})
+
+    # ---- chunk cutting + whole archives -------------------------------------------------------------------
+    with tempfile.TemporaryDirectory() as td:
+        files = {"tiny": TINY + b"\n", "illumina9000": synth.illumina_fastq(9000), "illumina7000_crlf": synth.illumina_fastq(7000, crlf=True),
+                 "iontorrent6000": synth.iontorrent_fastq(6000)}
+        for name, data in files.items():
+            p = os.path.join(td, name + ".fastq")
+            open(p, "wb").write(data)
+            g["chunks"].append({"name": name, "in_sha256": sha(data), "buf_mb": 1, "sizes": r.chunk_sizes(p, 1)})
+            for d, q, lossy, crc in [(0, 0, False, False), (3, 2, False, False), (2, 1, True, False), (1, 1, False, True)]:
+                if name.startswith("ion") and (crc or (d > 0 and not lossy)):
+                    continue     # reference UB / CRC mismatch by design on IUPAC data
+                dst = os.path.join(td, "o.dsrc")
+                rc = r.compress_file(p, dst, d, q, lossy, crc, 0, 1, 1)
+                assert rc == 0, (name, d, q, lossy, crc)
+                arc = open(dst, "rb").read()
+                g["archives"].append({"name": name, "in_sha256": sha(data), "levels": [d, q, lossy, crc], "buf_mb": 1, "threads": 1,
+                                      "size": len(arc), "sha256": sha(arc), "md5": hashlib.md5(arc).hexdigest()})
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.json"), "w") as f:
+        json.dump(g, f, indent=0, separators=(",", ":"))
+    print("blocks", len(g["blocks"]), "archives", len(g["archives"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,135 @@
+"""Kernel logic on the CPU: the *same* kernel sources (dsrc_amd/csrc/*.h, dsrc_gpu.hip) compiled against
+the HIP emulator in tests/emu and driven through the C ABI, compared with the oracle.  This is a test
+harness for a GPU-less container, not a product path (the product loads only libdsrc_gpu.so)."""
+import os
+import subprocess
+
+import pytest
+
+from dsrc_amd import synth
+from tests._oracle import Config
+from tests.cases import LEVELS, TINY, fuzz_fastq
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu", "libdsrc_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emu")], stdout=subprocess.DEVNULL)
+    old = os.environ.get("DSRC_GPU_LIB")
+    os.environ["DSRC_GPU_LIB"] = EMU
+    from dsrc_amd import _lib
+    _lib._lib = None
+    yield _lib
+    _lib._lib = None
+    if old is None:
+        os.environ.pop("DSRC_GPU_LIB", None)
+    else:
+        os.environ["DSRC_GPU_LIB"] = old
+
+
+def run(emu, cfg, data):
+    h = emu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
+    try:
+        return h.compress_block(data)
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("d,q,lossy,crc", LEVELS)
+def test_tiny(emu, oracle, d, q, lossy, crc):
+    cfg = Config.from_levels(d, q, lossy, crc)
+    assert run(emu, cfg, TINY) == oracle.compress_block(cfg, TINY)
+
+
+@pytest.mark.parametrize("d,q,lossy,crc", [(3, 2, False, False), (0, 0, False, True), (2, 1, True, False)])
+def test_illumina(emu, oracle, d, q, lossy, crc):
+    data = synth.illumina_fastq(150)[:-1]
+    cfg = Config.from_levels(d, q, lossy, crc)
+    assert run(emu, cfg, data) == oracle.compress_block(cfg, data)
+
+
+@pytest.mark.parametrize("d,q,lossy", [(2, 1, True), (0, 0, False), (0, 2, False)])
+def test_iontorrent(emu, oracle, d, q, lossy):
+    data = synth.iontorrent_fastq(120)[:-1]
+    cfg = Config.from_levels(d, q, lossy)
+    assert run(emu, cfg, data) == oracle.compress_block(cfg, data)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz(emu, oracle, seed):
+    data, desc = fuzz_fastq(seed, nrec=[2, 3, 10, 60, 150][seed % 5])
+    for d, q, lossy, crc in [(0, 0, False, False), (3, 2, False, True), (2, 1, True, False)]:
+        cfg = Config.from_levels(d, q, lossy, crc)
+        try:
+            want = oracle.compress_block(cfg, data)
+        except RuntimeError as e:
+            assert "rc=-2" in str(e)
+            with pytest.raises(emu.DsrcGpuError):
+                run(emu, cfg, data)
+            continue
+        assert run(emu, cfg, data) == want, (seed, desc, d, q, lossy, crc)
+
+
+def test_batch_state_and_queue_api(emu, oracle):
+    import ctypes as C
+    from tests._oracle import _orc_cfg
+    chunks = [synth.illumina_fastq(60, first=1 + 60 * k)[:-1] for k in range(3)] + [synth.iontorrent_fastq(40)[:-1]]
+    cfg = Config.from_levels(0, 1)
+    h = emu.Handle(cfg.dna_order, cfg.quality_order)
+    for i, c in enumerate(chunks):
+        h.submit(10 + i, c)
+    h.flush()
+    got = []
+    while True:
+        r = h.collect()
+        if r is None:
+            break
+        got.append(r)
+    h.close()
+    assert [g[0] for g in got] == [10, 11, 12, 13]
+    cap = C.c_uint32(0); c = _orc_cfg(cfg)
+    for i, ch in enumerate(chunks):
+        out = (C.c_uint8 * (len(ch) + 65536))(); osz = C.c_uint64(); raw = (C.c_uint64 * 4)(); comp = (C.c_uint64 * 4)()
+        assert oracle.lib.orc_compress_block_state(C.byref(c), C.byref(cap), ch, C.c_uint64(len(ch)), out, C.c_uint64(len(out)), C.byref(osz), raw, comp) == 0
+        assert got[i][1] == bytes(out[:osz.value])
+        assert got[i][2] == list(raw) and got[i][3] == list(comp)
+
+
+def test_hot_contexts_rescale(emu, oracle):
+    """One context with ~40k symbols: exercises the epoch/rescale path of k_replay and multi-wave ranges."""
+    import random
+    rng = random.Random(5)
+    recs = []
+    for i in range(170):
+        seq = ''.join(rng.choice('AAAAAAAC') for _ in range(250))
+        q = ''.join('I' if rng.random() < 0.97 else 'H' for _ in range(250))
+        recs.append(f"@r.{i}\n{seq}\n+\n{q}")
+    data = '\n'.join(recs).encode()
+    for d, q, lossy in [(1, 2, False), (2, 1, True)]:
+        cfg = Config.from_levels(d, q, lossy)
+        assert run(emu, cfg, data) == oracle.compress_block(cfg, data)
+
+
+def test_device_synth_matches_host(emu):
+    h = emu.Handle()
+    cap = 1 << 20
+    d = h.dev_alloc(cap)
+    n = h.synth_illumina(999990, 1200, d, cap)
+    got = h.dev_download(d, n)
+    h.dev_free(d); h.close()
+    assert got == synth.illumina_fastq(1200, first=999990)
+
+
+def test_bad_arguments(emu):
+    with pytest.raises(emu.DsrcGpuError):
+        emu.Handle(tag_flags=6)
+    with pytest.raises(emu.DsrcGpuError):
+        emu.Handle(color_space=True)
+    with pytest.raises(emu.DsrcGpuError):
+        emu.Handle(quality_offset=20)
+    h = emu.Handle()
+    with pytest.raises(emu.DsrcGpuError):
+        h.compress_block(b"not a fastq chunk")
+    h.close()

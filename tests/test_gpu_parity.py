@@ -56,7 +56,7 @@ def test_batch_of_blocks_with_state(gpu, oracle):
     import ctypes as C
     from tests._oracle import _orc_cfg
     chunks = [synth.illumina_fastq(3000, first=1 + 3000 * k)[:-1] for k in range(5)] + [synth.iontorrent_fastq(800)[:-1]]
-    for d, q in ((3, 2), (0, 0)):
+    for d, q in ((0, 2), (0, 0), (0, 1)):          # lossless order-k DNA on IUPAC data is undefined in the reference
         cfg = Config.from_levels(d, q)
         h = gpu.Handle(cfg.dna_order, cfg.quality_order)
         got = h.compress_batch(chunks)
@@ -89,6 +89,20 @@ def test_fuzz(gpu, oracle, seed):
         got = h.compress_block(data)
         h.close()
         assert got == want, f"seed {seed} {desc} -d{d} -q{q} lossy={lossy} crc={crc}"
+
+
+def test_hot_contexts_rescale(gpu, oracle):
+    """Contexts with > 32k symbols: the adaptive rows rescale several times (SymbolCoderRC::Rescale)."""
+    import random
+    rng = random.Random(5)
+    recs = []
+    for i in range(4000):
+        seq = ''.join(rng.choice('AAAAAAAC') for _ in range(250))
+        q = ''.join('I' if rng.random() < 0.97 else 'H' for _ in range(250))
+        recs.append(f"@r.{i}\n{seq}\n+\n{q}")
+    data = '\n'.join(recs).encode()
+    for d, q, lossy in [(1, 2, False), (3, 1, False), (2, 2, True), (3, 2, False)]:
+        _check(gpu, oracle, Config.from_levels(d, q, lossy), [data])
 
 
 def test_device_synth_matches_host(gpu):
