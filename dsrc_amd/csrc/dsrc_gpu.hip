@@ -333,13 +333,15 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		}
 		if (qo > 0)
 		{
-			D.qua_cap = (u32)((64 + (size_t)S.q_total * 2) / 4 + 4);
+			D.qua_cap = (u32)((1024 + (size_t)S.q_total * 2) / 4 + 4);
+			D.plain_mask |= 1u;
 			D.qua_out = A.alloc((size_t)D.qua_cap * 4) / 4;
 		}
 		if (dna_order == 0 && D.d_scheme == 0) { D.dna_cap = (u32)((S.d_total / 4 + 16) / 4 + 4); D.dna_out = A.alloc((size_t)D.dna_cap * 4) / 4; }
+		if (dna_order > 0 && D.d_scheme != 255) D.plain_mask |= 2u;
 		if (dna_order > 0 || D.d_scheme == 255)
 		{
-			D.dna_cap = (u32)((64 + (size_t)S.d_total * 2) / 4 + 4);
+			D.dna_cap = (u32)((1024 + (size_t)S.d_total * 2) / 4 + 4);
 			D.dna_out = A.alloc((size_t)D.dna_cap * 4) / 4;
 		}
 	}
@@ -359,7 +361,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			}
 			if (j.order > 7) return fail(h, DSRCGPU_E_ARG, "quality order %u not supported", j.order);
 			j.alpha_bits = log2u(j.n_alpha); j.key_bits = j.alpha_bits * (j.order + 1);
-			j.out_words = D.qua_out; j.out_cap = D.qua_cap * 4 - j.out_byte0;
+			j.out_words = D.qua_out; j.out_cap = D.qua_cap * 4 - j.out_byte0 - 16;
 			qjobs.push_back(j);
 		}
 	if (dna_order > 0)
@@ -372,7 +374,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			j.n_alpha = D.d_scheme ? 8 : 4; j.alpha_bits = D.d_scheme ? 3 : 2;
 			j.order = D.d_scheme ? std::min(dna_order, 7u) : dna_order;
 			j.key_bits = j.alpha_bits * j.order; j.scheme = D.d_scheme; j.out_byte0 = 1;
-			j.out_words = D.dna_out; j.out_cap = D.dna_cap * 4 - 1;
+			j.out_words = D.dna_out; j.out_cap = D.dna_cap * 4 - 1 - 16;
 			djobs.push_back(j);
 		}
 	// order jobs by (kind, alphabet) so that replay launches and 64-chain groups are homogeneous

@@ -93,7 +93,8 @@ struct BlkDesc   // host -> device
 	u32 qscr_base_lo, qscr_base_hi;   // u32 index: quality scratch (position histograms / run arrays / code tables)
 	u32 qscr_words;
 	u32 q_scheme;           // host-decided stream schemes (IQualityModelerProxy / IDnaModelerProxy::SelectSchemeId)
-	u32 d_scheme, pad1;
+	u32 d_scheme;
+	u32 plain_mask;         // bit0: quality stream staged as plain bytes, bit1: DNA stream (range-coder output)
 	u64 out_off;            // final block position in the output buffer (bytes), set after sizes are known
 };
 

@@ -1,0 +1,187 @@
+// Host side of the MI355X DSRC compressor, above the C ABI (include/dsrc_gpu.h).
+//
+// Mirrors the reference's operator / module interface for the compression path so that callers of
+//   dsrc::comp::IDsrcOperator::Process(const InputParameters&)      (src/DsrcOperator.h:26-91)
+//   dsrc::wrap::DsrcModule::Compress(in, out) + Configurable setters  (include/dsrc/DsrcModule.h:22-40,
+//                                                                     include/dsrc/Configurable.h:51-82)
+// keep their code: same names, same argument meaning, same error convention (Process returns false and
+// GetError() carries "Error: ...\n"; DsrcModule throws DsrcException).  What changes is below Process():
+// the reader thread + N DsrcCompressor workers + writer become
+//   FastqChunker (IFastqStreamReader::ReadNextChunk, src/FastqStream.cpp:18-98)
+//   -> batches of chunks -> dsrcgpu_compress_batch (GPU block scheduler)
+//   -> ArchiveWriter (DsrcFileWriter, src/DsrcFile.cpp:38-170).
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <exception>
+#include <string>
+#include <vector>
+
+namespace dsrc
+{
+
+typedef unsigned char uchar, byte;
+typedef unsigned int uint32;
+typedef unsigned long long uint64;
+typedef long long int64;
+
+class DsrcException : public std::exception
+{
+	std::string message;
+public:
+	explicit DsrcException(const std::string& m) : message(m) {}
+	~DsrcException() throw() {}
+	const char* what() const throw() { return message.c_str(); }
+};
+
+namespace fq
+{
+struct FastqDatasetType
+{
+	static const uint32 AutoQualityOffset = 0;
+	uint32 qualityOffset = AutoQualityOffset;
+	bool plusRepetition = false;
+	bool colorSpace = false;
+};
+
+struct StreamsInfo
+{
+	enum StreamName { MetaStream = 0, TagStream, DnaStream, QualityStream, StreamCount = 4 };
+	uint64 sizes[4] = {0, 0, 0, 0};
+};
+} // namespace fq
+
+namespace comp
+{
+
+struct CompressionSettings
+{
+	uint32 dnaOrder = 0;
+	uint32 qualityOrder = 0;
+	uint64 tagPreserveFlags = 0;
+	bool lossy = false;
+	bool calculateCrc32 = false;
+};
+
+struct InputParameters          // src/Common.h:149-193, plus the GPU knobs at the end
+{
+	uint32 qualityOffset = 0;
+	uint32 dnaCompressionLevel = 0;
+	uint32 qualityCompressionLevel = 0;
+	uint32 threadNum = 2;          // kept for source compatibility; the GPU scheduler ignores it
+	uint64 tagPreserveFlags = 0;
+	uint32 fastqBufferSizeMB = 8;
+	bool lossyCompression = false;
+	bool calculateCrc32 = false;
+	bool useFastqStdIo = false;
+	std::string inputFilename;
+	std::string outputFilename;
+	// GPU path
+	int device = 0;
+	uint32 batchBlocks = 0;        // chunks per scheduler pass; 0 = as many as fit ~2 GiB of input
+};
+
+class IDsrcOperator
+{
+public:
+	virtual ~IDsrcOperator() {}
+	virtual bool Process(const InputParameters& args_) = 0;
+	bool IsError() const { return errorMessage.length() > 0; }
+	const std::string& GetError() const { return errorMessage; }
+	void ClearError() { errorMessage.clear(); }
+	const std::string& GetLog() const { return logMessage; }
+	void ClearLog() { logMessage.clear(); }
+
+	// level -> order mapping of the reference (src/DsrcOperator.h:74-90)
+	static CompressionSettings GetCompressionSettings(const InputParameters& args_);
+
+protected:
+	std::string errorMessage, logMessage;
+	void AddError(const std::string& e) { errorMessage += "Error: " + e + '\n'; }
+	void AddLog(const std::string& l) { logMessage += l + '\n'; }
+};
+
+// Drop-in for DsrcCompressorMT / DsrcCompressorST (src/DsrcOperator.cpp:55-395)
+class DsrcCompressorGPU : public IDsrcOperator
+{
+public:
+	bool Process(const InputParameters& args_);
+};
+
+// ---- pieces (exposed for tests) -----------------------------------------------------------------------------
+
+// IFastqStreamReader::ReadNextChunk on a FILE* (src/FastqStream.cpp:18-98)
+class FastqChunker
+{
+public:
+	FastqChunker(FILE* f, uint64 bufferSize);
+	// returns false at end of input; chunk.size() is FastqDataChunk::size (final newline not included)
+	bool ReadNextChunk(std::vector<uchar>& chunk);
+private:
+	FILE* file;
+	uint64 bufSize;
+	std::vector<uchar> carry;
+	bool eof = false, usesCrlf = false;
+	static uint64 NextRecordPos(const uchar* d, uint64 pos, uint64 size, bool& crlf);
+};
+
+// FastqParser::Analyze (src/FastqParser.cpp:27-138)
+bool AnalyzeFirstChunk(const uchar* data, uint64 size, fq::FastqDatasetType& type, bool estimateQualityOffset);
+
+// DsrcFileWriter (src/DsrcFile.cpp:38-170)
+class ArchiveWriter
+{
+public:
+	void Start(const std::string& path);
+	void WriteBlock(const uchar* data, uint64 size, const uint64 raw[4], const uint64 comp[4]);
+	void Finish(const fq::FastqDatasetType& type, const CompressionSettings& settings);
+	const fq::StreamsInfo& Raw() const { return rawInfo; }
+	const fq::StreamsInfo& Comp() const { return compInfo; }
+	~ArchiveWriter();
+private:
+	FILE* f = nullptr;
+	std::vector<uint32> blockSizes;
+	fq::StreamsInfo rawInfo, compInfo;
+};
+
+} // namespace comp
+
+namespace wrap
+{
+
+class Configurable           // include/dsrc/Configurable.h:51-82 (compression-side setters)
+{
+public:
+	void SetFastqBufferSizeMB(uint64 size_);
+	uint64 GetFastqBufferSizeMB() const { return params.fastqBufferSizeMB; }
+	void SetDnaCompressionLevel(uint32 level_);
+	uint32 GetDnaCompressionLevel() const { return params.dnaCompressionLevel; }
+	void SetQualityCompressionLevel(uint32 level_);
+	uint32 GetQualityCompressionLevel() const { return params.qualityCompressionLevel; }
+	void SetLossyCompression(bool lossy_) { params.lossyCompression = lossy_; }
+	bool IsLossyCompression() const { return params.lossyCompression; }
+	void SetQualityOffset(uint32 off_);
+	uint32 GetQualityOffset() const { return params.qualityOffset; }
+	void SetThreadsNumber(uint32 threadNum_);
+	uint32 GetThreadsNumber() const { return params.threadNum; }
+	void SetStdIoUsing(bool use_) { params.useFastqStdIo = use_; }
+	bool IsStdIoUsing() const { return params.useFastqStdIo; }
+	void SetCrc32Checking(bool use_) { params.calculateCrc32 = use_; }
+	bool IsCrc32Checking() const { return params.calculateCrc32; }
+	void SetTagFieldFilterMask(uint64 mask_) { params.tagPreserveFlags = mask_; }
+	uint64 GetTagFieldFilterMask() const { return params.tagPreserveFlags; }
+	void SetDevice(int device_) { params.device = device_; }
+protected:
+	comp::InputParameters params;
+};
+
+class DsrcModule : public Configurable   // include/dsrc/DsrcModule.h:22-40
+{
+public:
+	void Compress(const std::string& inputFilename_, const std::string& outputFilename_);
+	void Decompress(const std::string& inputFilename_, const std::string& outputFilename_);
+};
+
+} // namespace wrap
+} // namespace dsrc

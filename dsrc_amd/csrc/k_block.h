@@ -49,10 +49,11 @@ __global__ void __launch_bounds__(WG) k_assemble(const BlkDesc* desc, const BlkS
 	for (u32 k = tid; k < S->tag_bytes; k += stride) o[at + k] = src[k ^ 3u];
 	at += S->tag_bytes;
 	src = (const u8*)(word_pool + d.qua_out);
-	for (u32 k = tid; k < S->qua_bytes; k += stride) o[at + k] = src[k ^ 3u];
+	const u32 xq = (d.plain_mask & 1u) ? 0u : 3u, xd = (d.plain_mask & 2u) ? 0u : 3u;
+	for (u32 k = tid; k < S->qua_bytes; k += stride) o[at + k] = src[k ^ xq];
 	at += S->qua_bytes;
 	src = (const u8*)(word_pool + d.dna_out);
-	for (u32 k = tid; k < S->dna_bytes; k += stride) o[at + k] = src[k ^ 3u];
+	for (u32 k = tid; k < S->dna_bytes; k += stride) o[at + k] = src[k ^ xd];
 }
 
 // ---- CRC-32 (poly 0xEDB88320, init/final 0xFFFFFFFF) ------------------------------------------------------

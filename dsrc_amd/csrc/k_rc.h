@@ -347,52 +347,53 @@ struct RcChain
 
 #define RC_AHEAD 16
 
-struct RcState { u64 low; u32 range; u64 acc; u32 nacc; u32 pos; u32 cap; bool ovf; };
-
 // exact floor(range / total) without a divide on the serial chain: magic[d] = ceil(2^48 / d);
 // floor(n * magic / 2^48) == floor(n / d) for every n < 2^32, d <= 2^16 (the error term n*e/2^48 < 2^-16
 // cannot carry the fraction (<= 1 - 1/d) over an integer).  The table (512 KiB, L2-resident) is built once
-// per handle; its entry is fetched together with the triple, RC_AHEAD symbols ahead of the coder.
+// per handle; its entry is fetched RC_AHEAD symbols ahead of the coder, the triple 2*RC_AHEAD ahead.
 __device__ __forceinline__ u32 rc_div(u32 range, u64 magic)
 {
 	const u32 t = __umulhi(range, (u32)magic);
 	return (u32)(((u64)range * (u32)(magic >> 32) + t) >> 16);
 }
 
-__device__ __forceinline__ void rc_flush_word(RcState& s, u32* out)
-{
-	const u32 sh = 8 * (s.nacc - 4);
-	if (s.pos + 4 <= s.cap) out[s.pos >> 2] = (u32)(s.acc >> sh); else s.ovf = true;
-	s.pos += 4; s.nacc -= 4;
-}
+// Output: range-coder streams are staged as PLAIN bytes (stream byte k at address k; BlkDesc::*_plain tells
+// k_assemble), so the k (0..3) bytes that leave the coder are written with one unaligned 32-bit store at the
+// current position; the bytes beyond k are overwritten by the following symbols.
+struct RcState { u64 low; u32 range; u32 pos; };
 
-__device__ __forceinline__ void rc_step(RcState& s, u32* out, u64 e, u64 magic)
+__device__ __forceinline__ void rc_step(RcState& s, u8* out, u64 e, u64 magic)
 {
 	const u32 f = (u32)e & 0xFFFFu, cum = (u32)(e >> 16) & 0xFFFFu;
 	const u32 r = rc_div(s.range, magic);
 	u64 low = s.low + (u32)(r * cum);
 	u32 range = r * f;
-	const u32 k = range > 0x00FFFFFFu ? 0u : (u32)__clz((int)range) >> 3;      // bytes leaving the coder (0..3)
-	const u64 x = low ^ (low + range);
-	if (k && ((u32)(x >> 40) >> (24 - 8 * k)))
-	{	// carry clamp of RangeEncoder::EncodeFrequency (src/RangeCoder.h:64-74) -- astronomically rare, verbatim
-		while (range <= 0x00FFFFFFu)
-		{
-			if ((low ^ (low + range)) & 0xFF00000000000000ull) { const u32 rr = (u32)low; range = (rr | 0x00FFFFFFu) - rr; }
-			s.acc = (s.acc << 8) | (low >> 56); s.nacc++;
-			if (s.nacc >= 4) rc_flush_word(s, out);
-			low <<= 8; range <<= 8;
+	u32 k = range > 0x00FFFFFFu ? 0u : (u32)__clz((int)range) >> 3;            // bytes leaving the coder (0..3)
+	// RangeEncoder::EncodeFrequency's carry clamp (src/RangeCoder.h:64-74) can only trigger when adding
+	// range (< 2^24) to low carries through bits 24..39: those 16 bits must all be ones
+	if (k && ((u32)(low >> 24) & 0xFFFFu) == 0xFFFFu)
+	{
+		const u64 x = low ^ (low + range);
+		if ((u32)(x >> 40) >> (24 - 8 * k))
+		{	// astronomically rare: the reference's loop, verbatim
+			while (range <= 0x00FFFFFFu)
+			{
+				if ((low ^ (low + range)) & 0xFF00000000000000ull) { const u32 rr = (u32)low; range = (rr | 0x00FFFFFFu) - rr; }
+				out[s.pos++] = (u8)(low >> 56);
+				low <<= 8; range <<= 8;
+			}
+			s.low = low; s.range = range;
+			return;
 		}
-		s.low = low; s.range = range;
-		return;
 	}
-	// the top k bytes of low are final
-	const u32 bytes = ((u32)(low >> 40) >> (24 - 8 * k)) & ((1u << (8 * k)) - 1u);
-	s.acc = (s.acc << (8 * k)) | bytes;
-	s.nacc += k;
+	// the top k bytes of low are final; store the top 4 in stream order
+	const u32 top = (u32)(low >> 32);
+	const u32 le = ((top >> 24) & 0xFFu) | ((top >> 8) & 0xFF00u) | ((top << 8) & 0xFF0000u) | (top << 24);
+	typedef u32 __attribute__((aligned(1))) u32_unaligned;
+	*(u32_unaligned*)(out + s.pos) = le;
+	s.pos += k;
 	s.low = low << (8 * k);
 	s.range = range << (8 * k);
-	if (s.nacc >= 4) rc_flush_word(s, out);
 }
 
 __global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, const u64* trip_pool, u32* word_pool, BlkState* st, const u64* magic_tab)
@@ -401,49 +402,38 @@ __global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, 
 	if (id >= n_chains) return;
 	const RcChain c = chains[id];
 	const u64* trip = trip_pool + c.trip;
-	u32* out = word_pool + c.out_words;
+	u8* out = (u8*)(word_pool + c.out_words);
 	RcState s;
-	s.low = 0; s.range = 0xFFFFFFFFu; s.ovf = false;
-	s.cap = (c.out_byte0 + c.out_cap) & ~3u;
-	// the prologue bytes (scheme byte / presence map) share the first word with the coder output
-	const u32 m = c.out_byte0 & 3u;
-	s.pos = c.out_byte0 - m; s.nacc = m;
-	s.acc = m ? (u64)(out[s.pos >> 2] >> (8 * (4 - m))) : 0;
+	s.low = 0; s.range = 0xFFFFFFFFu; s.pos = c.out_byte0;
 
 	const u32 n = c.n, stride = c.stride;
-	u64 buf[RC_AHEAD], mg[RC_AHEAD];
+	u64 cur[RC_AHEAD], mg[RC_AHEAD], nxt[RC_AHEAD];
 #pragma unroll
-	for (u32 i = 0; i < RC_AHEAD; ++i) buf[i] = i < n ? trip[(u64)i * stride] : 0;
+	for (u32 i = 0; i < RC_AHEAD; ++i) cur[i] = i < n ? trip[(u64)i * stride] : 0;
 #pragma unroll
-	for (u32 i = 0; i < RC_AHEAD; ++i) mg[i] = magic_tab[(u32)(buf[i] >> 32) & 0xFFFFu];
+	for (u32 i = 0; i < RC_AHEAD; ++i) nxt[i] = RC_AHEAD + i < n ? trip[(u64)(RC_AHEAD + i) * stride] : 0;
+#pragma unroll
+	for (u32 i = 0; i < RC_AHEAD; ++i) mg[i] = magic_tab[(u32)(cur[i] >> 32) & 0xFFFFu];
 	u32 t0 = 0;
 	for (; t0 + RC_AHEAD <= n; t0 += RC_AHEAD)
 	{
-		u64 nb[RC_AHEAD], nm[RC_AHEAD];
+		u64 nm[RC_AHEAD], far[RC_AHEAD];
+		// stage 1: reciprocals of the next group (its triples arrived one iteration ago); stage 2: triples two groups ahead
 #pragma unroll
-		for (u32 i = 0; i < RC_AHEAD; ++i) { const u32 t = t0 + RC_AHEAD + i; nb[i] = t < n ? trip[(u64)t * stride] : 0; }
+		for (u32 i = 0; i < RC_AHEAD; ++i) nm[i] = magic_tab[(u32)(nxt[i] >> 32) & 0xFFFFu];
 #pragma unroll
-		for (u32 i = 0; i < RC_AHEAD; ++i) rc_step(s, out, buf[i], mg[i]);
+		for (u32 i = 0; i < RC_AHEAD; ++i) { const u32 t = t0 + 2 * RC_AHEAD + i; far[i] = t < n ? trip[(u64)t * stride] : 0; }
 #pragma unroll
-		for (u32 i = 0; i < RC_AHEAD; ++i) nm[i] = magic_tab[(u32)(nb[i] >> 32) & 0xFFFFu];
+		for (u32 i = 0; i < RC_AHEAD; ++i) rc_step(s, out, cur[i], mg[i]);
 #pragma unroll
-		for (u32 i = 0; i < RC_AHEAD; ++i) { buf[i] = nb[i]; mg[i] = nm[i]; }
+		for (u32 i = 0; i < RC_AHEAD; ++i) { cur[i] = nxt[i]; mg[i] = nm[i]; nxt[i] = far[i]; }
 	}
 #pragma unroll
-	for (u32 i = 0; i < RC_AHEAD; ++i) if (t0 + i < n) rc_step(s, out, buf[i], mg[i]);
+	for (u32 i = 0; i < RC_AHEAD; ++i) if (t0 + i < n) rc_step(s, out, cur[i], mg[i]);
 
-	for (u32 k = 0; k < 8; ++k)                                                    // RangeEncoder::End
-	{
-		s.acc = (s.acc << 8) | (s.low >> 56); s.nacc++; s.low <<= 8;
-		if (s.nacc >= 4) rc_flush_word(s, out);
-	}
-	const u32 total = s.pos + s.nacc;
-	for (u32 k = 0; k < s.nacc; ++k)
-	{
-		if (s.pos + k < c.out_byte0 + c.out_cap) put_byte(out, s.pos + k, (u32)(s.acc >> (8 * (s.nacc - 1 - k)))); else s.ovf = true;
-	}
-	if (c.is_dna) st[c.blk].dna_bytes = total; else st[c.blk].qua_bytes = total;
-	if (s.ovf) atomicOr(&st[c.blk].err, (u32)DSRC_ERR_OUT_OVERFLOW);
+	for (u32 k = 0; k < 8; ++k) { out[s.pos++] = (u8)(s.low >> 56); s.low <<= 8; }      // RangeEncoder::End
+	if (c.is_dna) st[c.blk].dna_bytes = s.pos; else st[c.blk].qua_bytes = s.pos;
+	if (s.pos > c.out_byte0 + c.out_cap) atomicOr(&st[c.blk].err, (u32)DSRC_ERR_OUT_OVERFLOW);
 }
 
 // ---- stream prologues ---------------------------------------------------------------------------
@@ -456,15 +446,16 @@ __global__ void __launch_bounds__(64) k_rc_headers(const CtxJob* jobs, u32 n_job
 	if (i >= n_jobs) return;
 	const CtxJob j = jobs[i];
 	u32* out = word_pool + j.out_words;
-	if (j.is_dna) { put_byte(out, 0, j.scheme); return; }
+	u8* ob = (u8*)out;                      // range-coder streams are staged as plain bytes
+	if (j.is_dna) { ob[0] = (u8)j.scheme; return; }
 	if (!j.translate) return;
-	put_byte(out, 0, j.scheme);
+	ob[0] = (u8)j.scheme;
 	const BlkState* S = &st[j.blk];
 	for (u32 k = 0; k < 32; ++k)
 	{
 		u32 v = 0;
 		for (u32 b = 0; b < 8; ++b) v = (v << 1) | (S->q_sym[8 * k + b] != 255 ? 1u : 0u);
-		put_byte(out, 1 + k, v);
+		ob[1 + k] = (u8)v;
 	}
 }
 

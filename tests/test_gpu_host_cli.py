@@ -1,0 +1,59 @@
+"""Whole-file drop-in check on the GPU: the C++ host (DsrcCompressorGPU behind the dsrc-amd CLI) must write
+the same .dsrc bytes as the reference CLI (`dsrc c -t1`, oracle/_ref/dsrc_ref) and the reference must decode
+our archive back to the input."""
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+from dsrc_amd import synth
+from tests._oracle import REF_BIN
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "dsrc_amd", "csrc", "dsrc-amd")
+
+
+def md5(p):
+    return hashlib.md5(open(p, "rb").read()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("cli")
+    ill = d / "ill.fastq"; ill.write_bytes(synth.illumina_fastq(30000))
+    ion = d / "ion.fastq"; ion.write_bytes(synth.iontorrent_fastq(8000))
+    return d, str(ill), str(ion)
+
+
+def _run(args):
+    subprocess.check_call(args, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+@pytest.mark.parametrize("flags", [["-d3", "-q2"], ["-d0", "-q0"], ["-d2", "-q1", "-l"], ["-d1", "-q1", "-c"]])
+def test_illumina_archive_identical(files, flags):
+    if not os.path.exists(CLI):
+        pytest.skip("dsrc-amd not built")
+    d, ill, _ = files
+    ours = str(d / "ours.dsrc"); theirs = str(d / "ref.dsrc")
+    _run([CLI, "c", *flags, "-b1", ill, ours])
+    if not os.path.exists(REF_BIN):
+        pytest.skip("reference CLI not shipped")
+    _run([REF_BIN, "c", *flags, "-b1", "-t1", ill, theirs])
+    assert md5(ours) == md5(theirs)
+    back = str(d / "back.fastq")
+    _run([REF_BIN, "d", "-t1", ours, back])
+    if "-l" not in flags:
+        assert open(back, "rb").read() == open(ill, "rb").read()
+
+
+def test_iontorrent_lossy_archive_identical(files):
+    if not os.path.exists(CLI) or not os.path.exists(REF_BIN):
+        pytest.skip("CLI missing")
+    d, _, ion = files
+    ours = str(d / "o.dsrc"); theirs = str(d / "r.dsrc")
+    _run([CLI, "c", "-d2", "-q1", "-l", "-b1", ion, ours])
+    _run([REF_BIN, "c", "-d2", "-q1", "-l", "-b1", "-t1", ion, theirs])
+    assert md5(ours) == md5(theirs)
