@@ -1,23 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- raw FASTQ MB/s through the MI355X block-compression path (BASELINE.json metric).
 
-A *step* = one scheduler pass (dsrcgpu_compress_batch_device) over `--blocks` consecutive 8 MiB
-chunks of the synthetic 150 bp Illumina-like data set (BASELINE.json configs[2]: 100 M reads,
--d3 -q2, default -b8), generated on the device by the counter-based generator so that every rank /
-step can produce its own shard.  Inputs are resident in HBM when the timed region starts and the
-compressed blocks stay in HBM (PCIe is not in `value`).
+Workload (BASELINE.json configs[2] shape): synthetic Illumina-like 150 bp FASTQ of the 100 M-read data
+set, -d3 -q2, default -b8 (8 MiB chunks cut where IFastqStreamReader::ReadNextChunk would cut them).
+A *step* = `--blocks` consecutive chunks per GPU, generated in HBM by the counter-based generator before
+the timed region and pushed through dsrcgpu_compress_batch_device; compressed blocks stay in HBM (PCIe is
+not in `value`).  Inside a step the chunks go through `--pipeline` independent scheduler instances
+(own HIP stream + arena each) half a period apart, so that the serial range-coder kernel of one sub-batch
+overlaps the data-parallel front end of the next; the timed region covers all K steps end to end.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); blocks are independent, so
-ranks take disjoint record ranges (weak scaling, no collective in the data path) and only the
-per-block sizes / the compressed stream are gathered to rank 0 after the timed region.
+N > 1: one process per GPU (torch.distributed, nccl = RCCL).  Ranks take disjoint record ranges (weak
+scaling, no collective in the data path); after each step the compressed block stream is gathered to
+rank 0 in archive order (dsrc_amd/dist.py), inside the timed region.
 """
 from __future__ import annotations
 
 import argparse
-import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -27,12 +29,13 @@ sys.path.insert(0, ROOT)
 
 BUF = 8 << 20                     # -b8 (reference default, src/Common.h:156)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+RECS_PER_BLOCK = 22300
 
 
 def title_len(i: np.ndarray) -> np.ndarray:
     def digits(v):
         d = np.ones(v.shape, dtype=np.int64)
-        for k in range(1, 20):
+        for k in range(1, 19):
             d += (v >= 10 ** k)
         return d
     x = 1000 + (7 * i) % 20000
@@ -49,25 +52,24 @@ def record_offsets(first: int, count: int) -> np.ndarray:
 
 
 def cut_blocks(off: np.ndarray, nblocks: int):
-    """Chunk boundaries as IFastqStreamReader::ReadNextChunk would place them (reference
-    src/FastqStream.cpp:18-98): a chunk ends just before the first record that starts after
-    byte (start + buf - 8192); its size excludes the final newline."""
-    starts, sizes, recs = [], [], []
+    """Chunk boundaries as IFastqStreamReader::ReadNextChunk places them (reference src/FastqStream.cpp:18-98):
+    a chunk ends just before the first record that starts after byte (start + buf - 8192); its size excludes
+    the final newline."""
+    starts, sizes = [], []
     r = 0
     for _ in range(nblocks):
         start = off[r]
-        pos = start + BUF - 8192
-        nxt = int(np.searchsorted(off, pos, side="right"))
+        nxt = int(np.searchsorted(off, start + BUF - 8192, side="right"))
         if nxt >= len(off):
             break
-        starts.append(int(start)); sizes.append(int(off[nxt] - start - 1)); recs.append(nxt - r)
+        starts.append(int(start)); sizes.append(int(off[nxt] - start - 1))
         r = nxt
-    return starts, sizes, recs, r
+    return starts, sizes
 
 
 def cpu_baseline(sample: bytes, d: int, q: int):
-    """Reference (oracle/_ref, unmodified DSRC built from /root/reference) multi-threaded on the host
-    cores, or our C port on one core when _ref is absent.  Reported beside the GPU number only."""
+    """The unmodified reference (oracle/_ref, DsrcCompressorMT) on the host cores, or our C port on one core when
+    _ref is absent.  Reported beside the GPU number; it is not the target."""
     import tempfile
     from tests._oracle import Oracle, Ref, have_ref
     # the reference's queues use a 64-bit completion mask: thread counts >= 64 are undefined (SURVEY Appendix B.20)
@@ -87,7 +89,52 @@ def cpu_baseline(sample: bytes, d: int, q: int):
         assert rc == 0
     return {"value": round(len(sample) / dt / 1e6, 2), "unit": "MB/s", "cores": cores, "kind": kind,
             "sample": f"{len(sample)} bytes of the same synthetic FASTQ ({len(sample) // BUF + 1} blocks), -d{d} -q{q} -b8, "
-                      f"file in tmpfs, {cores} worker threads"}
+                      f"input and output in tmpfs, {cores} worker threads, wall {dt:.2f} s"}
+
+
+class Lane:
+    """One scheduler instance: own handle (HIP stream + arena) and its sub-batches."""
+
+    def __init__(self, cfg, device, sub_blocks, n_sub, rank, lane_id, n_lanes, alloc_out):
+        from dsrc_amd._lib import Handle
+        self.h = Handle(cfg.dna_order, cfg.quality_order, quality_offset=33, device=device)
+        self.sub = []
+        recs = int(sub_blocks * RECS_PER_BLOCK * 1.02) + 1000
+        cap_in = recs * 384
+        self.cap_out = cap_in // 2
+        for k in range(n_sub):
+            gid = (rank * n_lanes + lane_id) * n_sub + k            # disjoint record range per (rank, lane, sub-batch)
+            first = 1 + gid * recs
+            d_in = self.h.dev_alloc(cap_in)
+            nbytes = self.h.synth_illumina(first, recs, d_in, cap_in)
+            off = record_offsets(first, recs)
+            assert off[-1] == nbytes, (off[-1], nbytes)
+            starts, sizes = cut_blocks(off, sub_blocks)
+            assert len(starts) == sub_blocks
+            self.sub.append((d_in, starts, sizes))
+        self.d_out, self.out_keep = alloc_out(self.h, self.cap_out)
+        self.results = {}
+        self.timing = []
+
+    def run(self, k):
+        d_in, starts, sizes = self.sub[k]
+        res = self.h.compress_batch_device(d_in, starts, sizes, self.d_out, self.cap_out)
+        self.results[k] = res
+        self.timing.append(self.h.last_timing())
+        return res
+
+
+class StepGate:
+    """N > 1 only: all lanes of a step finish before its gather (which runs on the main thread)."""
+
+    def __init__(self):
+        self.n = 0; self.cv = threading.Condition(); self.gathered = False
+
+    def wait_lane(self):
+        with self.cv:
+            self.n += 1; self.cv.notify_all()
+            while not self.gathered:
+                self.cv.wait()
 
 
 def main():
@@ -95,95 +142,122 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=int(os.environ.get("DSRC_BENCH_BLOCKS", "256")), help="8 MiB chunks per step per GPU")
+    ap.add_argument("--blocks", type=int, default=int(os.environ.get("DSRC_BENCH_BLOCKS", "768")), help="8 MiB chunks per step per GPU")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DSRC_BENCH_PIPELINE", "2")), help="scheduler instances per GPU")
     ap.add_argument("--dna", type=int, default=3)
     ap.add_argument("--qua", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--check", type=int, default=2, help="blocks of the first step to verify against the oracle")
+    ap.add_argument("--check", type=int, default=2, help="blocks of the first sub-batch to verify against the oracle")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
+    dist = None; torch = None
     if world > 1:
-        import torch
+        import torch as torch_
         import torch.distributed as dist_
+        torch = torch_
         torch.cuda.set_device(local)
         dist_.init_process_group("nccl", device_id=torch.device("cuda", local))
         dist = dist_
 
-    from dsrc_amd._lib import Handle
     from tests._oracle import Config
     cfg = Config.from_levels(args.dna, args.qua)
-    h = Handle(cfg.dna_order, cfg.quality_order, quality_offset=33, device=local)
-
-    recs_per_block = 22300
-    per_step_recs = int(args.blocks * recs_per_block * 1.02) + 1000
+    P = max(1, args.pipeline)
+    sub_blocks = max(1, args.blocks // P)
     total_steps = args.steps + args.warmup
-    # rank r, step s covers records [base, base + per_step_recs)
-    cap_in = per_step_recs * 384
-    d_in = h.dev_alloc(cap_in)
-    d_out = h.dev_alloc(cap_in // 2)
 
-    def prepare(step):
-        first = 1 + (rank * total_steps + step) * per_step_recs
-        nbytes = h.synth_illumina(first, per_step_recs, d_in, cap_in)
-        off = record_offsets(first, per_step_recs)
-        assert off[-1] == nbytes, (off[-1], nbytes)
-        starts, sizes, recs, _ = cut_blocks(off, args.blocks)
-        assert len(starts) == args.blocks
-        return first, starts, sizes, recs
+    def alloc_out(h, cap):
+        if torch is not None:                      # a torch tensor so that the gather can send it over RCCL
+            t = torch.empty(cap, dtype=torch.uint8, device="cuda")
+            return t.data_ptr(), t
+        return h.dev_alloc(cap), None
 
-    def barrier():
+    lanes = [Lane(cfg, local, sub_blocks, total_steps, rank, i, P, alloc_out) for i in range(P)]
+
+    def sync_all():
+        if torch is not None:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    def run(step_info):
-        _, starts, sizes, _ = step_info
-        return h.compress_batch_device(d_in, starts, sizes, d_out, cap_in // 2)
+    def gather_step(step):
+        if dist is None:
+            return
+        from dsrc_amd.dist import gather_block_stream
+        for ln in lanes:
+            _, o_sizes, _, _ = ln.results[step]
+            gather_block_stream(o_sizes, ln.out_keep)
 
-    def stage(step_info):
-        pass
-
-    infos = []
-    t_kernel = []; t_rc = []
-    in_bytes = 0; out_bytes = 0
-    first_out = None
+    # ---- warmup (also sizes the arenas and measures one sub-batch for the stagger) ------------------------
+    t_sub = 0.0
+    first_chunks = None; first_blob = None
     for s in range(args.warmup):
-        info = prepare(s); stage(info); res = run(info)
-        if s == 0:
-            first_out = (info, res, h.dev_download(d_out, res[0][min(args.check, len(res[0])) - 1] + res[1][min(args.check, len(res[0])) - 1]) if args.check else b"")
-            first_chunks = [h.dev_download(d_in + info[1][i], info[2][i]) for i in range(min(args.check, args.blocks))]
-    barrier()
-    wall = 0.0
-    for s in range(args.warmup, total_steps):
-        info = prepare(s); stage(info)
-        barrier()
-        t0 = time.perf_counter()
-        res = run(info)
-        barrier()
-        wall += time.perf_counter() - t0
-        ms, rc_ms, nrc = h.last_timing()
-        t_kernel.append(ms); t_rc.append(rc_ms)
-        in_bytes += sum(info[2]) + len(info[2]); out_bytes += sum(res[1])
-        if first_out is None and args.check:
-            first_out = (info, res, h.dev_download(d_out, res[0][args.check - 1] + res[1][args.check - 1]))
-            first_chunks = [h.dev_download(d_in + info[1][i], info[2][i]) for i in range(min(args.check, args.blocks))]
+        for ln in lanes:
+            t0 = time.perf_counter(); res = ln.run(s); t_sub = time.perf_counter() - t0
+            if first_chunks is None and args.check and rank == 0:
+                d_in, starts, sizes = ln.sub[s]
+                n = min(args.check, sub_blocks)
+                first_chunks = [ln.h.dev_download(d_in + starts[i], sizes[i]) for i in range(n)]
+                first_blob = (res, ln.h.dev_download(ln.d_out, res[0][n - 1] + res[1][n - 1]))
+        gather_step(s)
+    for ln in lanes:
+        ln.timing.clear()
 
-    # parity spot-check of the first step against the oracle (outside the timed region)
+    # ---- timed region: K steps, lanes half a period apart ---------------------------------------------------
+    step_done = {s: StepGate() for s in range(args.warmup, total_steps)}
+    errors = []
+
+    def worker(idx):
+        try:
+            if idx:
+                time.sleep(t_sub * idx / P)
+            for s in range(args.warmup, total_steps):
+                lanes[idx].run(s)
+                if dist is not None:
+                    step_done[s].wait_lane()
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    sync_all()
+    t_begin = time.perf_counter()
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(P)]
+    for t in threads:
+        t.start()
+    if dist is not None:
+        for s in range(args.warmup, total_steps):
+            g = step_done[s]
+            with g.cv:
+                while g.n < P:
+                    g.cv.wait()
+            gather_step(s)
+            with g.cv:
+                g.gathered = True; g.cv.notify_all()
+    for t in threads:
+        t.join()
+    sync_all()
+    wall = time.perf_counter() - t_begin
+    if errors:
+        raise errors[0]
+
+    in_bytes = 0; out_bytes = 0
+    for ln in lanes:
+        for s in range(args.warmup, total_steps):
+            in_bytes += sum(ln.sub[s][2]) + len(ln.sub[s][2])
+            out_bytes += sum(ln.results[s][1])
+
+    # parity spot-check against the oracle (outside the timed region)
     checked = 0
-    if rank == 0 and args.check and first_out is not None:
+    if rank == 0 and first_chunks:
         from tests._oracle import Oracle
         o = Oracle()
-        info, res, blob = first_out
-        for i in range(min(args.check, args.blocks)):
-            want = o.compress_block(cfg, first_chunks[i])[0]
-            got = blob[res[0][i]: res[0][i] + res[1][i]]
-            assert got == want, f"bench parity check failed on block {i}"
+        res, blob = first_blob
+        for i, ch in enumerate(first_chunks):
+            want = o.compress_block(cfg, ch)[0]
+            assert blob[res[0][i]: res[0][i] + res[1][i]] == want, f"bench parity check failed on block {i}"
             checked += 1
 
     if dist is not None:
-        import torch
         t = torch.tensor([wall, float(in_bytes), float(out_bytes)], device="cuda", dtype=torch.float64)
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
@@ -191,35 +265,35 @@ def main():
 
     if rank == 0:
         value = in_bytes / wall / 1e6
-        rc_avg = sum(t_rc) / max(1, len(t_rc))
-        k_avg = sum(t_kernel) / max(1, len(t_kernel))
-        per_rank_in = in_bytes / world / args.steps; per_rank_out = out_bytes / world / args.steps
-        alg_bytes = per_rank_in + per_rank_out            # chunk read once + block written once
-        achieved = alg_bytes / (k_avg / 1e3) / 1e9 if k_avg > 0 else 0.0
+        tm = [x for ln in lanes for x in ln.timing]
+        batch_ms = sum(x[0] for x in tm) / max(1, len(tm))
+        rc_ms = sum(x[1] for x in tm) / max(1, len(tm))
+        n_sub_total = world * P * args.steps
+        alg = (in_bytes + out_bytes) / n_sub_total               # chunk read once + block written once, per sub-batch launch
+        achieved = alg / (rc_ms / 1e3) / 1e9 if rc_ms > 0 else 0.0
         line = {
             "metric": "raw FASTQ MB/s compressed (bit-identical .dsrc)", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16/u32 integer", "data": "synthetic",
-            "config": {"workload": f"Synthetic Illumina 150 bp FASTQ (BASELINE configs[2] shape: 100M-read set), -d{args.dna} -q{args.qua} -b8; "
-                                   f"one step = {args.blocks} consecutive 8 MiB blocks per GPU, device-resident",
-                       "blocks_per_step": args.blocks, "parallelism": f"blocks sharded over {world} GPU(s), no data-path collective",
+            "config": {"workload": f"Synthetic Illumina 150 bp FASTQ, 100M-read data set shape (BASELINE configs[2]), -d{args.dna} -q{args.qua} -b8; "
+                                   f"step = {args.blocks} consecutive 8 MiB chunks per GPU, device-resident, {P} scheduler instances per GPU",
+                       "blocks_per_step": args.blocks, "pipeline": P,
+                       "parallelism": f"blocks sharded over {world} GPU(s); per-step RCCL gather of the block stream to rank 0" if world > 1 else "1 GPU",
                        "ratio_out_in": round(out_bytes / in_bytes, 4), "parity_checked_blocks": checked},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "whole batch (all kernels of one scheduler pass, HIP events on the scheduler stream)",
-                         "batch_ms": round(k_avg, 2), "k_rc_ms": round(rc_avg, 2)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "k_rc (range coder, one lane per stream)",
+                         "kernel_ms": round(rc_ms, 2), "launch_bytes": int(alg), "batch_ms": round(batch_ms, 2),
+                         "note": "algorithmic bytes = chunk bytes in + block bytes out of one sub-batch launch; durations from HIP events on the scheduler stream"},
         }
         if not args.no_cpu and world == 1:
-            sample_blocks = 120
-            from dsrc_amd import synth
-            nrec = sample_blocks * 22000
-            # the same generator on the host would take minutes in numpy; download the device bytes instead
-            need = min(sample_blocks, args.blocks)
-            info = prepare(0)
-            sample = h.dev_download(d_in, info[1][need - 1] + info[2][need - 1] + 1)
+            ln = lanes[0]
+            d_in, starts, sizes = ln.sub[0]
+            need = min(120, sub_blocks)
+            sample = ln.h.dev_download(d_in, starts[need - 1] + sizes[need - 1] + 1)
             line["cpu_baseline"] = cpu_baseline(sample, args.dna, args.qua)
         print(json.dumps(line))
-    h.close()
+    for ln in lanes:
+        ln.h.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -26,7 +26,8 @@ struct CtxJob     // one (block, stream)
 	u64 src_off;        // byte offset of the symbol stream (q_stream / d_stream)
 	u64 elems;          // u64 index of sort buffer A
 	u64 elems_b;        // u64 index of sort buffer B
-	u64 trip;           // u64 index of this chain's first triple (group base + lane)
+	u64 trip;           // u64 index of this chain's first (reciprocal,freq) word (group base + lane)
+	u64 cum;            // u16 index of this chain's first cumulative frequency
 	u32 n;              // symbols
 	u32 blk;
 	u32 alpha_bits;     // log2(alphabet)
@@ -207,11 +208,12 @@ template <int N> __device__ __forceinline__ void replay_prefix(const ReplayRow<N
 }
 
 template <int N>
-__global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const u64* pool, u64* trip_pool)
+__global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const u64* pool, u64* trip_pool, const u64* magic_tab)
 {
 	const CtxJob j = jobs[blockIdx.y];
 	const u64* src = pool + (j.sorted_in_b ? j.elems_b : j.elems);
 	u64* trip = trip_pool + j.trip;
+	u16* cums = (u16*)trip_pool + j.cum;
 	const u32 n = j.n, stride = j.trip_stride;
 	const u32 lane = lane_id();
 	const u32 limit = (1u << 16) - 2u * N;                   // MaxAccumulatedValue (src/SymbolCoderRC.h:67)
@@ -299,7 +301,12 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 			if (in_cont) { f = b0 + 2 * (cc + same); cum = cb + 2 * (cp + less); tot = T0 + 2 * (epoch_cnt + in_seg); }
 			else { f = 1 + 2 * same; cum = sym + 2 * less; tot = N + 2 * in_seg; }
 		}
-		if (active) trip[(u64)(u32)el * stride] = ((u64)tot << 32) | ((u64)cum << 16) | f;
+		if (active)
+		{	// what k_rc needs per symbol: the 48-bit reciprocal of `total` (see rc_div), freq, cum
+			const u64 at = (u64)(u32)el * stride;
+			trip[at] = (magic_tab[tot & 0xFFFFu] << 16) | f;
+			cums[at] = (u16)cum;
+		}
 
 		// carry the segment that is open at the end of the window
 		if (tile_len > 0)
@@ -337,7 +344,8 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 // and output bytes are packed into 32-bit words before they are stored.
 struct RcChain
 {
-	u64 trip;          // u64 index of the chain's first triple
+	u64 trip;          // u64 index: (reciprocal << 16 | freq) of symbol t at trip + t*stride
+	u64 cum;           // u16 index: cumulative frequency of symbol t at cum + t*stride
 	u64 out_words;     // u32 index of the staging stream
 	u32 n;
 	u32 out_byte0, out_cap;
@@ -349,26 +357,34 @@ struct RcChain
 
 // exact floor(range / total) without a divide on the serial chain: magic[d] = ceil(2^48 / d);
 // floor(n * magic / 2^48) == floor(n / d) for every n < 2^32, d <= 2^16 (the error term n*e/2^48 < 2^-16
-// cannot carry the fraction (<= 1 - 1/d) over an integer).  The table (512 KiB, L2-resident) is built once
-// per handle; its entry is fetched RC_AHEAD symbols ahead of the coder, the triple 2*RC_AHEAD ahead.
-__device__ __forceinline__ u32 rc_div(u32 range, u64 magic)
+// cannot carry the fraction (<= 1 - 1/d) over an integer).  k_replay looks the reciprocal up (512 KiB
+// table, L2-resident) and stores it instead of `total`, so the coder's loads are two coalesced rows.
+__device__ __forceinline__ u32 rc_div(u32 range, u32 m_lo, u32 m_hi)
 {
-	const u32 t = __umulhi(range, (u32)magic);
-	return (u32)(((u64)range * (u32)(magic >> 32) + t) >> 16);
+	const u32 t = __umulhi(range, m_lo);
+	return (u32)(((u64)range * m_hi + t) >> 16);
 }
 
-// Output: range-coder streams are staged as PLAIN bytes (stream byte k at address k; BlkDesc::*_plain tells
-// k_assemble), so the k (0..3) bytes that leave the coder are written with one unaligned 32-bit store at the
-// current position; the bytes beyond k are overwritten by the following symbols.
-struct RcState { u64 low; u32 range; u32 pos; };
+// Output: range-coder streams are staged as PLAIN bytes (stream byte k at address k; BlkDesc::plain_mask
+// tells k_assemble).  Bytes leaving the coder collect in a 64-bit register and go out four at a time.
+struct RcState { u64 low; u32 range; u64 acc; u32 nacc; u32 pos; };
 
-__device__ __forceinline__ void rc_step(RcState& s, u8* out, u64 e, u64 magic)
+typedef u32 __attribute__((aligned(1))) u32_unaligned;
+
+__device__ __forceinline__ void rc_flush4(RcState& s, u8* out)
 {
-	const u32 f = (u32)e & 0xFFFFu, cum = (u32)(e >> 16) & 0xFFFFu;
-	const u32 r = rc_div(s.range, magic);
+	const u32 w = (u32)(s.acc >> (8 * (s.nacc - 4)));                      // oldest four pending bytes, first byte in the MSB
+	*(u32_unaligned*)(out + s.pos) = ((w >> 24) & 0xFFu) | ((w >> 8) & 0xFF00u) | ((w << 8) & 0xFF0000u) | (w << 24);
+	s.pos += 4; s.nacc -= 4;
+}
+
+__device__ __forceinline__ void rc_step(RcState& s, u8* out, u64 e, u32 cum)
+{
+	const u32 f = (u32)e & 0xFFFFu;
+	const u32 r = rc_div(s.range, (u32)(e >> 16), (u32)(e >> 48));
 	u64 low = s.low + (u32)(r * cum);
 	u32 range = r * f;
-	u32 k = range > 0x00FFFFFFu ? 0u : (u32)__clz((int)range) >> 3;            // bytes leaving the coder (0..3)
+	const u32 k = (u32)__builtin_clz(range) >> 3;                               // bytes leaving the coder (0..3); range != 0
 	// RangeEncoder::EncodeFrequency's carry clamp (src/RangeCoder.h:64-74) can only trigger when adding
 	// range (< 2^24) to low carries through bits 24..39: those 16 bits must all be ones
 	if (k && ((u32)(low >> 24) & 0xFFFFu) == 0xFFFFu)
@@ -379,58 +395,58 @@ __device__ __forceinline__ void rc_step(RcState& s, u8* out, u64 e, u64 magic)
 			while (range <= 0x00FFFFFFu)
 			{
 				if ((low ^ (low + range)) & 0xFF00000000000000ull) { const u32 rr = (u32)low; range = (rr | 0x00FFFFFFu) - rr; }
-				out[s.pos++] = (u8)(low >> 56);
+				s.acc = (s.acc << 8) | (low >> 56); s.nacc++;
+				if (s.nacc >= 4) rc_flush4(s, out);
 				low <<= 8; range <<= 8;
 			}
 			s.low = low; s.range = range;
 			return;
 		}
 	}
-	// the top k bytes of low are final; store the top 4 in stream order
-	const u32 top = (u32)(low >> 32);
-	const u32 le = ((top >> 24) & 0xFFu) | ((top >> 8) & 0xFF00u) | ((top << 8) & 0xFF0000u) | (top << 24);
-	typedef u32 __attribute__((aligned(1))) u32_unaligned;
-	*(u32_unaligned*)(out + s.pos) = le;
-	s.pos += k;
-	s.low = low << (8 * k);
-	s.range = range << (8 * k);
+	// the top k bytes of low are final
+	const u32 sh = 8 * k;
+	s.acc = (s.acc << sh) | (u32)((low >> 8) >> (56 - sh));
+	s.nacc += k;
+	s.low = low << sh;
+	s.range = range << sh;
+	if (s.nacc >= 4) rc_flush4(s, out);
 }
 
-__global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, const u64* trip_pool, u32* word_pool, BlkState* st, const u64* magic_tab)
+__global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, const u64* trip_pool, u32* word_pool, BlkState* st)
 {
 	const u32 id = blockIdx.x * 64 + threadIdx.x;
 	if (id >= n_chains) return;
 	const RcChain c = chains[id];
 	const u64* trip = trip_pool + c.trip;
+	const u16* cums = (const u16*)trip_pool + c.cum;
 	u8* out = (u8*)(word_pool + c.out_words);
 	RcState s;
-	s.low = 0; s.range = 0xFFFFFFFFu; s.pos = c.out_byte0;
+	s.low = 0; s.range = 0xFFFFFFFFu; s.pos = c.out_byte0; s.acc = 0; s.nacc = 0;
 
 	const u32 n = c.n, stride = c.stride;
-	u64 cur[RC_AHEAD], mg[RC_AHEAD], nxt[RC_AHEAD];
+	u64 cur[RC_AHEAD], nxt[RC_AHEAD];
+	u32 cc[RC_AHEAD], nc[RC_AHEAD];
 #pragma unroll
-	for (u32 i = 0; i < RC_AHEAD; ++i) cur[i] = i < n ? trip[(u64)i * stride] : 0;
-#pragma unroll
-	for (u32 i = 0; i < RC_AHEAD; ++i) nxt[i] = RC_AHEAD + i < n ? trip[(u64)(RC_AHEAD + i) * stride] : 0;
-#pragma unroll
-	for (u32 i = 0; i < RC_AHEAD; ++i) mg[i] = magic_tab[(u32)(cur[i] >> 32) & 0xFFFFu];
+	for (u32 i = 0; i < RC_AHEAD; ++i) { const bool in = i < n; cur[i] = in ? trip[(u64)i * stride] : 0; cc[i] = in ? cums[(u64)i * stride] : 0; }
 	u32 t0 = 0;
 	for (; t0 + RC_AHEAD <= n; t0 += RC_AHEAD)
 	{
-		u64 nm[RC_AHEAD], far[RC_AHEAD];
-		// stage 1: reciprocals of the next group (its triples arrived one iteration ago); stage 2: triples two groups ahead
 #pragma unroll
-		for (u32 i = 0; i < RC_AHEAD; ++i) nm[i] = magic_tab[(u32)(nxt[i] >> 32) & 0xFFFFu];
+		for (u32 i = 0; i < RC_AHEAD; ++i)
+		{
+			const u32 t = t0 + RC_AHEAD + i; const bool in = t < n;
+			nxt[i] = in ? trip[(u64)t * stride] : 0; nc[i] = in ? cums[(u64)t * stride] : 0;
+		}
 #pragma unroll
-		for (u32 i = 0; i < RC_AHEAD; ++i) { const u32 t = t0 + 2 * RC_AHEAD + i; far[i] = t < n ? trip[(u64)t * stride] : 0; }
+		for (u32 i = 0; i < RC_AHEAD; ++i) rc_step(s, out, cur[i], cc[i]);
 #pragma unroll
-		for (u32 i = 0; i < RC_AHEAD; ++i) rc_step(s, out, cur[i], mg[i]);
-#pragma unroll
-		for (u32 i = 0; i < RC_AHEAD; ++i) { cur[i] = nxt[i]; mg[i] = nm[i]; nxt[i] = far[i]; }
+		for (u32 i = 0; i < RC_AHEAD; ++i) { cur[i] = nxt[i]; cc[i] = nc[i]; }
 	}
 #pragma unroll
-	for (u32 i = 0; i < RC_AHEAD; ++i) if (t0 + i < n) rc_step(s, out, cur[i], mg[i]);
+	for (u32 i = 0; i < RC_AHEAD; ++i) if (t0 + i < n) rc_step(s, out, cur[i], cc[i]);
 
+	for (u32 k = 0; k < s.nacc; ++k) out[s.pos + k] = (u8)(s.acc >> (8 * (s.nacc - 1 - k)));
+	s.pos += s.nacc;
 	for (u32 k = 0; k < 8; ++k) { out[s.pos++] = (u8)(s.low >> 56); s.low <<= 8; }      // RangeEncoder::End
 	if (c.is_dna) st[c.blk].dna_bytes = s.pos; else st[c.blk].qua_bytes = s.pos;
 	if (s.pos > c.out_byte0 + c.out_cap) atomicOr(&st[c.blk].err, (u32)DSRC_ERR_OUT_OVERFLOW);
