@@ -108,7 +108,7 @@ size_t estimate_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
 	const bool rc = h->set.dna_order > 0 || h->set.quality_order > 0;
 	size_t tot = 0, mx = 0;
 	for (u32 i = 0; i < n; ++i) { tot += (size_t)sizes[i] + 4096; mx = std::max(mx, (size_t)sizes[i]); }
-	return tot * (rc ? 29 : 14) + (size_t)n * (2u << 20) + (16u << 20);
+	return tot * (rc ? 34 : 14) + (size_t)n * (2u << 20) + (16u << 20);
 }
 
 struct BatchIO
@@ -393,8 +393,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			for (u32 i = g * 64; i < std::min(NJ, g * 64 + 64); ++i) mx = std::max(mx, jobs[i].n);
 			gbase[g] = trip_words; trip_words += (size_t)mx * (std::min(NJ, g * 64 + 64) - g * 64);
 		}
-		const size_t o_trip = A.alloc(trip_words * 8 + 64);
-		const size_t o_cum = A.alloc(trip_words * 2 + 64);
+		const size_t o_trip = A.alloc(trip_words * sizeof(RcRec) + 64);
 		for (u32 i = 0; i < NJ; ++i)
 		{
 			CtxJob& j = jobs[i];
@@ -402,11 +401,10 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			j.dbits = (j.key_bits + j.passes - 1) / j.passes; if (j.dbits == 0) j.dbits = 1;
 			j.sorted_in_b = j.passes & 1;
 			j.elems = A.alloc((size_t)j.n * 8 + 64) / 8; j.elems_b = A.alloc((size_t)j.n * 8 + 64) / 8;
-			j.trip = o_trip / 8 + gbase[i / 64] + (i % 64);
-			j.cum = o_cum / 2 + gbase[i / 64] + (i % 64);
+			j.trip = o_trip / sizeof(RcRec) + gbase[i / 64] + (i % 64);
 			j.trip_stride = std::min(NJ, (i / 64) * 64 + 64) - (i / 64) * 64;
 			RcChain& c = chains[i];
-			c.trip = j.trip; c.cum = j.cum; c.out_words = j.out_words; c.n = j.n; c.out_byte0 = j.out_byte0; c.out_cap = j.out_cap; c.blk = j.blk; c.is_dna = j.is_dna; c.stride = j.trip_stride;
+			c.trip = j.trip; c.out_words = j.out_words; c.n = j.n; c.out_byte0 = j.out_byte0; c.out_cap = j.out_cap; c.blk = j.blk; c.is_dna = j.is_dna; c.stride = j.trip_stride;
 		}
 	}
 	const size_t o_jobs = A.alloc(sizeof(CtxJob) * std::max(1u, NJ)), o_chains = A.alloc(sizeof(RcChain) * std::max(1u, NJ));
@@ -517,18 +515,18 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			const u32 parts = std::max(1u, std::min(32u, mxn / 16384u));   // REPLAY_WG/64 waves each; >= 4k symbols per wave
 			switch (jobs[lo].n_alpha)
 			{
-			case 4:   hipLaunchKernelGGL(k_replay<4>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool, h->d_rc_magic); break;
-			case 8:   hipLaunchKernelGGL(k_replay<8>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool, h->d_rc_magic); break;
-			case 16:  hipLaunchKernelGGL(k_replay<16>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool, h->d_rc_magic); break;
-			case 32:  hipLaunchKernelGGL(k_replay<32>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool, h->d_rc_magic); break;
-			case 64:  hipLaunchKernelGGL(k_replay<64>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool, h->d_rc_magic); break;
-			default:  hipLaunchKernelGGL(k_replay<128>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, lpool, h->d_rc_magic); break;
+			case 4:   hipLaunchKernelGGL(k_replay<4>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+			case 8:   hipLaunchKernelGGL(k_replay<8>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+			case 16:  hipLaunchKernelGGL(k_replay<16>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+			case 32:  hipLaunchKernelGGL(k_replay<32>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+			case 64:  hipLaunchKernelGGL(k_replay<64>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+			default:  hipLaunchKernelGGL(k_replay<128>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
 			}
 			KCHK();
 			lo = hi;
 		}
 		HIPCHK(hipEventRecord(h->ev[2], s));
-		hipLaunchKernelGGL(k_rc, dim3((NJ + 63) / 64), dim3(64), 0, s, d_chains, NJ, lpool, wpool, d_state); KCHK();
+		hipLaunchKernelGGL(k_rc, dim3((NJ + 63) / 64), dim3(64), 0, s, d_chains, NJ, AP<RcRec>(h, 0), wpool, d_state); KCHK();
 		HIPCHK(hipEventRecord(h->ev[3], s));
 		h->rc_launches = 1;
 	}

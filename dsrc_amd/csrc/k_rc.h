@@ -21,13 +21,15 @@
 #define ELEM_SYM_SHIFT 32
 #define ELEM_CTX_SHIFT 40
 
+// what the range coder consumes per symbol (written by k_replay in stream order, lane-interleaved per group)
+struct __attribute__((aligned(16))) RcRec { u64 w; u32 cum; u32 pad; };   // w = ceil(2^48/total) << 16 | freq
+
 struct CtxJob     // one (block, stream)
 {
 	u64 src_off;        // byte offset of the symbol stream (q_stream / d_stream)
 	u64 elems;          // u64 index of sort buffer A
 	u64 elems_b;        // u64 index of sort buffer B
-	u64 trip;           // u64 index of this chain's first (reciprocal,freq) word (group base + lane)
-	u64 cum;            // u16 index of this chain's first cumulative frequency
+	u64 trip;           // RcRec index of this chain's first record (group base + lane)
 	u32 n;              // symbols
 	u32 blk;
 	u32 alpha_bits;     // log2(alphabet)
@@ -208,12 +210,11 @@ template <int N> __device__ __forceinline__ void replay_prefix(const ReplayRow<N
 }
 
 template <int N>
-__global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const u64* pool, u64* trip_pool, const u64* magic_tab)
+__global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const u64* pool, RcRec* rec_pool)
 {
 	const CtxJob j = jobs[blockIdx.y];
 	const u64* src = pool + (j.sorted_in_b ? j.elems_b : j.elems);
-	u64* trip = trip_pool + j.trip;
-	u16* cums = (u16*)trip_pool + j.cum;
+	RcRec* recs = rec_pool + j.trip;
 	const u32 n = j.n, stride = j.trip_stride;
 	const u32 lane = lane_id();
 	const u32 limit = (1u << 16) - 2u * N;                   // MaxAccumulatedValue (src/SymbolCoderRC.h:67)
@@ -302,10 +303,11 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 			else { f = 1 + 2 * same; cum = sym + 2 * less; tot = N + 2 * in_seg; }
 		}
 		if (active)
-		{	// what k_rc needs per symbol: the 48-bit reciprocal of `total` (see rc_div), freq, cum
-			const u64 at = (u64)(u32)el * stride;
-			trip[at] = (magic_tab[tot & 0xFFFFu] << 16) | f;
-			cums[at] = (u16)cum;
+		{	// what k_rc needs per symbol: the 48-bit reciprocal of `total` (rc_div), freq, cum -- one 16-byte record
+			RcRec rr;
+			rr.w = ((((1ull << 48) + tot - 1) / tot) << 16) | f;
+			rr.cum = cum; rr.pad = 0;
+			recs[(u64)(u32)el * stride] = rr;
 		}
 
 		// carry the segment that is open at the end of the window
@@ -338,14 +340,17 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 // ---- range coder: one lane = one stream ---------------------------------------------------------
 // The only serial part of the path.  Per symbol the dependent chain is
 //   range -> floor(range / total) -> * freq -> renormalise
-// so everything else is kept off it: triples (and the reciprocal of `total`) are prefetched RC_AHEAD
-// symbols ahead (the loads do not depend on the coder state), the renormalisation count comes from
-// clz, the (astronomically rare) carry clamp of RangeEncoder::EncodeFrequency takes a slow path,
-// and output bytes are packed into 32-bit words before they are stored.
+// and on the GPU its cost is instruction issue, so the step is kept to ~25 straight-line instructions:
+//   * floor(range/total) is a multiply by the 48-bit reciprocal k_replay stored (exact, see rc_div);
+//   * records are fetched 16 symbols ahead with one 16-byte load each (ping-pong register buffers);
+//   * the renormalisation count comes from clz; bytes leaving the coder collect in a register and are
+//     stored four at a time;
+//   * RangeEncoder::EncodeFrequency's carry clamp (src/RangeCoder.h:64-74) needs bits 24..39 of `low` to be
+//     all ones; that is accumulated branch-free and checked once per 16 symbols -- if it ever shows, the
+//     group is replayed from a snapshot with the reference's loop, verbatim.
 struct RcChain
 {
-	u64 trip;          // u64 index: (reciprocal << 16 | freq) of symbol t at trip + t*stride
-	u64 cum;           // u16 index: cumulative frequency of symbol t at cum + t*stride
+	u64 trip;          // RcRec index: record of symbol t at trip + t*stride
 	u64 out_words;     // u32 index of the staging stream
 	u32 n;
 	u32 out_byte0, out_cap;
@@ -353,100 +358,111 @@ struct RcChain
 	u32 stride;
 };
 
-#define RC_AHEAD 16
+#define RC_GROUP 16
 
-// exact floor(range / total) without a divide on the serial chain: magic[d] = ceil(2^48 / d);
-// floor(n * magic / 2^48) == floor(n / d) for every n < 2^32, d <= 2^16 (the error term n*e/2^48 < 2^-16
-// cannot carry the fraction (<= 1 - 1/d) over an integer).  k_replay looks the reciprocal up (512 KiB
-// table, L2-resident) and stores it instead of `total`, so the coder's loads are two coalesced rows.
+// magic = ceil(2^48 / d): floor(n * magic / 2^48) == floor(n / d) for every n < 2^32, d <= 2^16 (the error term
+// n*e/2^48 < 2^-16 cannot carry the fraction (<= 1 - 1/d) over an integer)
 __device__ __forceinline__ u32 rc_div(u32 range, u32 m_lo, u32 m_hi)
 {
 	const u32 t = __umulhi(range, m_lo);
 	return (u32)(((u64)range * m_hi + t) >> 16);
 }
 
-// Output: range-coder streams are staged as PLAIN bytes (stream byte k at address k; BlkDesc::plain_mask
-// tells k_assemble).  Bytes leaving the coder collect in a 64-bit register and go out four at a time.
-struct RcState { u64 low; u32 range; u64 acc; u32 nacc; u32 pos; };
+struct RcState { u64 low; u32 range; u64 acc; u32 nbits; u32 pos; };   // acc holds nbits/8 pending output bytes
 
 typedef u32 __attribute__((aligned(1))) u32_unaligned;
 
 __device__ __forceinline__ void rc_flush4(RcState& s, u8* out)
 {
-	const u32 w = (u32)(s.acc >> (8 * (s.nacc - 4)));                      // oldest four pending bytes, first byte in the MSB
+	const u32 w = (u32)(s.acc >> (s.nbits - 32));                          // oldest four pending bytes, first byte in the MSB
 	*(u32_unaligned*)(out + s.pos) = ((w >> 24) & 0xFFu) | ((w >> 8) & 0xFF00u) | ((w << 8) & 0xFF0000u) | (w << 24);
-	s.pos += 4; s.nacc -= 4;
+	s.pos += 4; s.nbits -= 32;
 }
 
-__device__ __forceinline__ void rc_step(RcState& s, u8* out, u64 e, u32 cum)
+// fast step; returns non-zero if the clamp pre-condition was seen
+__device__ __forceinline__ u32 rc_step_fast(RcState& s, u8* out, const RcRec& e)
 {
-	const u32 f = (u32)e & 0xFFFFu;
-	const u32 r = rc_div(s.range, (u32)(e >> 16), (u32)(e >> 48));
-	u64 low = s.low + (u32)(r * cum);
-	u32 range = r * f;
-	const u32 k = (u32)__builtin_clz(range) >> 3;                               // bytes leaving the coder (0..3); range != 0
-	// RangeEncoder::EncodeFrequency's carry clamp (src/RangeCoder.h:64-74) can only trigger when adding
-	// range (< 2^24) to low carries through bits 24..39: those 16 bits must all be ones
-	if (k && ((u32)(low >> 24) & 0xFFFFu) == 0xFFFFu)
-	{
-		const u64 x = low ^ (low + range);
-		if ((u32)(x >> 40) >> (24 - 8 * k))
-		{	// astronomically rare: the reference's loop, verbatim
-			while (range <= 0x00FFFFFFu)
-			{
-				if ((low ^ (low + range)) & 0xFF00000000000000ull) { const u32 rr = (u32)low; range = (rr | 0x00FFFFFFu) - rr; }
-				s.acc = (s.acc << 8) | (low >> 56); s.nacc++;
-				if (s.nacc >= 4) rc_flush4(s, out);
-				low <<= 8; range <<= 8;
-			}
-			s.low = low; s.range = range;
-			return;
-		}
-	}
-	// the top k bytes of low are final
-	const u32 sh = 8 * k;
-	s.acc = (s.acc << sh) | (u32)((low >> 8) >> (56 - sh));
-	s.nacc += k;
-	s.low = low << sh;
-	s.range = range << sh;
-	if (s.nacc >= 4) rc_flush4(s, out);
+	const u32 f = (u32)e.w & 0xFFFFu;
+	const u32 r = rc_div(s.range, (u32)(e.w >> 16), (u32)(e.w >> 48));
+	const u64 low = s.low + (u64)r * e.cum;                                // r*cum <= range < 2^32: identical to the reference's 32-bit product
+	const u32 range = r * f;
+	const u32 k8 = ((u32)__builtin_clz(range) >> 3) << 3;                    // 8 * bytes leaving the coder (0..24); range != 0
+	const u32 flag = (((u32)(low >> 24) & 0xFFFFu) == 0xFFFFu) ? 1u : 0u;
+	s.acc = (s.acc << k8) | (u32)((low >> 8) >> (56 - k8));
+	s.nbits += k8;
+	s.low = low << k8;
+	s.range = range << k8;
+	if (s.nbits >= 32) rc_flush4(s, out);
+	return flag;
 }
 
-__global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, const u64* trip_pool, u32* word_pool, BlkState* st)
+// exact step: RangeEncoder::EncodeFrequency, verbatim, on the same output state
+__device__ inline void rc_step_exact(RcState& s, u8* out, const RcRec& e)
+{
+	const u32 f = (u32)e.w & 0xFFFFu;
+	const u32 r = rc_div(s.range, (u32)(e.w >> 16), (u32)(e.w >> 48));
+	u64 low = s.low + (u64)r * e.cum;
+	u32 range = r * f;
+	while (range <= 0x00FFFFFFu)
+	{
+		if ((low ^ (low + range)) & 0xFF00000000000000ull) { const u32 rr = (u32)low; range = (rr | 0x00FFFFFFu) - rr; }
+		s.acc = (s.acc << 8) | (low >> 56); s.nbits += 8;
+		if (s.nbits >= 32) rc_flush4(s, out);
+		low <<= 8; range <<= 8;
+	}
+	s.low = low; s.range = range;
+}
+
+__device__ __forceinline__ void rc_group(RcState& s, u8* out, const RcRec (&g)[RC_GROUP])
+{
+	const RcState snap = s;
+	u32 bad = 0;
+#pragma unroll
+	for (u32 i = 0; i < RC_GROUP; ++i) bad |= rc_step_fast(s, out, g[i]);
+	if (bad)
+	{
+		s = snap;
+		for (u32 i = 0; i < RC_GROUP; ++i) rc_step_exact(s, out, g[i]);
+	}
+}
+
+__global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, const RcRec* rec_pool, u32* word_pool, BlkState* st)
 {
 	const u32 id = blockIdx.x * 64 + threadIdx.x;
 	if (id >= n_chains) return;
 	const RcChain c = chains[id];
-	const u64* trip = trip_pool + c.trip;
-	const u16* cums = (const u16*)trip_pool + c.cum;
+	const RcRec* p = rec_pool + c.trip;
 	u8* out = (u8*)(word_pool + c.out_words);
 	RcState s;
-	s.low = 0; s.range = 0xFFFFFFFFu; s.pos = c.out_byte0; s.acc = 0; s.nacc = 0;
+	s.low = 0; s.range = 0xFFFFFFFFu; s.pos = c.out_byte0; s.acc = 0; s.nbits = 0;
 
-	const u32 n = c.n, stride = c.stride;
-	u64 cur[RC_AHEAD], nxt[RC_AHEAD];
-	u32 cc[RC_AHEAD], nc[RC_AHEAD];
-#pragma unroll
-	for (u32 i = 0; i < RC_AHEAD; ++i) { const bool in = i < n; cur[i] = in ? trip[(u64)i * stride] : 0; cc[i] = in ? cums[(u64)i * stride] : 0; }
+	const u32 n = c.n;
+	const u64 stride = c.stride;
+	RcRec A[RC_GROUP], B[RC_GROUP];
 	u32 t0 = 0;
-	for (; t0 + RC_AHEAD <= n; t0 += RC_AHEAD)
+	if (n >= 2 * RC_GROUP)
 	{
 #pragma unroll
-		for (u32 i = 0; i < RC_AHEAD; ++i)
+		for (u32 i = 0; i < RC_GROUP; ++i) A[i] = p[(u64)i * stride];
+		for (; t0 + 3 * RC_GROUP <= n; t0 += 2 * RC_GROUP)
 		{
-			const u32 t = t0 + RC_AHEAD + i; const bool in = t < n;
-			nxt[i] = in ? trip[(u64)t * stride] : 0; nc[i] = in ? cums[(u64)t * stride] : 0;
+			const RcRec* q = p + (u64)(t0 + RC_GROUP) * stride;
+#pragma unroll
+			for (u32 i = 0; i < RC_GROUP; ++i) B[i] = q[(u64)i * stride];
+			rc_group(s, out, A);
+			q += (u64)RC_GROUP * stride;
+#pragma unroll
+			for (u32 i = 0; i < RC_GROUP; ++i) A[i] = q[(u64)i * stride];
+			rc_group(s, out, B);
 		}
-#pragma unroll
-		for (u32 i = 0; i < RC_AHEAD; ++i) rc_step(s, out, cur[i], cc[i]);
-#pragma unroll
-		for (u32 i = 0; i < RC_AHEAD; ++i) { cur[i] = nxt[i]; cc[i] = nc[i]; }
+		rc_group(s, out, A);                                                   // the group loaded last is complete: t0 + 16 <= n
+		t0 += RC_GROUP;
 	}
-#pragma unroll
-	for (u32 i = 0; i < RC_AHEAD; ++i) if (t0 + i < n) rc_step(s, out, cur[i], cc[i]);
+	for (; t0 < n; ++t0) { const RcRec e = p[(u64)t0 * stride]; rc_step_exact(s, out, e); }
 
-	for (u32 k = 0; k < s.nacc; ++k) out[s.pos + k] = (u8)(s.acc >> (8 * (s.nacc - 1 - k)));
-	s.pos += s.nacc;
+	const u32 nb = s.nbits >> 3;
+	for (u32 k = 0; k < nb; ++k) out[s.pos + k] = (u8)(s.acc >> (8 * (nb - 1 - k)));
+	s.pos += nb;
 	for (u32 k = 0; k < 8; ++k) { out[s.pos++] = (u8)(s.low >> 56); s.low <<= 8; }      // RangeEncoder::End
 	if (c.is_dna) st[c.blk].dna_bytes = s.pos; else st[c.blk].qua_bytes = s.pos;
 	if (s.pos > c.out_byte0 + c.out_cap) atomicOr(&st[c.blk].err, (u32)DSRC_ERR_OUT_OVERFLOW);
