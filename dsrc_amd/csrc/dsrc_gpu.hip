@@ -56,6 +56,7 @@ struct dsrcgpu_handle
 	dsrcgpu_dataset ds;
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t rc_stream = nullptr;    // high priority: k_rc only
 	Arena arena;
 	u64 arena_fixed = 0;
 	u32 fields_cap = 0;              // capacity of the reference's TagStats::fields vector, carried block to block
@@ -66,7 +67,7 @@ struct dsrcgpu_handle
 	std::deque<Done> done;
 	float batch_ms = 0.f, rc_ms = 0.f;
 	u32 rc_launches = 0;
-	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace
@@ -108,7 +109,8 @@ size_t estimate_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
 	const bool rc = h->set.dna_order > 0 || h->set.quality_order > 0;
 	size_t tot = 0, mx = 0;
 	for (u32 i = 0; i < n; ++i) { tot += (size_t)sizes[i] + 4096; mx = std::max(mx, (size_t)sizes[i]); }
-	return tot * (rc ? 34 : 14) + (size_t)n * (2u << 20) + (16u << 20);
+	const size_t sort_slice = std::min(tot * 14, ((size_t)12288 << 20) + mx * 16);      // see slice_lo in run_batch
+	return tot * (rc ? 21 : 14) + (rc ? sort_slice : 0) + (size_t)n * (2u << 20) + (16u << 20);
 }
 
 struct BatchIO
@@ -400,11 +402,36 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			j.passes = (j.key_bits + 7) / 8; if (j.passes == 0) j.passes = 1;
 			j.dbits = (j.key_bits + j.passes - 1) / j.passes; if (j.dbits == 0) j.dbits = 1;
 			j.sorted_in_b = j.passes & 1;
-			j.elems = A.alloc((size_t)j.n * 8 + 64) / 8; j.elems_b = A.alloc((size_t)j.n * 8 + 64) / 8;
 			j.trip = o_trip / sizeof(RcRec) + gbase[i / 64] + (i % 64);
 			j.trip_stride = std::min(NJ, (i / 64) * 64 + 64) - (i / 64) * 64;
 			RcChain& c = chains[i];
 			c.trip = j.trip; c.out_words = j.out_words; c.n = j.n; c.out_byte0 = j.out_byte0; c.out_cap = j.out_cap; c.blk = j.blk; c.is_dna = j.is_dna; c.stride = j.trip_stride;
+		}
+	}
+	// The ping-pong sort buffers are only alive from k_ctx to k_replay, so the job list is cut into slices that
+	// reuse one region (kernels of consecutive slices are ordered on the stream).  What persists per block until
+	// the range coder has run is the record array, which keeps many more blocks in flight per GiB of HBM.
+	std::vector<u32> slice_lo;
+	{
+		const char* env = getenv("DSRC_GPU_SORT_SLICE_MB");
+		const size_t budget = (env ? (size_t)atol(env) : (size_t)12288) << 20;
+		size_t cur = 0, mx = 0;
+		for (u32 i = 0; i < NJ; ++i)
+		{
+			const size_t need = ((size_t)jobs[i].n * 8 + 64) * 2;
+			if (i == 0 || cur + need > budget) { slice_lo.push_back(i); cur = 0; }
+			cur += need; mx = std::max(mx, cur);
+		}
+		slice_lo.push_back(NJ);
+		const size_t o_sort = A.alloc(mx + 64);
+		for (size_t sl = 0; sl + 1 < slice_lo.size(); ++sl)
+		{
+			size_t off = 0;
+			for (u32 i = slice_lo[sl]; i < slice_lo[sl + 1]; ++i)
+			{
+				jobs[i].elems = (o_sort + off) / 8; off += (size_t)jobs[i].n * 8 + 64;
+				jobs[i].elems_b = (o_sort + off) / 8; off += (size_t)jobs[i].n * 8 + 64;
+			}
 		}
 	}
 	const size_t o_jobs = A.alloc(sizeof(CtxJob) * std::max(1u, NJ)), o_chains = A.alloc(sizeof(RcChain) * std::max(1u, NJ));
@@ -503,31 +530,41 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	{
 		const u32 nq = (u32)qjobs.size(), nd = (u32)djobs.size();
 		hipLaunchKernelGGL(k_rc_headers, dim3((NJ + 63) / 64), dim3(64), 0, s, d_jobs, NJ, d_state, wpool); KCHK();
-		if (nq) { const u32 gx = std::max(1u, std::min(32u, (maxq + WG * 8 - 1) / (WG * 8))); hipLaunchKernelGGL(k_ctx_qua, dim3(gx, nq), dim3(WG), 0, s, d_jobs, d_q, d_qp, lpool, d_state); KCHK(); }
-		if (nd) { const u32 gx = std::max(1u, std::min(32u, (maxd + WG * 8 - 1) / (WG * 8))); hipLaunchKernelGGL(k_ctx_dna, dim3(gx, nd), dim3(WG), 0, s, d_jobs + nq, d_d, lpool, d_state); KCHK(); }
-		hipLaunchKernelGGL(k_sort, dim3(NJ), dim3(WG), 0, s, d_jobs, lpool); KCHK();
-		for (u32 lo = 0; lo < NJ;)
+		for (size_t sl = 0; sl + 1 < slice_lo.size(); ++sl)
 		{
-			u32 hi = lo;
-			while (hi < NJ && jobs[hi].n_alpha == jobs[lo].n_alpha) ++hi;
-			const u32 cnt = hi - lo;
-			u32 mxn = 1; for (u32 i = lo; i < hi; ++i) mxn = std::max(mxn, jobs[i].n);
-			const u32 parts = std::max(1u, std::min(32u, mxn / 16384u));   // REPLAY_WG/64 waves each; >= 4k symbols per wave
-			switch (jobs[lo].n_alpha)
+			const u32 s_lo = slice_lo[sl], s_hi = slice_lo[sl + 1];
+			const u32 q_lo = std::min(s_lo, nq), q_hi = std::min(s_hi, nq), d_lo = std::max(s_lo, nq), d_hi = std::max(s_hi, nq);
+			if (q_hi > q_lo) { const u32 gx = std::max(1u, std::min(32u, (maxq + WG * 8 - 1) / (WG * 8))); hipLaunchKernelGGL(k_ctx_qua, dim3(gx, q_hi - q_lo), dim3(WG), 0, s, d_jobs + q_lo, d_q, d_qp, lpool, d_state); KCHK(); }
+			if (d_hi > d_lo) { const u32 gx = std::max(1u, std::min(32u, (maxd + WG * 8 - 1) / (WG * 8))); hipLaunchKernelGGL(k_ctx_dna, dim3(gx, d_hi - d_lo), dim3(WG), 0, s, d_jobs + d_lo, d_d, lpool, d_state); KCHK(); }
+			hipLaunchKernelGGL(k_sort, dim3(s_hi - s_lo), dim3(WG), 0, s, d_jobs + s_lo, lpool); KCHK();
+			for (u32 lo = s_lo; lo < s_hi;)
 			{
-			case 4:   hipLaunchKernelGGL(k_replay<4>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
-			case 8:   hipLaunchKernelGGL(k_replay<8>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
-			case 16:  hipLaunchKernelGGL(k_replay<16>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
-			case 32:  hipLaunchKernelGGL(k_replay<32>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
-			case 64:  hipLaunchKernelGGL(k_replay<64>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
-			default:  hipLaunchKernelGGL(k_replay<128>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+				u32 hi = lo;
+				while (hi < s_hi && jobs[hi].n_alpha == jobs[lo].n_alpha) ++hi;
+				const u32 cnt = hi - lo;
+				u32 mxn = 1; for (u32 i = lo; i < hi; ++i) mxn = std::max(mxn, jobs[i].n);
+				const u32 parts = std::max(1u, std::min(32u, mxn / 16384u));   // REPLAY_WG/64 waves each; >= 4k symbols per wave
+				switch (jobs[lo].n_alpha)
+				{
+				case 4:   hipLaunchKernelGGL(k_replay<4>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+				case 8:   hipLaunchKernelGGL(k_replay<8>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+				case 16:  hipLaunchKernelGGL(k_replay<16>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+				case 32:  hipLaunchKernelGGL(k_replay<32>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+				case 64:  hipLaunchKernelGGL(k_replay<64>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+				default:  hipLaunchKernelGGL(k_replay<128>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+				}
+				KCHK();
+				lo = hi;
 			}
-			KCHK();
-			lo = hi;
 		}
-		HIPCHK(hipEventRecord(h->ev[2], s));
-		hipLaunchKernelGGL(k_rc, dim3((NJ + 63) / 64), dim3(64), 0, s, d_chains, NJ, AP<RcRec>(h, 0), wpool, d_state); KCHK();
-		HIPCHK(hipEventRecord(h->ev[3], s));
+		// the serial coder runs on its own high-priority stream: its few waves must not queue behind the
+		// data-parallel kernels of another scheduler instance sharing the GPU
+		HIPCHK(hipEventRecord(h->ev[4], s));
+		HIPCHK(hipStreamWaitEvent(h->rc_stream, h->ev[4], 0));
+		HIPCHK(hipEventRecord(h->ev[2], h->rc_stream));
+		hipLaunchKernelGGL(k_rc, dim3((NJ + 63) / 64), dim3(64), 0, h->rc_stream, d_chains, NJ, AP<RcRec>(h, 0), wpool, d_state); KCHK();
+		HIPCHK(hipEventRecord(h->ev[3], h->rc_stream));
+		HIPCHK(hipStreamWaitEvent(s, h->ev[3], 0));
 		h->rc_launches = 1;
 	}
 
@@ -618,7 +655,12 @@ int dsrcgpu_create(const dsrcgpu_settings* settings, const dsrcgpu_dataset* data
 	if (device < 0 || device >= ndev) return fail(h, DSRCGPU_E_ARG, "device %d out of range (%d devices)", device, ndev);
 	HIPCHK(hipSetDevice(device));
 	HIPCHK(hipStreamCreate(&h->stream));
-	for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
+	{
+		int lo_p = 0, hi_p = 0;
+		HIPCHK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+		HIPCHK(hipStreamCreateWithPriority(&h->rc_stream, hipStreamNonBlocking, hi_p));
+	}
+	for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
 	h->arena_fixed = arena_bytes;
 	{	// CRC tables: 256 byte-table entries + x^(2^k) mod P, k = 0..31
 		u32 tab[288];
@@ -646,7 +688,8 @@ void dsrcgpu_destroy(dsrcgpu_handle* h)
 	if (h->arena.base) hipFree(h->arena.base);
 	if (h->d_crc_tab) hipFree(h->d_crc_tab);
 	if (h->d_rc_magic) hipFree(h->d_rc_magic);
-	for (int i = 0; i < 4; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+	for (int i = 0; i < 5; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+	if (h->rc_stream) hipStreamDestroy(h->rc_stream);
 	if (h->stream) hipStreamDestroy(h->stream);
 	delete h;
 }
