@@ -90,7 +90,7 @@ int ensure_arena(dsrcgpu_handle* h, size_t need)
 	if (h->arena_fixed && need > h->arena_fixed)
 		return fail(h, DSRCGPU_E_NOMEM, "batch needs %zu bytes of HBM scratch, arena is fixed at %llu", need, (unsigned long long)h->arena_fixed);
 	if (h->arena.base) { HIPCHK(hipFree(h->arena.base)); h->arena.base = nullptr; h->arena.cap = 0; }
-	size_t want = h->arena_fixed ? (size_t)h->arena_fixed : need + need / 8;
+	size_t want = h->arena_fixed ? (size_t)h->arena_fixed : need + need / 64;
 	hipError_t e = hipMalloc((void**)&h->arena.base, want);
 	if (e != hipSuccess) return fail(h, DSRCGPU_E_NOMEM, "hipMalloc(%zu) for the batch arena failed: %s", want, hipGetErrorString(e));
 	h->arena.cap = want; h->arena.top = 0; h->arena.failed = false;
@@ -110,7 +110,7 @@ size_t estimate_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
 	size_t tot = 0, mx = 0;
 	for (u32 i = 0; i < n; ++i) { tot += (size_t)sizes[i] + 4096; mx = std::max(mx, (size_t)sizes[i]); }
 	const size_t sort_slice = std::min(tot * 14, ((size_t)12288 << 20) + mx * 16);      // see slice_lo in run_batch
-	return tot * (rc ? 21 : 14) + (rc ? sort_slice : 0) + (size_t)n * (2u << 20) + (16u << 20);
+	return tot * (rc ? 18 : 14) + (rc ? sort_slice : 0) + (size_t)n * (1u << 20) + (16u << 20);
 }
 
 struct BatchIO
@@ -399,7 +399,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		for (u32 i = 0; i < NJ; ++i)
 		{
 			CtxJob& j = jobs[i];
-			j.passes = (j.key_bits + 7) / 8; if (j.passes == 0) j.passes = 1;
+			j.passes = (j.key_bits + 9) / 10; if (j.passes == 0) j.passes = 1;
 			j.dbits = (j.key_bits + j.passes - 1) / j.passes; if (j.dbits == 0) j.dbits = 1;
 			j.sorted_in_b = j.passes & 1;
 			j.trip = o_trip / sizeof(RcRec) + gbase[i / 64] + (i % 64);

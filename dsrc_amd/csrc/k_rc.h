@@ -103,7 +103,12 @@ __global__ void __launch_bounds__(WG) k_ctx_qua(const CtxJob* jobs, const u8* q_
 }
 
 // ---- stable LSD radix sort by ctx; one workgroup owns one stream ------------------------------
-#define SORT_MAX_BINS 256
+// Per pass: LDS histogram -> exclusive scan -> tiles of WG*SORT_ITEMS elements.  A wave owns a contiguous
+// run of 64*SORT_ITEMS elements of the tile and walks it 64 at a time: equal-digit lanes are found with one
+// ballot per digit bit, the wave's private counter row in LDS gives the running rank, and a per-digit
+// scan over the waves turns the rows into global offsets once per tile.
+#define SORT_MAX_BINS 1024
+#define SORT_ITEMS 8
 __global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool)
 {
 	__shared__ u32 s_base[SORT_MAX_BINS];
@@ -111,7 +116,8 @@ __global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool)
 	__shared__ u32 s_off[WAVES][SORT_MAX_BINS];
 	const CtxJob j = jobs[blockIdx.x];
 	const u32 n = j.n, bins = 1u << j.dbits;
-	const u32 wv = wave_id(), nw = blockDim.x >> 6;
+	const u32 wv = wave_id(), nw = blockDim.x >> 6, lane = lane_id();
+	const u32 tile_elems = blockDim.x * SORT_ITEMS;
 
 	for (u32 pass = 0; pass < j.passes; ++pass)
 	{
@@ -138,20 +144,29 @@ __global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool)
 		}
 		__syncthreads();
 
-		for (u32 tile = 0; tile < n; tile += blockDim.x)
+		for (u32 tile = 0; tile < n; tile += tile_elems)
 		{
-			const u32 i = tile + threadIdx.x;
-			const bool valid = i < n;
-			const u64 el = valid ? src[i] : 0;
-			const u32 d = (u32)(el >> shift) & (bins - 1);
-			u64 peers = __ballot(valid);
-			for (u32 b = 0; b < j.dbits; ++b)
+			u64 el[SORT_ITEMS]; u32 rk[SORT_ITEMS];
+			const u32 wbase = tile + wv * 64 * SORT_ITEMS;
+#pragma unroll
+			for (u32 k = 0; k < SORT_ITEMS; ++k)
 			{
-				const u64 m = __ballot((d >> b) & 1u);
-				peers &= ((d >> b) & 1u) ? m : ~m;
+				const u32 i = wbase + k * 64 + lane;
+				const bool valid = i < n;
+				el[k] = valid ? src[i] : 0;
+				const u32 d = (u32)(el[k] >> shift) & (bins - 1);
+				u64 peers = __ballot(valid);
+				for (u32 b = 0; b < j.dbits; ++b)
+				{
+					const u64 m = __ballot((d >> b) & 1u);
+					peers &= ((d >> b) & 1u) ? m : ~m;
+				}
+				const u32 before = valid ? s_cnt[wv][d] : 0;          // this wave's earlier elements with the same digit
+				const u32 r = (u32)__popcll(peers & lanemask_lt());
+				rk[k] = before + r;
+				const u64 sync = __ballot(true);                       // every lane has read its counter before a leader bumps it
+				if (valid && r == 0 && sync) s_cnt[wv][d] = before + (u32)__popcll(peers);
 			}
-			const u32 rank = (u32)__popcll(peers & lanemask_lt());
-			if (valid && rank == 0) s_cnt[wv][d] = (u32)__popcll(peers);
 			__syncthreads();
 			for (u32 dd = threadIdx.x; dd < bins; dd += blockDim.x)
 			{
@@ -166,7 +181,12 @@ __global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool)
 				s_base[dd] = run;
 			}
 			__syncthreads();
-			if (valid) dst[s_off[wv][d] + rank] = el;
+#pragma unroll
+			for (u32 k = 0; k < SORT_ITEMS; ++k)
+			{
+				const u32 i = wbase + k * 64 + lane;
+				if (i < n) dst[s_off[wv][(u32)(el[k] >> shift) & (bins - 1)] + rk[k]] = el[k];
+			}
 			__syncthreads();
 		}
 	}
