@@ -6,7 +6,7 @@ set, -d3 -q2, default -b8 (8 MiB chunks cut where IFastqStreamReader::ReadNextCh
 A *step* = `--blocks` consecutive chunks per GPU, generated in HBM by the counter-based generator before
 the timed region and pushed through dsrcgpu_compress_batch_device; compressed blocks stay in HBM (PCIe is
 not in `value`).  Inside a step the chunks go through `--pipeline` independent scheduler instances
-(own HIP stream + arena each) half a period apart, so that the serial range-coder kernel of one sub-batch
+(own HIP stream + arena each) a fraction of a period apart, so that the serial range-coder kernel of one sub-batch
 overlaps the data-parallel front end of the next; the timed region covers all K steps end to end.
 
 N > 1: one process per GPU (torch.distributed, nccl = RCCL).  Ranks take disjoint record ranges (weak
@@ -140,10 +140,10 @@ class StepGate:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)   # 3 x 1280 blocks = 85 % of the 100 M-read set (~4500 blocks of 8 MiB); all inputs stay resident in HBM
+    ap.add_argument("--steps", type=int, default=3)   # 3 x 1200 blocks = 80 % of the 100 M-read set (~4500 blocks of 8 MiB); all inputs stay resident in HBM
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=int(os.environ.get("DSRC_BENCH_BLOCKS", "1280")), help="8 MiB chunks per step per GPU")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DSRC_BENCH_PIPELINE", "2")), help="scheduler instances per GPU")
+    ap.add_argument("--blocks", type=int, default=int(os.environ.get("DSRC_BENCH_BLOCKS", "1200")), help="8 MiB chunks per step per GPU")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DSRC_BENCH_PIPELINE", "3")), help="scheduler instances per GPU")
     ap.add_argument("--dna", type=int, default=3)
     ap.add_argument("--qua", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
