@@ -115,12 +115,16 @@ class Lane:
         self.d_out, self.out_keep = alloc_out(self.h, self.cap_out)
         self.results = {}
         self.timing = []
+        self.trace = []
 
     def run(self, k):
         d_in, starts, sizes = self.sub[k]
+        t0 = time.perf_counter()
         res = self.h.compress_batch_device(d_in, starts, sizes, self.d_out, self.cap_out)
+        t1 = time.perf_counter()
         self.results[k] = res
         self.timing.append(self.h.last_timing())
+        self.trace.append((k, t0, t1) + self.timing[-1][:2])
         return res
 
 
@@ -239,6 +243,11 @@ def main():
     wall = time.perf_counter() - t_begin
     if errors:
         raise errors[0]
+    if os.environ.get("DSRC_BENCH_TRACE") and rank == 0:
+        for i, ln in enumerate(lanes):
+            for k, a, b_, bm, rm in ln.trace:
+                if k >= args.warmup:
+                    print(f"[trace] lane {i} sub {k}: start {1e3 * (a - t_begin):8.1f} ms  end {1e3 * (b_ - t_begin):8.1f} ms  batch {bm:7.1f} ms  k_rc {rm:6.1f} ms", file=sys.stderr)
 
     in_bytes = 0; out_bytes = 0
     for ln in lanes:

@@ -265,15 +265,18 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 	u32 T0 = N, epoch_cnt = 0, epoch_left = 0;
 	const u32 E0 = (limit - N + 1) / 2;     // symbols a fresh row codes before its first rescale
 
+	// software pipeline: the next window is requested as soon as this window's length is known
+	u64 el_cur = pos + lane < n ? src[pos + lane] : 0;
+	u64 prev_ctx = pos > 0 ? (src[pos - 1] >> ELEM_CTX_SHIFT) : ~0ull;      // context of the element before the window
 	for (;;)
 	{
 		if (pos >= n) break;
 		const u32 idx = pos + lane;
 		const bool valid = idx < n;
-		const u64 el = valid ? src[idx] : 0;
+		const u64 el = el_cur;
 		const u64 ctx = el >> ELEM_CTX_SHIFT;
 		u64 pctx = __shfl_up(ctx, 1);
-		if (lane == 0) pctx = pos > 0 ? (src[pos - 1] >> ELEM_CTX_SHIFT) : ~0ull;
+		if (lane == 0) pctx = prev_ctx;
 		const bool head = valid && ctx != pctx;
 		const u64 hm_all = __ballot(head);
 		u32 tile_len = (u32)__popcll(__ballot(valid));
@@ -290,6 +293,8 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 			if (c > epoch_left) { tile_len = epoch_left; rescale_after = true; last = false; }
 			else if (c == epoch_left && c == tile_len && !last) { /* boundary falls on the window end: rescale lazily below */ }
 		}
+		const u32 npos = pos + tile_len;
+		const u64 el_next = npos + lane < n ? src[npos + lane] : 0;
 		const u64 tmask = tile_len >= 64 ? ~0ull : ((1ull << tile_len) - 1ull);
 		const bool active = lane < tile_len;
 		const u64 hm = hm_all & tmask;
@@ -352,7 +357,9 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 			epoch_cnt = 0; epoch_left = (limit - T0 + 1) / 2;
 		}
 		{ u32 t; replay_prefix<N>(cnt, cntpre, &t); }
-		pos += tile_len;
+		if (tile_len) prev_ctx = __shfl(ctx, (int)(tile_len - 1));
+		el_cur = el_next;
+		pos = npos;
 		if (last) break;
 	}
 }
@@ -458,25 +465,35 @@ __global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, 
 
 	const u32 n = c.n;
 	const u64 stride = c.stride;
-	RcRec A[RC_GROUP], B[RC_GROUP];
+	// three register buffers in rotation: while group g is coded, g+1 has landed and g+2 is in flight
+	// (32 symbols ~ 3 us of prefetch distance: enough when other kernels load the memory system)
+	RcRec A[RC_GROUP], B[RC_GROUP], C[RC_GROUP];
 	u32 t0 = 0;
-	if (n >= 2 * RC_GROUP)
+	if (n >= 3 * RC_GROUP)
 	{
 #pragma unroll
 		for (u32 i = 0; i < RC_GROUP; ++i) A[i] = p[(u64)i * stride];
-		for (; t0 + 3 * RC_GROUP <= n; t0 += 2 * RC_GROUP)
-		{
-			const RcRec* q = p + (u64)(t0 + RC_GROUP) * stride;
 #pragma unroll
-			for (u32 i = 0; i < RC_GROUP; ++i) B[i] = q[(u64)i * stride];
+		for (u32 i = 0; i < RC_GROUP; ++i) B[i] = p[(u64)(RC_GROUP + i) * stride];
+		// invariant at the loop head: A = group at t0, B = group at t0+16, both requested
+		for (; t0 + 5 * RC_GROUP <= n; t0 += 3 * RC_GROUP)
+		{
+			const RcRec* q = p + (u64)(t0 + 2 * RC_GROUP) * stride;
+#pragma unroll
+			for (u32 i = 0; i < RC_GROUP; ++i) C[i] = q[(u64)i * stride];
 			rc_group(s, out, A);
 			q += (u64)RC_GROUP * stride;
 #pragma unroll
 			for (u32 i = 0; i < RC_GROUP; ++i) A[i] = q[(u64)i * stride];
 			rc_group(s, out, B);
+			q += (u64)RC_GROUP * stride;
+#pragma unroll
+			for (u32 i = 0; i < RC_GROUP; ++i) B[i] = q[(u64)i * stride];
+			rc_group(s, out, C);
 		}
-		rc_group(s, out, A);                                                   // the group loaded last is complete: t0 + 16 <= n
-		t0 += RC_GROUP;
+		rc_group(s, out, A);                                                   // both pending groups are complete: t0 + 32 <= n
+		rc_group(s, out, B);
+		t0 += 2 * RC_GROUP;
 	}
 	for (; t0 < n; ++t0) { const RcRec e = p[(u64)t0 * stride]; rc_step_exact(s, out, e); }
 

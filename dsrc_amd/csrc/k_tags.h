@@ -32,6 +32,24 @@ __device__ __forceinline__ bool tag_is_sep(u32 c)
 	return c == ' ' || c == '.' || c == '_' || c == ',' || c == '=' || c == ':' || c == '/' || c == '-' || c == '#' || c == 0;
 }
 
+// sequential byte access through 8-byte windows (titles are walked once, left to right, by one lane)
+typedef u64 __attribute__((aligned(1))) u64_unaligned;
+struct TitleReader
+{
+	const u8* p; u32 lim; u64 w; u32 base;
+	__device__ __forceinline__ void init(const u8* p_, u32 lim_) { p = p_; lim = lim_; base = 0xFFFFFFF8u; w = 0; }
+	__device__ __forceinline__ u32 get(u32 k)
+	{
+		if (k - base >= 8u)
+		{
+			base = k & ~7u;
+			if (base + 8u <= lim) w = *(const u64_unaligned*)(p + base);
+			else { w = 0; for (u32 i = 0; base + i < lim && i < 8; ++i) w |= (u64)p[base + i] << (8 * i); }
+		}
+		return (u32)(w >> (8 * (k - base))) & 0xFFu;
+	}
+};
+
 // core::is_num (src/utils.h:163-175)
 __device__ __forceinline__ bool tag_is_num(const u8* s, u32 len, u32* val)
 {
@@ -89,6 +107,7 @@ __global__ void __launch_bounds__(WG) k_tag_scan(const u8* in, const BlkDesc* de
 	__shared__ u8 s_sep[DSRC_MAX_FIELDS], s_isnum[DSRC_MAX_FIELDS], s_slot[DSRC_MAX_FIELDS];
 	__shared__ u32 s_start0[DSRC_MAX_FIELDS], s_len0[DSRC_MAX_FIELDS];
 	__shared__ u32 s_tmin, s_tmax, s_fmix;
+	__shared__ u8 s_t0[256];                // head of record 0's title (the field template's text)
 	const u32 b = blockIdx.x;
 	BlkState* S = &st[b];
 	const BlkDesc d = desc[b];
@@ -105,35 +124,49 @@ __global__ void __launch_bounds__(WG) k_tag_scan(const u8* in, const BlkDesc* de
 	__syncthreads();
 	const u8* base = in + d.in_off;
 	const u8* t0 = base + rp.title_off[d.rec_base];
-	u32* val = val_pool + plans[b].val;
+	u32* val_arr = val_pool + plans[b].val;
+	for (u32 i = threadIdx.x; i < 256; i += blockDim.x) s_t0[i] = i < rp.title_len[d.rec_base] ? t0[i] : 0;
+	__syncthreads();
 	for (u32 r = threadIdx.x; r < n; r += blockDim.x)
 	{
 		const u64 g = (u64)d.rec_base + r;
-		const u8* t = base + rp.title_off[g];
+		const u32 toff = rp.title_off[g];
 		const u32 tl = rp.title_len[g];
 		atomicMin(&s_tmin, tl); atomicMax(&s_tmax, tl);
+		TitleReader tr; tr.init(base + toff, d.in_size - toff);
 		u32 c = 0, start = 0, k;
+		// one pass: per field accumulate "all digits" / value / first char / equality with record 0
+		bool numok = true, same = true; u32 val = 0, first = 0;
 		for (k = 0; k <= tl && c < nf; ++k)
 		{
-			if (k < tl && t[k] != s_sep[c]) continue;
+			const u32 ch = k < tl ? tr.get(k) : 0;
+			if (k < tl && ch != s_sep[c])
+			{
+				const u32 x = k - start;
+				if (x == 0) first = ch;
+				if (ch < '0' || ch > '9') numok = false;
+				val = val * 10u + (ch - '0');
+				if (x >= s_len0[c] || ch != (x + s_start0[c] < 256u ? (u32)s_t0[s_start0[c] + x] : (u32)t0[s_start0[c] + x])) same = false;
+				continue;
+			}
 			const u32 L = k - start;
 			if (L > s_maxlen[c]) atomicMax(&s_maxlen[c], L);
 			if (L < s_minlen[c]) atomicMin(&s_minlen[c], L);
-			bool same = L == s_len0[c];
-			if (!same) s_nlc[c] = 1;
-			if (same) for (u32 x = 0; x < L; ++x) if (t[start + x] != t0[s_start0[c] + x]) { same = false; break; }
+			if (L != s_len0[c]) { s_nlc[c] = 1; same = false; }
 			if (!same) s_nc[c] = 1;
 			if (s_isnum[c])
 			{
-				u32 v;
-				if (tag_is_num(t + start, L, &v))
+				const bool isn = numok && (L == 1 || L == 0 || first != '0');         // core::is_num
+				if (isn)
 				{
+					const u32 v = L ? val : 0;
 					atomicMin(&s_minv[c], (i32)v); atomicMax(&s_maxv[c], (i32)v);
-					val[(u64)s_slot[c] * n + r] = v;
+					val_arr[(u64)s_slot[c] * n + r] = v;
 				}
-				else { s_nn[c] = 1; val[(u64)s_slot[c] * n + r] = 0; }
+				else { s_nn[c] = 1; val_arr[(u64)s_slot[c] * n + r] = 0; }
 			}
 			start = k + 1; c++;
+			numok = true; same = true; val = 0; first = 0;
 		}
 		if (c != nf || k != tl + 1) atomicMin(&s_fmix, r);
 	}
