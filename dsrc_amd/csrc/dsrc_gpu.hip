@@ -654,11 +654,35 @@ int dsrcgpu_create(const dsrcgpu_settings* settings, const dsrcgpu_dataset* data
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(h, DSRCGPU_E_HIP, "no HIP device available: the DSRC GPU path requires an MI355X-class GPU (there is no CPU fallback)");
 	if (device < 0 || device >= ndev) return fail(h, DSRCGPU_E_ARG, "device %d out of range (%d devices)", device, ndev);
 	HIPCHK(hipSetDevice(device));
-	HIPCHK(hipStreamCreate(&h->stream));
 	{
-		int lo_p = 0, hi_p = 0;
-		HIPCHK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-		HIPCHK(hipStreamCreateWithPriority(&h->rc_stream, hipStreamNonBlocking, hi_p));
+		// Optional CU partitioning (DSRC_GPU_RC_CUS=n): the serial coder gets n compute units of its own (every
+		// (256/n)-th CU, i.e. spread over the XCDs) and the data-parallel kernels get the rest, so that
+		// concurrent scheduler instances never share a CU's instruction cache / issue slots with k_rc.
+		const char* env = getenv("DSRC_GPU_RC_CUS");
+		const int rc_cus = env ? atoi(env) : 0;
+		hipDeviceProp_t prop;
+		HIPCHK(hipGetDeviceProperties(&prop, device));
+		const int ncu = prop.multiProcessorCount;
+		if (rc_cus > 0 && rc_cus < ncu)
+		{
+			const int words = (ncu + 31) / 32;
+			std::vector<uint32_t> m_rc(words, 0), m_fe(words, 0);
+			const int step = ncu / rc_cus;
+			for (int c = 0; c < ncu; ++c)
+			{
+				const bool is_rc = (c % step) == 0 && (c / step) < rc_cus;
+				(is_rc ? m_rc : m_fe)[c / 32] |= 1u << (c % 32);
+			}
+			HIPCHK(hipExtStreamCreateWithCUMask(&h->stream, words, m_fe.data()));
+			HIPCHK(hipExtStreamCreateWithCUMask(&h->rc_stream, words, m_rc.data()));
+		}
+		else
+		{
+			HIPCHK(hipStreamCreate(&h->stream));
+			int lo_p = 0, hi_p = 0;
+			HIPCHK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+			HIPCHK(hipStreamCreateWithPriority(&h->rc_stream, hipStreamNonBlocking, hi_p));
+		}
 	}
 	for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
 	h->arena_fixed = arena_bytes;

@@ -135,6 +135,7 @@ enum { hipStreamDefault = 0, hipStreamNonBlocking = 1 };
 inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (void*)2; return hipSuccess; }
 inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = -1; return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, unsigned, const uint32_t*) { *s = (void*)3; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
