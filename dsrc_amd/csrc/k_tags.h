@@ -438,81 +438,106 @@ __global__ void __launch_bounds__(64) k_tag_trees(BlkState* st, u32* scr_pool, c
 	}
 }
 
+// what the per-record payload writer needs of a field, staged in LDS (BlkState::fld lives in HBM)
+struct TagFieldLite
+{
+	u32 min_value, min_delta, min_len, len0;
+	u32 bits_num, bits_value, bits_len;
+	u32 code_off, len_off, ham_off;
+	u8 sep, is_constant, is_numeric, is_len_constant, scheme, var_stat_encode, num_slot, pad;
+};
+
+__device__ __forceinline__ void tag_lite_load(TagFieldLite* dst, const BlkState* S, const TagFieldRes* res, u32 nf)
+{
+	for (u32 i = threadIdx.x; i < nf; i += blockDim.x)
+	{
+		const TagField* f = &S->fld[i];
+		TagFieldLite l;
+		l.min_value = (u32)f->min_value; l.min_delta = (u32)f->min_delta; l.min_len = f->min_len; l.len0 = f->len0;
+		l.bits_num = f->bits_num; l.bits_value = f->bits_value; l.bits_len = f->bits_len;
+		l.code_off = res[i].code_off; l.len_off = res[i].len_off; l.ham_off = res[i].ham_off;
+		l.sep = f->sep; l.is_constant = f->is_constant; l.is_numeric = f->is_numeric; l.is_len_constant = f->is_len_constant;
+		l.scheme = f->scheme; l.var_stat_encode = f->var_stat_encode; l.num_slot = f->num_slot; l.pad = 0;
+		dst[i] = l;
+	}
+}
+
 // bits of one numeric field of record r (StoreNumericField, src/TagModeler.cpp:753-874); emits when out != 0
-__device__ __forceinline__ u32 tag_numeric_bits(const TagField* f, const TagFieldRes& rs, const u32* scr, const u32* v, const u16* rv, const u16* rd,
+__device__ __forceinline__ u32 tag_numeric_bits(const TagFieldLite& f, const u32* scr, const u32* v, const u16* rv, const u16* rd,
 												u32 r, u32* out, u64 at)
 {
 	const u32 cur = v[r];
 	if (r == 0)
 	{
-		u32 bits = f->bits_value;
-		if (out) put_bits(out, at, cur - (u32)f->min_value, f->bits_value);
-		if (f->scheme == NS_VALUE_RLE) { if (out) put_bits(out, at + bits, (u32)rv[0] - 1u, 8); bits += 8; }
+		u32 bits = f.bits_value;
+		if (out) put_bits(out, at, cur - f.min_value, f.bits_value);
+		if (f.scheme == NS_VALUE_RLE) { if (out) put_bits(out, at + bits, (u32)rv[0] - 1u, 8); bits += 8; }
 		return bits;
 	}
-	switch (f->scheme)
+	switch (f.scheme)
 	{
 	case NS_DELTA_RLE:
 		if (rd[r])
 		{
-			if (out) { put_bits(out, at, cur - v[r - 1] - (u32)f->min_delta, f->bits_num); put_bits(out, at + f->bits_num, (u32)rd[r] - 1u, 8); }
-			return f->bits_num + 8;
+			if (out) { put_bits(out, at, cur - v[r - 1] - f.min_delta, f.bits_num); put_bits(out, at + f.bits_num, (u32)rd[r] - 1u, 8); }
+			return f.bits_num + 8;
 		}
 		return 0;
 	case NS_VALUE_RLE:
 		if (rv[r])
 		{
-			if (out) { put_bits(out, at, cur - (u32)f->min_value, f->bits_value); put_bits(out, at + f->bits_value, (u32)rv[r] - 1u, 8); }
-			return f->bits_value + 8;
+			if (out) { put_bits(out, at, cur - f.min_value, f.bits_value); put_bits(out, at + f.bits_value, (u32)rv[r] - 1u, 8); }
+			return f.bits_value + 8;
 		}
 		return 0;
 	case NS_DELTA_VAR:
 	case NS_VALUE_VAR:
 	{
-		const u32 x = f->scheme == NS_DELTA_VAR ? cur - v[r - 1] - (u32)f->min_delta : cur - (u32)f->min_value;
-		if (f->var_stat_encode)
+		const u32 x = f.scheme == NS_DELTA_VAR ? cur - v[r - 1] - f.min_delta : cur - f.min_value;
+		if (f.var_stat_encode)
 		{
-			const u32 len = scr[rs.len_off + x];
-			if (out) put_bits(out, at, scr[rs.code_off + x], len);
+			const u32 len = scr[f.len_off + x];
+			if (out) put_bits(out, at, scr[f.code_off + x], len);
 			return len;
 		}
-		if (out) put_bits(out, at, x, f->bits_num);
-		return f->bits_num;
+		if (out) put_bits(out, at, x, f.bits_num);
+		return f.bits_num;
 	}
 	default: return 0;   // DeltaConst
 	}
 }
 
 // payload bits of record r: walks the title once; emits when out != 0
-__device__ inline u32 tag_record_bits(const BlkState* S, const TagFieldRes* res, const u32* scr, const u8* t, u32 tl, u32 n, u32 r,
+__device__ inline u32 tag_record_bits(const TagFieldLite* fl, u32 nf, const u32* scr, const u8* t, u32 tlim, u32 tl, u32 n, u32 r,
 									  const u32* val, const u16* rl, u32 len_bits, u32 qlen_minus_min, u32* out, u64 at0)
 {
-	const u32 nf = S->n_fields;
+	TitleReader tr; tr.init(t, tlim);
 	u32 c = 0, start = 0; u64 at = at0;
 	for (u32 k = 0; k <= tl && c < nf; ++k)
 	{
-		const TagField* f = &S->fld[c];
-		if (k < tl && t[k] != f->sep) continue;
-		if (!f->is_constant)
+		const TagFieldLite& f = fl[c];
+		const u32 ch = k < tl ? tr.get(k) : 0;
+		if (k < tl && ch != f.sep) continue;
+		if (!f.is_constant)
 		{
-			if (f->is_numeric)
+			if (f.is_numeric)
 			{
-				const u32* v = val + (u64)f->num_slot * n;
-				const u16* rv = rl + (u64)(2 * f->num_slot) * n;
-				at += tag_numeric_bits(f, res[c], scr, v, rv, rv + n, r, out, at);
+				const u32* v = val + (u64)f.num_slot * n;
+				const u16* rv = rl + (u64)(2 * f.num_slot) * n;
+				at += tag_numeric_bits(f, scr, v, rv, rv + n, r, out, at);
 			}
 			else
 			{
 				const u32 L = k - start;
-				if (!f->is_len_constant) { if (out) put_bits(out, at, L - f->min_len, f->bits_len); at += f->bits_len; }
-				const u32* ham = scr + res[c].ham_off;
+				if (!f.is_len_constant) { if (out) put_bits(out, at, L - f.min_len, f.bits_len); at += f.bits_len; }
+				const u32* ham = scr + f.ham_off;
 				for (u32 x = 0; x < L; ++x)
 				{
-					if (x >= f->len0 || ham[x])
+					if (x >= f.len0 || ham[x])
 					{
 						const u32 ix = (x < 128 ? x : 128u) * 256u + t[start + x];
-						const u32 len = scr[res[c].len_off + ix];
-						if (out) put_bits(out, at, scr[res[c].code_off + ix], len);
+						const u32 len = scr[f.len_off + ix];
+						if (out) put_bits(out, at, scr[f.code_off + ix], len);
 						at += len;
 					}
 				}
@@ -530,6 +555,7 @@ __global__ void __launch_bounds__(WG) k_tag_emit(const u8* in, const BlkDesc* de
 {
 	__shared__ u32 s_hdr;
 	__shared__ u64 s_total;
+	__shared__ TagFieldLite s_fl[DSRC_MAX_FIELDS];
 	const u32 b = blockIdx.x;
 	BlkState* S = &st[b];
 	const u32 nf = S->n_fields, n = S->n_recs;
@@ -539,6 +565,7 @@ __global__ void __launch_bounds__(WG) k_tag_emit(const u8* in, const BlkDesc* de
 	const TagFieldRes* res = res_all + (u64)b * DSRC_MAX_FIELDS;
 	u32* scr = scr_pool + pl.scr;
 	u32* out = word_pool + d.tag_out;
+	tag_lite_load(s_fl, S, res, nf);
 	const u8* base = in + d.in_off;
 	const u8* t0 = base + rp.title_off[d.rec_base];
 	if (threadIdx.x == 0)
@@ -606,7 +633,7 @@ __global__ void __launch_bounds__(WG) k_tag_emit(const u8* in, const BlkDesc* de
 	for (u32 r = threadIdx.x; r < n; r += blockDim.x)
 	{
 		const u64 g = (u64)d.rec_base + r;
-		rbits[r] = tag_record_bits(S, res, scr, base + rp.title_off[g], rp.title_len[g], n, r, val, rl, len_bits, rp.len[g] - minq, 0, 0);
+		rbits[r] = tag_record_bits(s_fl, nf, scr, base + rp.title_off[g], d.in_size - rp.title_off[g], rp.title_len[g], n, r, val, rl, len_bits, rp.len[g] - minq, 0, 0);
 	}
 	__syncthreads();
 	const u64 carry = (u64)s_hdr * 8;
@@ -627,7 +654,7 @@ __global__ void __launch_bounds__(WG) k_tag_emit(const u8* in, const BlkDesc* de
 	for (u32 r = threadIdx.x; r < n; r += blockDim.x)
 	{
 		const u64 g = (u64)d.rec_base + r;
-		tag_record_bits(S, res, scr, base + rp.title_off[g], rp.title_len[g], n, r, val, rl, len_bits, rp.len[g] - minq, out, carry + rbits[r]);
+		tag_record_bits(s_fl, nf, scr, base + rp.title_off[g], d.in_size - rp.title_off[g], rp.title_len[g], n, r, val, rl, len_bits, rp.len[g] - minq, out, carry + rbits[r]);
 	}
 	if (threadIdx.x == 0) S->tag_bytes = (u32)((s_total + 7) / 8);
 }

@@ -1,0 +1,84 @@
+"""Parity at BASELINE block size through size-independent properties (the oracle is too slow for whole data sets):
+a batch of full 8 MiB chunks generated in HBM is compressed in one scheduler pass, then
+  * every block's header must carry the exact record count / chunk size of its chunk,
+  * the reference's own decoder (oracle/_ref, BlockCompressor::Read) must reproduce sampled chunks byte for byte,
+  * sampled blocks must equal the oracle's bytes (with the compressor state carried in chunk order),
+  * a block's bytes must not depend on which other chunks share the batch (apart from that documented state)."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from tests._oracle import Config, _orc_cfg, have_ref
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    os.environ.pop("DSRC_GPU_LIB", None)
+    from dsrc_amd import _lib
+    _lib._lib = None
+    return _lib
+
+
+def _bench_helpers():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("d,q", [(3, 2), (0, 0)])
+def test_full_size_blocks(gpu, oracle, d, q):
+    bench = _bench_helpers()
+    nblocks = 24
+    cfg = Config.from_levels(d, q)
+    h = gpu.Handle(cfg.dna_order, cfg.quality_order)
+    recs = int(nblocks * bench.RECS_PER_BLOCK * 1.02) + 1000
+    cap = recs * 384
+    d_in = h.dev_alloc(cap); d_out = h.dev_alloc(cap // 2)
+    first = 123456789
+    nbytes = h.synth_illumina(first, recs, d_in, cap)
+    off = bench.record_offsets(first, recs)
+    assert off[-1] == nbytes
+    starts, sizes = bench.cut_blocks(off, nblocks)
+    o_offs, o_sizes, raw, comp = h.compress_batch_device(d_in, starts, sizes, d_out, cap // 2)
+    blob = h.dev_download(d_out, o_offs[-1] + o_sizes[-1])
+    # header words: recordsCount, maxQuaLength, flags, chunkSize (StoreMetaData, reference src/BlockCompressor.cpp:403-443)
+    rec_starts = np.searchsorted(off, np.array(starts + [starts[-1] + sizes[-1] + 1]))
+    for i in range(nblocks):
+        n_recs, max_len, flags, chunk_size = struct.unpack(">IIII", blob[o_offs[i]: o_offs[i] + 16])
+        assert n_recs == rec_starts[i + 1] - rec_starts[i]
+        assert (max_len, flags, chunk_size) == (150, 0, sizes[i])
+        assert sum(comp[4 * i: 4 * i + 4]) == o_sizes[i] and raw[4 * i + 2] == raw[4 * i + 3] == 150 * n_recs
+    assert all(o_offs[i] + o_sizes[i] == o_offs[i + 1] for i in range(nblocks - 1))
+    sample = [0, nblocks // 2, nblocks - 1]
+    chunks = {i: h.dev_download(d_in + starts[i], sizes[i]) for i in sample}
+    if have_ref():
+        from tests._oracle import Ref
+        r = Ref()
+        for i in sample:
+            back = r.decompress_block(cfg, blob[o_offs[i]: o_offs[i] + o_sizes[i]], sizes[i] + 64)
+            assert back == chunks[i] + b"\n"
+    # oracle bytes, carrying the reference's block-to-block compressor state in chunk order
+    capst = C.c_uint32(0); c = _orc_cfg(cfg)
+    for i in range(nblocks):
+        if i not in sample and i > 1:
+            continue
+        ch = chunks[i] if i in chunks else h.dev_download(d_in + starts[i], sizes[i])
+        out = (C.c_uint8 * (len(ch) + 65536))(); osz = C.c_uint64(); r4 = (C.c_uint64 * 4)(); c4 = (C.c_uint64 * 4)()
+        assert oracle.lib.orc_compress_block_state(C.byref(c), C.byref(capst), ch, C.c_uint64(len(ch)), out, C.c_uint64(len(out)), C.byref(osz), r4, c4) == 0
+        assert blob[o_offs[i]: o_offs[i] + o_sizes[i]] == bytes(out[:osz.value]), f"block {i}"
+    # batch independence: the same chunk in a different batch position (state already warmed up) gives the same bytes
+    h2 = gpu.Handle(cfg.dna_order, cfg.quality_order)
+    o2 = h2.compress_batch_device(d_in, [starts[0], starts[5], starts[3]], [sizes[0], sizes[5], sizes[3]], d_out, cap // 2)
+    blob2 = h2.dev_download(d_out, o2[0][-1] + o2[1][-1])
+    assert blob2[o2[0][1]: o2[0][1] + o2[1][1]] == blob[o_offs[5]: o_offs[5] + o_sizes[5]]
+    assert blob2[o2[0][2]: o2[0][2] + o2[1][2]] == blob[o_offs[3]: o_offs[3] + o_sizes[3]]
+    h2.close()
+    h.dev_free(d_in); h.dev_free(d_out); h.close()
