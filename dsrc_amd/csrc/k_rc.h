@@ -22,7 +22,7 @@
 #define ELEM_CTX_SHIFT 40
 
 // what the range coder consumes per symbol (written by k_replay in stream order, lane-interleaved per group)
-struct __attribute__((aligned(16))) RcRec { u64 w; u32 cum; u32 pad; };   // w = ceil(2^48/total) << 16 | freq
+struct RcRec { u32 w_lo, w_hi, cum; };   // 12 bytes; w = w_hi:w_lo = ceil(2^48/total) << 16 | freq
 
 struct CtxJob     // one (block, stream)
 {
@@ -330,8 +330,8 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 		if (active)
 		{	// what k_rc needs per symbol: the 48-bit reciprocal of `total` (rc_div), freq, cum -- one 16-byte record
 			RcRec rr;
-			rr.w = ((((1ull << 48) + tot - 1) / tot) << 16) | f;
-			rr.cum = cum; rr.pad = 0;
+			const u64 w = ((((1ull << 48) + tot - 1) / tot) << 16) | f;
+			rr.w_lo = (u32)w; rr.w_hi = (u32)(w >> 32); rr.cum = cum;
 			recs[(u64)(u32)el * stride] = rr;
 		}
 
@@ -409,8 +409,8 @@ __device__ __forceinline__ void rc_flush4(RcState& s, u8* out)
 // fast step; returns non-zero if the clamp pre-condition was seen
 __device__ __forceinline__ u32 rc_step_fast(RcState& s, u8* out, const RcRec& e)
 {
-	const u32 f = (u32)e.w & 0xFFFFu;
-	const u32 r = rc_div(s.range, (u32)(e.w >> 16), (u32)(e.w >> 48));
+	const u32 f = e.w_lo & 0xFFFFu;
+	const u32 r = rc_div(s.range, (e.w_lo >> 16) | (e.w_hi << 16), e.w_hi >> 16);
 	const u64 low = s.low + (u64)r * e.cum;                                // r*cum <= range < 2^32: identical to the reference's 32-bit product
 	const u32 range = r * f;
 	const u32 k8 = ((u32)__builtin_clz(range) >> 3) << 3;                    // 8 * bytes leaving the coder (0..24); range != 0
@@ -426,8 +426,8 @@ __device__ __forceinline__ u32 rc_step_fast(RcState& s, u8* out, const RcRec& e)
 // exact step: RangeEncoder::EncodeFrequency, verbatim, on the same output state
 __device__ inline void rc_step_exact(RcState& s, u8* out, const RcRec& e)
 {
-	const u32 f = (u32)e.w & 0xFFFFu;
-	const u32 r = rc_div(s.range, (u32)(e.w >> 16), (u32)(e.w >> 48));
+	const u32 f = e.w_lo & 0xFFFFu;
+	const u32 r = rc_div(s.range, (e.w_lo >> 16) | (e.w_hi << 16), e.w_hi >> 16);
 	u64 low = s.low + (u64)r * e.cum;
 	u32 range = r * f;
 	while (range <= 0x00FFFFFFu)
@@ -465,22 +465,25 @@ __global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, 
 
 	const u32 n = c.n;
 	const u64 stride = c.stride;
-	// three register buffers in rotation: while group g is coded, g+1 has landed and g+2 is in flight
-	// (32 symbols ~ 3 us of prefetch distance: enough when other kernels load the memory system)
-	RcRec A[RC_GROUP], B[RC_GROUP], C[RC_GROUP];
+	// four register buffers in rotation: while group g is coded, g+1 and g+2 have landed or are landing and g+3
+	// is being requested (48 symbols ~ 4-5 us of prefetch distance: the coder must not stall when other kernels
+	// load the memory system)
+	RcRec A[RC_GROUP], B[RC_GROUP], C[RC_GROUP], D[RC_GROUP];
 	u32 t0 = 0;
-	if (n >= 3 * RC_GROUP)
+	if (n >= 4 * RC_GROUP)
 	{
 #pragma unroll
 		for (u32 i = 0; i < RC_GROUP; ++i) A[i] = p[(u64)i * stride];
 #pragma unroll
 		for (u32 i = 0; i < RC_GROUP; ++i) B[i] = p[(u64)(RC_GROUP + i) * stride];
-		// invariant at the loop head: A = group at t0, B = group at t0+16, both requested
-		for (; t0 + 5 * RC_GROUP <= n; t0 += 3 * RC_GROUP)
-		{
-			const RcRec* q = p + (u64)(t0 + 2 * RC_GROUP) * stride;
 #pragma unroll
-			for (u32 i = 0; i < RC_GROUP; ++i) C[i] = q[(u64)i * stride];
+		for (u32 i = 0; i < RC_GROUP; ++i) C[i] = p[(u64)(2 * RC_GROUP + i) * stride];
+		// invariant at the loop head: A, B, C = groups at t0, t0+16, t0+32, all requested
+		for (; t0 + 7 * RC_GROUP <= n; t0 += 4 * RC_GROUP)
+		{
+			const RcRec* q = p + (u64)(t0 + 3 * RC_GROUP) * stride;
+#pragma unroll
+			for (u32 i = 0; i < RC_GROUP; ++i) D[i] = q[(u64)i * stride];
 			rc_group(s, out, A);
 			q += (u64)RC_GROUP * stride;
 #pragma unroll
@@ -490,10 +493,15 @@ __global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, 
 #pragma unroll
 			for (u32 i = 0; i < RC_GROUP; ++i) B[i] = q[(u64)i * stride];
 			rc_group(s, out, C);
+			q += (u64)RC_GROUP * stride;
+#pragma unroll
+			for (u32 i = 0; i < RC_GROUP; ++i) C[i] = q[(u64)i * stride];
+			rc_group(s, out, D);
 		}
-		rc_group(s, out, A);                                                   // both pending groups are complete: t0 + 32 <= n
+		rc_group(s, out, A);                                                   // the three pending groups are complete: t0 + 48 <= n
 		rc_group(s, out, B);
-		t0 += 2 * RC_GROUP;
+		rc_group(s, out, C);
+		t0 += 3 * RC_GROUP;
 	}
 	for (; t0 < n; ++t0) { const RcRec e = p[(u64)t0 * stride]; rc_step_exact(s, out, e); }
 
