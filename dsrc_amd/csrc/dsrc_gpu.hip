@@ -387,25 +387,23 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	const u32 NJ = (u32)jobs.size();
 	std::vector<RcChain> chains(NJ);
 	{
-		size_t trip_words = 0;
-		std::vector<size_t> gbase((NJ + 63) / 64 + 1, 0);
-		for (u32 g = 0; g * 64 < NJ; ++g)
-		{
-			u32 mx = 0;
-			for (u32 i = g * 64; i < std::min(NJ, g * 64 + 64); ++i) mx = std::max(mx, jobs[i].n);
-			gbase[g] = trip_words; trip_words += (size_t)mx * (std::min(NJ, g * 64 + 64) - g * 64);
-		}
-		const size_t o_trip = A.alloc(trip_words * sizeof(RcRec) + 64);
+		// records of one chain are contiguous: k_replay scatters inside one chain's 12 B x n array (a few chains in
+		// flight stay within the memory-side cache) and k_rc streams it through LDS.  Chains start on 48-byte
+		// boundaries; k_rc's DMA may read RC_OVERREAD records past the longest chain of its wave.
+		size_t trip_words = 0; u32 mxn = 0;
+		std::vector<size_t> cbase(NJ + 1, 0);
+		for (u32 i = 0; i < NJ; ++i) { cbase[i] = trip_words; trip_words += ((size_t)jobs[i].n + 3) / 4 * 4; mxn = std::max(mxn, jobs[i].n); }
+		const size_t o_trip = A.alloc((trip_words + mxn + RC_OVERREAD) * sizeof(RcRec) + 256);
+		const size_t trip0 = (o_trip + 47) / 48 * 4;
 		for (u32 i = 0; i < NJ; ++i)
 		{
 			CtxJob& j = jobs[i];
 			j.passes = (j.key_bits + 9) / 10; if (j.passes == 0) j.passes = 1;
 			j.dbits = (j.key_bits + j.passes - 1) / j.passes; if (j.dbits == 0) j.dbits = 1;
 			j.sorted_in_b = j.passes & 1;
-			j.trip = o_trip / sizeof(RcRec) + gbase[i / 64] + (i % 64);
-			j.trip_stride = std::min(NJ, (i / 64) * 64 + 64) - (i / 64) * 64;
+			j.trip = trip0 + cbase[i];
 			RcChain& c = chains[i];
-			c.trip = j.trip; c.out_words = j.out_words; c.n = j.n; c.out_byte0 = j.out_byte0; c.out_cap = j.out_cap; c.blk = j.blk; c.is_dna = j.is_dna; c.stride = j.trip_stride;
+			c.trip = j.trip; c.out_words = j.out_words; c.n = j.n; c.out_byte0 = j.out_byte0; c.out_cap = j.out_cap; c.blk = j.blk; c.is_dna = j.is_dna;
 		}
 	}
 	// The ping-pong sort buffers are only alive from k_ctx to k_replay, so the job list is cut into slices that
@@ -543,7 +541,9 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 				while (hi < s_hi && jobs[hi].n_alpha == jobs[lo].n_alpha) ++hi;
 				const u32 cnt = hi - lo;
 				u32 mxn = 1; for (u32 i = lo; i < hi; ++i) mxn = std::max(mxn, jobs[i].n);
-				const u32 parts = std::max(1u, std::min(32u, mxn / 16384u));   // REPLAY_WG/64 waves each; >= 4k symbols per wave
+				// REPLAY_WG/64 waves per part.  Many waves per chain = few chains in flight: the scattered 12-byte records of
+				// a chain then merge in the memory-side cache (measured: 32 parts 164 ms, 512 parts 71 ms per 512 DNA chains)
+				const u32 parts = std::max(1u, std::min(512u, mxn / 1024u));
 				switch (jobs[lo].n_alpha)
 				{
 				case 4:   hipLaunchKernelGGL(k_replay<4>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
@@ -562,7 +562,8 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		HIPCHK(hipEventRecord(h->ev[4], s));
 		HIPCHK(hipStreamWaitEvent(h->rc_stream, h->ev[4], 0));
 		HIPCHK(hipEventRecord(h->ev[2], h->rc_stream));
-		hipLaunchKernelGGL(k_rc, dim3((NJ + 63) / 64), dim3(64), 0, h->rc_stream, d_chains, NJ, AP<RcRec>(h, 0), wpool, d_state); KCHK();
+		if (!getenv("DSRC_GPU_EXP_SKIP_RC"))     // timing experiments on the front end only (output is then meaningless)
+			hipLaunchKernelGGL(k_rc, dim3((NJ + 63) / 64), dim3(64), 0, h->rc_stream, d_chains, NJ, AP<RcRec>(h, 0), wpool, d_state); KCHK();
 		HIPCHK(hipEventRecord(h->ev[3], h->rc_stream));
 		HIPCHK(hipStreamWaitEvent(s, h->ev[3], 0));
 		h->rc_launches = 1;

@@ -28,6 +28,23 @@ __device__ __forceinline__ u32 wave_max(u32 v)
 	return v;
 }
 
+// LDS DMA (gfx950 global_load_lds_dwordx4): every active lane fetches 16 bytes from its own global address and
+// they land at lds_dst (wave-uniform) + 16 * lane without passing through registers
+__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst)
+{
+	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// every LDS-DMA request this wave has issued so far has landed: s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt in bits
+// 3:0 and 15:14, expcnt/lgkmcnt left at their maxima), followed by a wave-scope fence (no instruction; it keeps the
+// compiler from moving LDS reads above the wait).  The compiler's own tracking of LDS DMA is not relied upon.
+__device__ __forceinline__ void lds_dma_wait()
+{
+	__builtin_amdgcn_s_waitcnt(0x0F70);
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ u32 wave_sum(u32 v)
 {
 	for (u32 d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, (int)d);

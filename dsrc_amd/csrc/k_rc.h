@@ -11,8 +11,8 @@
 //   k_sort    : stable LSD radix sort of (ctx, sym, t) by ctx -> each context's history is contiguous
 //   k_replay  : one lane replays one context's history on a private counter row in LDS and
 //               emits (total, cum, freq) for every symbol, scattered back to stream order
-//   k_rc      : the integer range-coder recurrence, one LANE per stream (64 streams per wave);
-//               triples are lane-interleaved so that the wave's loads are one coalesced 512 B row
+//   k_rc      : the integer range-coder recurrence, one LANE per stream (64 streams per wave); each
+//               stream's records are contiguous, the wave pulls them through LDS 768 B at a time (LDS DMA)
 // No adaptive table ever exists in HBM (the reference clears 2-64 MiB per block).
 #pragma once
 #include "k_common.h"
@@ -21,7 +21,7 @@
 #define ELEM_SYM_SHIFT 32
 #define ELEM_CTX_SHIFT 40
 
-// what the range coder consumes per symbol (written by k_replay in stream order, lane-interleaved per group)
+// what the range coder consumes per symbol (written by k_replay in stream order, one contiguous array per chain)
 struct RcRec { u32 w_lo, w_hi, cum; };   // 12 bytes; w = w_hi:w_lo = ceil(2^48/total) << 16 | freq
 
 struct CtxJob     // one (block, stream)
@@ -29,7 +29,7 @@ struct CtxJob     // one (block, stream)
 	u64 src_off;        // byte offset of the symbol stream (q_stream / d_stream)
 	u64 elems;          // u64 index of sort buffer A
 	u64 elems_b;        // u64 index of sort buffer B
-	u64 trip;           // RcRec index of this chain's first record (group base + lane)
+	u64 trip;           // RcRec index of this chain's first record
 	u32 n;              // symbols
 	u32 blk;
 	u32 alpha_bits;     // log2(alphabet)
@@ -45,7 +45,7 @@ struct CtxJob     // one (block, stream)
 	u32 is_dna;
 	u32 scheme;         // scheme byte of the stream prologue
 	u32 n_alpha;        // alphabet size (replay template selector)
-	u32 trip_stride;    // chains in this chain's group (<= 64): triples of symbol t live at trip + t*stride
+	u32 pad0;
 };
 
 // ---- DNA context: hash of the previous `order` symbols, carried across records --------------
@@ -200,7 +200,9 @@ __global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool)
 //     freq  = base[s] + 2 * #{earlier lanes of my segment with the same symbol}
 //     cum   = cumbase[s] + 2 * #{earlier lanes of my segment with a smaller symbol}
 //     total = T0 + 2 * (symbols coded so far in the epoch)
-// which are popcounts of per-symbol ballots masked to the lane's segment.  Only the segment that
+// which are popcounts of per-symbol ballots masked to the lane's segment.  (The records are scattered into
+// the chain's own 12 B x n array: with few chains in flight that array stays in the memory-side cache, so the
+// 12-byte pieces merge into full lines before they reach HBM -- the launch uses many waves per chain.)  Only the segment that
 // is still open at the end of a window carries state (lane v keeps base[v] / cnt[v]); a window is
 // cut short where that segment hits its rescale point.  A wave owns the segments whose heads fall
 // into its slice of the array, so any number of waves can work on one stream.
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 	const CtxJob j = jobs[blockIdx.y];
 	const u64* src = pool + (j.sorted_in_b ? j.elems_b : j.elems);
 	RcRec* recs = rec_pool + j.trip;
-	const u32 n = j.n, stride = j.trip_stride;
+	const u32 n = j.n;
 	const u32 lane = lane_id();
 	const u32 limit = (1u << 16) - 2u * N;                   // MaxAccumulatedValue (src/SymbolCoderRC.h:67)
 	const u32 n_ranges = gridDim.x * (REPLAY_WG / 64);
@@ -332,7 +334,7 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 			RcRec rr;
 			const u64 w = ((((1ull << 48) + tot - 1) / tot) << 16) | f;
 			rr.w_lo = (u32)w; rr.w_hi = (u32)(w >> 32); rr.cum = cum;
-			recs[(u64)(u32)el * stride] = rr;
+			recs[(u32)el] = rr;
 		}
 
 		// carry the segment that is open at the end of the window
@@ -369,7 +371,11 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 //   range -> floor(range / total) -> * freq -> renormalise
 // and on the GPU its cost is instruction issue, so the step is kept to ~25 straight-line instructions:
 //   * floor(range/total) is a multiply by the 48-bit reciprocal k_replay stored (exact, see rc_div);
-//   * records are fetched 16 symbols ahead with one 16-byte load each (ping-pong register buffers);
+//   * a wave owns 64 chains whose records lie in 64 different arrays.  Per 64 symbols it issues one LDS-DMA
+//     load per chain (global_load_lds_dwordx4 on 48 lanes = 768 contiguous bytes = 64 records of ONE chain,
+//     landing in that chain's LDS row) for the chunk after the current one, so every global access is a full
+//     coalesced row and the coder runs 64-128 symbols (6-12 us) behind its loads; lane c then reads row c,
+//     16 records at a time, with ds_read_b128 into ping-pong registers;
 //   * the renormalisation count comes from clz; bytes leaving the coder collect in a register and are
 //     stored four at a time;
 //   * RangeEncoder::EncodeFrequency's carry clamp (src/RangeCoder.h:64-74) needs bits 24..39 of `low` to be
@@ -377,15 +383,20 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 //     group is replayed from a snapshot with the reference's loop, verbatim.
 struct RcChain
 {
-	u64 trip;          // RcRec index: record of symbol t at trip + t*stride
+	u64 trip;          // RcRec index of the chain's first record (a multiple of 4: rows are 16-byte aligned)
 	u64 out_words;     // u32 index of the staging stream
 	u32 n;
 	u32 out_byte0, out_cap;
 	u32 blk, is_dna;
-	u32 stride;
+	u32 pad0;
 };
 
-#define RC_GROUP 16
+#define RC_GROUP 16                    // symbols per register group / clamp check
+#define RC_CHUNK 64                    // symbols per chain per LDS chunk (768 B = 48 lanes x 16 B)
+#define RC_ROW_U4 49                   // LDS row pitch in 16-byte units: 48 of data + 1 so that a 16-lane ds_read_b128 pass covers all 64 banks
+#define RC_OVERREAD (3 * RC_CHUNK)     // records the DMA may touch past the longest chain of a wave (arena slack)
+
+struct alignas(16) U4 { u32 x, y, z, w; };
 
 // magic = ceil(2^48 / d): floor(n * magic / 2^48) == floor(n / d) for every n < 2^32, d <= 2^16 (the error term
 // n*e/2^48 < 2^-16 cannot carry the fraction (<= 1 - 1/d) over an integer)
@@ -440,70 +451,108 @@ __device__ inline void rc_step_exact(RcState& s, u8* out, const RcRec& e)
 	s.low = low; s.range = range;
 }
 
-__device__ __forceinline__ void rc_group(RcState& s, u8* out, const RcRec (&g)[RC_GROUP])
+// one register group: 16 records = 48 dwords = 12 x 16 bytes, as they lie in the chain's array
+struct RcRegs { U4 q[3 * RC_GROUP / 4]; };
+
+__device__ __forceinline__ RcRec rc_rec(const RcRegs& g, u32 i)
+{
+	const u32* d = (const u32*)g.q;
+	RcRec e; e.w_lo = d[3 * i]; e.w_hi = d[3 * i + 1]; e.cum = d[3 * i + 2];
+	return e;
+}
+
+// `row` = the chain's LDS row the group was read from (still intact while the group is coded)
+__device__ __forceinline__ void rc_group(RcState& s, u8* out, const RcRegs& g, const U4* row, u32 grp)
 {
 	const RcState snap = s;
 	u32 bad = 0;
 #pragma unroll
-	for (u32 i = 0; i < RC_GROUP; ++i) bad |= rc_step_fast(s, out, g[i]);
+	for (u32 i = 0; i < RC_GROUP; ++i) bad |= rc_step_fast(s, out, rc_rec(g, i));
 	if (bad)
 	{
 		s = snap;
-		for (u32 i = 0; i < RC_GROUP; ++i) rc_step_exact(s, out, g[i]);
+		const u32* d = (const u32*)row + 3 * RC_GROUP * grp;
+		for (u32 i = 0; i < RC_GROUP; ++i)
+		{
+			RcRec e; e.w_lo = d[3 * i]; e.w_hi = d[3 * i + 1]; e.cum = d[3 * i + 2];
+			rc_step_exact(s, out, e);
+		}
 	}
+}
+
+__device__ __forceinline__ void rc_load_group(RcRegs& g, const U4* row, u32 grp)
+{
+#pragma unroll
+	for (u32 i = 0; i < 3 * RC_GROUP / 4; ++i) g.q[i] = row[grp * (3 * RC_GROUP / 4) + i];
+}
+
+// LDS-DMA requests for chains [J0, J1) of the wave: lanes 0..47 fetch the 48 x 16 bytes (= 64 records) of chain j
+// that start at byte `byte_off` of its array into row j
+template <int J0, int J1>
+__device__ __forceinline__ void rc_dma(U4* buf, u32 src_lo, u32 src_hi, u32 byte_off)
+{
+	u64 base[J1 - J0];
+#pragma unroll
+	for (int j = J0; j < J1; ++j)
+		base[j - J0] = ((u64)(u32)__builtin_amdgcn_readlane((int)src_hi, j) << 32) | (u32)__builtin_amdgcn_readlane((int)src_lo, j);
+	if (threadIdx.x < 3 * RC_CHUNK / 4)
+	{
+#pragma unroll
+		for (int j = J0; j < J1; ++j) lds_dma16((const u8*)base[j - J0] + byte_off, buf + j * RC_ROW_U4);
+	}
+}
+
+// one 64-symbol chunk: the chain's records are in `cur` (landed), r0 holds its first group; requests the
+// chunk after it into `nxt` and leaves that chunk's first group in r0
+__device__ __forceinline__ void rc_chunk(RcState& s, u8* out, RcRegs& r0, RcRegs& r1, const U4* cur, U4* nxt, u32 t0, u32 n, u32 src_lo, u32 src_hi)
+{
+	const u32 lane = threadIdx.x;
+	const u32 off = (t0 + RC_CHUNK) * (u32)sizeof(RcRec) + lane * 16u;
+	const U4* row = cur + lane * RC_ROW_U4;
+	rc_load_group(r1, row, 1);
+	rc_dma<0, 22>(nxt, src_lo, src_hi, off);
+	if (t0 + 1 * RC_GROUP <= n) rc_group(s, out, r0, row, 0);
+	rc_load_group(r0, row, 2);
+	rc_dma<22, 43>(nxt, src_lo, src_hi, off);
+	if (t0 + 2 * RC_GROUP <= n) rc_group(s, out, r1, row, 1);
+	rc_load_group(r1, row, 3);
+	rc_dma<43, 64>(nxt, src_lo, src_hi, off);
+	if (t0 + 3 * RC_GROUP <= n) rc_group(s, out, r0, row, 2);
+	lds_dma_wait();                                                        // the requests above have landed before row 0 of `nxt` is read
+	rc_load_group(r0, nxt + lane * RC_ROW_U4, 0);
+	if (t0 + 4 * RC_GROUP <= n) rc_group(s, out, r1, row, 3);
 }
 
 __global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, const RcRec* rec_pool, u32* word_pool, BlkState* st)
 {
-	const u32 id = blockIdx.x * 64 + threadIdx.x;
-	if (id >= n_chains) return;
-	const RcChain c = chains[id];
+	__shared__ U4 s_a[64 * RC_ROW_U4];
+	__shared__ U4 s_b[64 * RC_ROW_U4];
+	const u32 lane = threadIdx.x, id = blockIdx.x * 64 + lane;
+	const bool have = id < n_chains;
+	const RcChain c = chains[have ? id : n_chains - 1];                        // idle lanes shadow a real chain's addresses and code nothing
+	const u32 n = have ? c.n : 0;
 	const RcRec* p = rec_pool + c.trip;
 	u8* out = (u8*)(word_pool + c.out_words);
 	RcState s;
 	s.low = 0; s.range = 0xFFFFFFFFu; s.pos = c.out_byte0; s.acc = 0; s.nbits = 0;
 
-	const u32 n = c.n;
-	const u64 stride = c.stride;
-	// four register buffers in rotation: while group g is coded, g+1 and g+2 have landed or are landing and g+3
-	// is being requested (48 symbols ~ 4-5 us of prefetch distance: the coder must not stall when other kernels
-	// load the memory system)
-	RcRec A[RC_GROUP], B[RC_GROUP], C[RC_GROUP], D[RC_GROUP];
-	u32 t0 = 0;
-	if (n >= 4 * RC_GROUP)
+	const u32 n_full = n & ~(u32)(RC_GROUP - 1);
+	const u32 wave_full = wave_max(n_full);
+	if (wave_full)
 	{
-#pragma unroll
-		for (u32 i = 0; i < RC_GROUP; ++i) A[i] = p[(u64)i * stride];
-#pragma unroll
-		for (u32 i = 0; i < RC_GROUP; ++i) B[i] = p[(u64)(RC_GROUP + i) * stride];
-#pragma unroll
-		for (u32 i = 0; i < RC_GROUP; ++i) C[i] = p[(u64)(2 * RC_GROUP + i) * stride];
-		// invariant at the loop head: A, B, C = groups at t0, t0+16, t0+32, all requested
-		for (; t0 + 7 * RC_GROUP <= n; t0 += 4 * RC_GROUP)
+		const u32 src_lo = (u32)(u64)p, src_hi = (u32)((u64)p >> 32);
+		RcRegs r0, r1;
+		rc_dma<0, 64>(s_a, src_lo, src_hi, lane * 16u);
+		lds_dma_wait();
+		rc_load_group(r0, s_a + lane * RC_ROW_U4, 0);
+		for (u32 t0 = 0; t0 < wave_full; t0 += 2 * RC_CHUNK)
 		{
-			const RcRec* q = p + (u64)(t0 + 3 * RC_GROUP) * stride;
-#pragma unroll
-			for (u32 i = 0; i < RC_GROUP; ++i) D[i] = q[(u64)i * stride];
-			rc_group(s, out, A);
-			q += (u64)RC_GROUP * stride;
-#pragma unroll
-			for (u32 i = 0; i < RC_GROUP; ++i) A[i] = q[(u64)i * stride];
-			rc_group(s, out, B);
-			q += (u64)RC_GROUP * stride;
-#pragma unroll
-			for (u32 i = 0; i < RC_GROUP; ++i) B[i] = q[(u64)i * stride];
-			rc_group(s, out, C);
-			q += (u64)RC_GROUP * stride;
-#pragma unroll
-			for (u32 i = 0; i < RC_GROUP; ++i) C[i] = q[(u64)i * stride];
-			rc_group(s, out, D);
+			rc_chunk(s, out, r0, r1, s_a, s_b, t0, n, src_lo, src_hi);
+			rc_chunk(s, out, r0, r1, s_b, s_a, t0 + RC_CHUNK, n, src_lo, src_hi);
 		}
-		rc_group(s, out, A);                                                   // the three pending groups are complete: t0 + 48 <= n
-		rc_group(s, out, B);
-		rc_group(s, out, C);
-		t0 += 3 * RC_GROUP;
 	}
-	for (; t0 < n; ++t0) { const RcRec e = p[(u64)t0 * stride]; rc_step_exact(s, out, e); }
+	for (u32 t = n_full; t < n; ++t) { const RcRec e = p[t]; rc_step_exact(s, out, e); }
+	if (!have) return;
 
 	const u32 nb = s.nbits >> 3;
 	for (u32 k = 0; k < nb; ++k) out[s.pos + k] = (u8)(s.acc >> (8 * (nb - 1 - k)));

@@ -94,6 +94,13 @@ template <typename T> inline T __shfl_up(T v, unsigned d, int width = 64) { (voi
 template <typename T> inline T __shfl_down(T v, unsigned d, int width = 64) { (void)width; int l = (int)(threadIdx.x & 63); return emu_shfl_from(v, l + (int)d <= 63 ? l + (int)d : l); }
 template <typename T> inline T __shfl_xor(T v, int m, int width = 64) { (void)width; int l = (int)(threadIdx.x & 63); return emu_shfl_from(v, l ^ m); }
 
+// gfx950 intrinsics used by k_common.h / k_rc.h
+#define __builtin_amdgcn_readlane(v, l) emu_shfl_from((int)(v), (int)(l))
+#define __builtin_amdgcn_wave_barrier() do { uint64_t g_[64]; emu::wave_exchange(0, g_); } while (0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_global_load_lds(g, l, sz, off, aux) memcpy((char*)(l) + (threadIdx.x & 63) * ((sz) == 12 ? 16 : (sz)), (const char*)(g) + (off), (sz))   /* measured on gfx950: the 12-byte form also advances 16 bytes per lane */
+
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
