@@ -390,6 +390,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		// records of one chain are contiguous: k_replay scatters inside one chain's 12 B x n array (a few chains in
 		// flight stay within the memory-side cache) and k_rc streams it through LDS.  Chains start on 48-byte
 		// boundaries; k_rc's DMA may read RC_OVERREAD records past the longest chain of its wave.
+		const u32 force_exact = getenv("DSRC_GPU_FORCE_EXACT_RC") ? 1u : 0u;             // tests only (read per batch)
 		size_t trip_words = 0; u32 mxn = 0;
 		std::vector<size_t> cbase(NJ + 1, 0);
 		for (u32 i = 0; i < NJ; ++i) { cbase[i] = trip_words; trip_words += ((size_t)jobs[i].n + 3) / 4 * 4; mxn = std::max(mxn, jobs[i].n); }
@@ -398,12 +399,19 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		for (u32 i = 0; i < NJ; ++i)
 		{
 			CtxJob& j = jobs[i];
-			j.passes = (j.key_bits + 9) / 10; if (j.passes == 0) j.passes = 1;
+			j.passes = (j.key_bits + SORT_DIGIT_BITS - 1) / SORT_DIGIT_BITS; if (j.passes == 0) j.passes = 1;
 			j.dbits = (j.key_bits + j.passes - 1) / j.passes; if (j.dbits == 0) j.dbits = 1;
 			j.sorted_in_b = j.passes & 1;
 			j.trip = trip0 + cbase[i];
 			RcChain& c = chains[i];
 			c.trip = j.trip; c.out_words = j.out_words; c.n = j.n; c.out_byte0 = j.out_byte0; c.out_cap = j.out_cap; c.blk = j.blk; c.is_dna = j.is_dna;
+			c.force_exact = force_exact;
+		}
+		for (u32 i = 0; i < NJ; i += 64)
+		{	// k_rc addresses the 64 arrays of a wave as one base + 32-bit byte offsets
+			const u32 last = std::min(NJ, i + 64) - 1;
+			if ((cbase[last] - cbase[i] + jobs[last].n + mxn + RC_OVERREAD) * sizeof(RcRec) >= (1ull << 32))
+				return fail(h, DSRCGPU_E_ARG, "chunks too large for the range-coder stage (64 streams exceed 4 GiB of records); use a smaller buffer size");
 		}
 	}
 	// The ping-pong sort buffers are only alive from k_ctx to k_replay, so the job list is cut into slices that
@@ -433,6 +441,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		}
 	}
 	const size_t o_jobs = A.alloc(sizeof(CtxJob) * std::max(1u, NJ)), o_chains = A.alloc(sizeof(RcChain) * std::max(1u, NJ));
+	const size_t o_fin = A.alloc(sizeof(RcFin) * std::max(1u, NJ));
 	if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (phase 3b): batch needs > %zu bytes of HBM scratch", A.top);
 	CtxJob* d_jobs = AP<CtxJob>(h, o_jobs); RcChain* d_chains = AP<RcChain>(h, o_chains);
 
@@ -531,10 +540,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		for (size_t sl = 0; sl + 1 < slice_lo.size(); ++sl)
 		{
 			const u32 s_lo = slice_lo[sl], s_hi = slice_lo[sl + 1];
-			const u32 q_lo = std::min(s_lo, nq), q_hi = std::min(s_hi, nq), d_lo = std::max(s_lo, nq), d_hi = std::max(s_hi, nq);
-			if (q_hi > q_lo) { const u32 gx = std::max(1u, std::min(32u, (maxq + WG * 8 - 1) / (WG * 8))); hipLaunchKernelGGL(k_ctx_qua, dim3(gx, q_hi - q_lo), dim3(WG), 0, s, d_jobs + q_lo, d_q, d_qp, lpool, d_state); KCHK(); }
-			if (d_hi > d_lo) { const u32 gx = std::max(1u, std::min(32u, (maxd + WG * 8 - 1) / (WG * 8))); hipLaunchKernelGGL(k_ctx_dna, dim3(gx, d_hi - d_lo), dim3(WG), 0, s, d_jobs + d_lo, d_d, lpool, d_state); KCHK(); }
-			hipLaunchKernelGGL(k_sort, dim3(s_hi - s_lo), dim3(WG), 0, s, d_jobs + s_lo, lpool); KCHK();
+			hipLaunchKernelGGL(k_sort, dim3(s_hi - s_lo), dim3(WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state); KCHK();
 			for (u32 lo = s_lo; lo < s_hi;)
 			{
 				u32 hi = lo;
@@ -562,8 +568,8 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		HIPCHK(hipEventRecord(h->ev[4], s));
 		HIPCHK(hipStreamWaitEvent(h->rc_stream, h->ev[4], 0));
 		HIPCHK(hipEventRecord(h->ev[2], h->rc_stream));
-		if (!getenv("DSRC_GPU_EXP_SKIP_RC"))     // timing experiments on the front end only (output is then meaningless)
-			hipLaunchKernelGGL(k_rc, dim3((NJ + 63) / 64), dim3(64), 0, h->rc_stream, d_chains, NJ, AP<RcRec>(h, 0), wpool, d_state); KCHK();
+		hipLaunchKernelGGL(k_rc, dim3((NJ + 63) / 64), dim3(64), 0, h->rc_stream, d_chains, NJ, AP<RcRec>(h, 0), AP<RcFin>(h, o_fin), d_state); KCHK();
+		hipLaunchKernelGGL(k_rc_emit, dim3(NJ), dim3(RC_EMIT_WG), 0, h->rc_stream, d_chains, AP<RcRec>(h, 0), AP<RcFin>(h, o_fin), wpool, d_state); KCHK();
 		HIPCHK(hipEventRecord(h->ev[3], h->rc_stream));
 		HIPCHK(hipStreamWaitEvent(s, h->ev[3], 0));
 		h->rc_launches = 1;

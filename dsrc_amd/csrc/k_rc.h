@@ -7,8 +7,8 @@
 // The reference walks one 3.3 M-symbol chain per stream: table row -> (freq, cum, total) ->
 // range update.  Context ids depend on the INPUT symbols only, never on coder state, so the
 // chain is cut in three data-parallel stages and one short serial one:
-//   k_ctx_*   : context id of every symbol (pure function of <= order+2 previous symbols)
-//   k_sort    : stable LSD radix sort of (ctx, sym, t) by ctx -> each context's history is contiguous
+//   k_sort    : context id of every symbol (pure function of <= order+2 previous symbols), computed on the fly by
+//               the first pass of a stable LSD radix sort of (ctx, sym, t) by ctx -> each context's history is contiguous
 //   k_replay  : one lane replays one context's history on a private counter row in LDS and
 //               emits (total, cum, freq) for every symbol, scattered back to stream order
 //   k_rc      : the integer range-coder recurrence, one LANE per stream (64 streams per wave); each
@@ -48,88 +48,120 @@ struct CtxJob     // one (block, stream)
 	u32 pad0;
 };
 
+typedef u64 __attribute__((aligned(1))) u64_unaligned;
+
 // ---- DNA context: hash of the previous `order` symbols, carried across records --------------
-__global__ void __launch_bounds__(WG) k_ctx_dna(const CtxJob* jobs, const u8* d_stream, u64* pool, BlkState* st)
+// (TDnaRCOrderModeler::UpdateHash, src/DnaModelerRCO.h:121-131).  Element of symbol t:
+// ctx << 40 | sym << 32 | t.  Symbols before the start of the stream do not enter the hash.
+__device__ __forceinline__ u64 ctx_elem_dna(const CtxJob& j, const u8* s, u32 t, bool* bad)
 {
-	const CtxJob j = jobs[blockIdx.y];
-	const u8* s = d_stream + j.src_off;
-	u64* e = pool + j.elems;
-	const u32 ab = j.alpha_bits, n_alpha = 1u << ab;
-	const u64 mask = (1ull << (ab * j.order)) - 1ull;
-	bool bad = false;
-	for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < j.n; t += gridDim.x * blockDim.x)
-	{
-		u64 h = 0;
-		const u32 k0 = t < j.order ? t : j.order;
-		for (u32 k = k0; k >= 1; --k) h = (h << ab) | s[t - k];
-		h &= mask;
-		const u32 sym = s[t];
-		if (sym >= n_alpha) bad = true;                     // reference UB
-		e[t] = (h << ELEM_CTX_SHIFT) | ((u64)(sym & (n_alpha - 1)) << ELEM_SYM_SHIFT) | t;
+	const u32 ab = j.alpha_bits, n_alpha = 1u << ab, order = j.order;
+	u64 h = 0; u32 sym;
+	if (t >= 15 && order <= 15)
+	{	// s[t-15 .. t] in two unaligned 8-byte loads
+		const u64 lo = *(const u64_unaligned*)(s + t - 15), hi = *(const u64_unaligned*)(s + t - 7);
+		sym = (u32)(hi >> 56);
+		for (u32 k = order; k >= 1; --k)
+		{
+			const u32 v = k <= 7 ? (u32)(hi >> (8 * (7 - k))) & 0xFFu : (u32)(lo >> (8 * (15 - k))) & 0xFFu;
+			h = (h << ab) | v;
+		}
 	}
-	if (bad) atomicOr(&st[j.blk].err, (u32)DSRC_ERR_REF_UB);
+	else
+	{
+		const u32 k0 = t < order ? t : order;
+		for (u32 k = k0; k >= 1; --k) h = (h << ab) | s[t - k];
+		sym = s[t];
+	}
+	h &= (1ull << (ab * order)) - 1ull;
+	if (sym >= n_alpha) *bad = true;                        // reference UB
+	return (h << ELEM_CTX_SHIFT) | ((u64)(sym & (n_alpha - 1)) << ELEM_SYM_SHIFT) | t;
 }
 
 // ---- quality context (TQualityModelBase::UpdateHash, src/QualityEncoder.h:77-94) -------------
 // Before coding symbol t the hash slots are: k < order/2 : raw s[t-1-k];
 // k >= order/2 : floor((s[t-1-k] + s[t-2-k]) / 2)  (order 1: slot 0 is raw).  Symbols before the
 // start of the block read as 0.  ctx = (slots << alpha_bits) | position_context.
-__global__ void __launch_bounds__(WG) k_ctx_qua(const CtxJob* jobs, const u8* q_stream, const u8* qp_stream, u64* pool, const BlkState* st)
+// rank: 256-entry LDS table (dense rank of a raw quality value, or identity for the lossy model).
+__device__ __forceinline__ u64 ctx_elem_qua(const CtxJob& j, const u8* s, const u8* qp, const u8* rank, u32 t)
 {
-	__shared__ u8 s_rank[256];
-	const CtxJob j = jobs[blockIdx.y];
-	for (u32 i = threadIdx.x; i < 256; i += blockDim.x) s_rank[i] = j.translate ? st[j.blk].q_sym[i] : (u8)i;
-	__syncthreads();
-	const u8* s = q_stream + j.src_off;
-	const u8* qp = qp_stream + j.src_off;
-	u64* e = pool + j.elems;
-	const u32 ab = j.alpha_bits, half = j.order / 2;
-	for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < j.n; t += gridDim.x * blockDim.x)
+	const u32 ab = j.alpha_bits, order = j.order, half = order / 2;
+	u32 v[8];                                               // v[k] = rank of s[t-1-k], k <= order (<= 6)
+	u32 cur;
+	if (t >= 7)
 	{
-		u32 v[8];                                           // v[k] = rank of s[t-1-k], k <= order (<= 6) + 1
-		for (u32 k = 0; k <= j.order; ++k) v[k] = (t >= k + 1) ? s_rank[s[t - 1 - k]] : 0;
-		u64 h = 0;
-		for (u32 k = j.order; k >= 1; --k)
-		{
-			const u32 slot = k - 1;
-			const u32 x = (slot < half || j.order == 1) ? v[slot] : ((v[slot] + v[slot + 1]) >> 1);
-			h = (h << ab) | x;
-		}
-		const u32 pctx = qp[t] >> j.rescale_shift;
-		const u64 ctx = (h << ab) | pctx;
-		const u32 sym = s_rank[s[t]] & ((1u << ab) - 1u);
-		e[t] = (ctx << ELEM_CTX_SHIFT) | ((u64)sym << ELEM_SYM_SHIFT) | t;
+		const u64 w = *(const u64_unaligned*)(s + t - 7);     // s[t-7 .. t]
+		cur = (u32)(w >> 56);
+#pragma unroll
+		for (u32 k = 0; k < 7; ++k) v[k] = k <= order ? rank[(u32)(w >> (8 * (6 - k))) & 0xFFu] : 0;
 	}
+	else
+	{
+		cur = s[t];
+#pragma unroll
+		for (u32 k = 0; k < 7; ++k) v[k] = (k <= order && t >= k + 1) ? rank[s[t - 1 - k]] : 0;
+	}
+	v[7] = 0;
+	u64 h = 0;
+	for (u32 k = order; k >= 1; --k)
+	{
+		const u32 slot = k - 1;
+		const u32 x = (slot < half || order == 1) ? v[slot] : ((v[slot] + v[slot + 1]) >> 1);
+		h = (h << ab) | x;
+	}
+	const u32 pctx = qp[t] >> j.rescale_shift;
+	const u64 ctx = (h << ab) | pctx;
+	const u32 sym = rank[cur] & ((1u << ab) - 1u);
+	return (ctx << ELEM_CTX_SHIFT) | ((u64)sym << ELEM_SYM_SHIFT) | t;
 }
 
 // ---- stable LSD radix sort by ctx; one workgroup owns one stream ------------------------------
-// Per pass: LDS histogram -> exclusive scan -> tiles of WG*SORT_ITEMS elements.  A wave owns a contiguous
+// Pass 0 computes the elements from the symbol stream on the fly (no context array is ever written); every pass
+// builds the histogram of the NEXT digit while it scatters, so a pass reads its input exactly once.
+// Per pass: exclusive scan of the digit histogram -> tiles of WG*SORT_ITEMS elements.  A wave owns a contiguous
 // run of 64*SORT_ITEMS elements of the tile and walks it 64 at a time: equal-digit lanes are found with one
 // ballot per digit bit, the wave's private counter row in LDS gives the running rank, and a per-digit
 // scan over the waves turns the rows into global offsets once per tile.
-#define SORT_MAX_BINS 1024
+#define SORT_MAX_BINS 512
+#define SORT_DIGIT_BITS 9
 #define SORT_ITEMS 8
-__global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool)
+__global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool, const u8* d_stream, const u8* q_stream, const u8* qp_stream, BlkState* st)
 {
 	__shared__ u32 s_base[SORT_MAX_BINS];
+	__shared__ u32 s_next[SORT_MAX_BINS];
 	__shared__ u32 s_cnt[WAVES][SORT_MAX_BINS];
 	__shared__ u32 s_off[WAVES][SORT_MAX_BINS];
+	__shared__ u8 s_rank[256];
 	const CtxJob j = jobs[blockIdx.x];
 	const u32 n = j.n, bins = 1u << j.dbits;
 	const u32 wv = wave_id(), nw = blockDim.x >> 6, lane = lane_id();
 	const u32 tile_elems = blockDim.x * SORT_ITEMS;
+	const u8* sym_src = (j.is_dna ? d_stream : q_stream) + j.src_off;
+	const u8* qp = qp_stream + j.src_off;
+
+	for (u32 i = threadIdx.x; i < 256; i += blockDim.x) s_rank[i] = (!j.is_dna && j.translate) ? st[j.blk].q_sym[i] : (u8)i;
+	for (u32 i = threadIdx.x; i < bins; i += blockDim.x) s_base[i] = 0;
+	__syncthreads();
+	{	// histogram of digit 0
+		bool bad = false;
+		for (u32 i = threadIdx.x; i < n; i += blockDim.x)
+		{
+			const u64 e = j.is_dna ? ctx_elem_dna(j, sym_src, i, &bad) : ctx_elem_qua(j, sym_src, qp, s_rank, i);
+			atomicAdd(&s_base[(u32)(e >> ELEM_CTX_SHIFT) & (bins - 1)], 1u);
+		}
+		if (bad) atomicOr(&st[j.blk].err, (u32)DSRC_ERR_REF_UB);
+	}
+	__syncthreads();
 
 	for (u32 pass = 0; pass < j.passes; ++pass)
 	{
-		const u64* src = pool + ((pass & 1) ? j.elems_b : j.elems);
-		u64* dst = pool + ((pass & 1) ? j.elems : j.elems_b);
+		// sources/destinations alternate so that the last pass lands in the buffer k_replay reads (sorted_in_b)
+		const bool to_b = ((j.passes - 1 - pass) & 1u) ? !j.sorted_in_b : (bool)j.sorted_in_b;
+		const u64* src = pool + (to_b ? j.elems : j.elems_b);
+		u64* dst = pool + (to_b ? j.elems_b : j.elems);
 		const u32 shift = ELEM_CTX_SHIFT + pass * j.dbits;
+		const bool more = pass + 1 < j.passes;
 
-		for (u32 i = threadIdx.x; i < bins; i += blockDim.x) s_base[i] = 0;
-		for (u32 i = threadIdx.x; i < WAVES * SORT_MAX_BINS; i += blockDim.x) (&s_cnt[0][0])[i] = 0;
-		__syncthreads();
-		for (u32 i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&s_base[(u32)(src[i] >> shift) & (bins - 1)], 1u);
-		__syncthreads();
 		{	// exclusive scan of the histogram
 			u32 carry = 0;
 			for (u32 b0 = 0; b0 < bins; b0 += blockDim.x)
@@ -142,18 +174,27 @@ __global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool)
 				carry += tot;
 			}
 		}
+		for (u32 i = threadIdx.x; i < bins; i += blockDim.x) s_next[i] = 0;
+		for (u32 i = threadIdx.x; i < WAVES * SORT_MAX_BINS; i += blockDim.x) (&s_cnt[0][0])[i] = 0;
 		__syncthreads();
 
 		for (u32 tile = 0; tile < n; tile += tile_elems)
 		{
 			u64 el[SORT_ITEMS]; u32 rk[SORT_ITEMS];
 			const u32 wbase = tile + wv * 64 * SORT_ITEMS;
+			bool bad = false;
+#pragma unroll
+			for (u32 k = 0; k < SORT_ITEMS; ++k)
+			{
+				const u32 i = wbase + k * 64 + lane;
+				el[k] = 0;
+				if (i < n) el[k] = pass ? src[i] : (j.is_dna ? ctx_elem_dna(j, sym_src, i, &bad) : ctx_elem_qua(j, sym_src, qp, s_rank, i));
+			}
 #pragma unroll
 			for (u32 k = 0; k < SORT_ITEMS; ++k)
 			{
 				const u32 i = wbase + k * 64 + lane;
 				const bool valid = i < n;
-				el[k] = valid ? src[i] : 0;
 				const u32 d = (u32)(el[k] >> shift) & (bins - 1);
 				u64 peers = __ballot(valid);
 				for (u32 b = 0; b < j.dbits; ++b)
@@ -185,10 +226,16 @@ __global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool)
 			for (u32 k = 0; k < SORT_ITEMS; ++k)
 			{
 				const u32 i = wbase + k * 64 + lane;
-				if (i < n) dst[s_off[wv][(u32)(el[k] >> shift) & (bins - 1)] + rk[k]] = el[k];
+				if (i < n)
+				{
+					dst[s_off[wv][(u32)(el[k] >> shift) & (bins - 1)] + rk[k]] = el[k];
+					if (more) atomicAdd(&s_next[(u32)(el[k] >> (shift + j.dbits)) & (bins - 1)], 1u);
+				}
 			}
 			__syncthreads();
 		}
+		for (u32 i = threadIdx.x; i < bins; i += blockDim.x) s_base[i] = s_next[i];
+		__syncthreads();
 	}
 }
 
@@ -368,16 +415,19 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 
 // ---- range coder: one lane = one stream ---------------------------------------------------------
 // The only serial part of the path.  Per symbol the dependent chain is
-//   range -> floor(range / total) -> * freq -> renormalise
-// and on the GPU its cost is instruction issue, so the step is kept to ~25 straight-line instructions:
+//   range -> floor(range / total) -> * freq -> renormalise          low -> low + r*cum -> renormalise
+// and on the GPU its cost is instruction issue, so the serial kernel (k_rc) does the arithmetic and nothing
+// else:
 //   * floor(range/total) is a multiply by the 48-bit reciprocal k_replay stored (exact, see rc_div);
 //   * a wave owns 64 chains whose records lie in 64 different arrays.  Per 64 symbols it issues one LDS-DMA
 //     load per chain (global_load_lds_dwordx4 on 48 lanes = 768 contiguous bytes = 64 records of ONE chain,
 //     landing in that chain's LDS row) for the chunk after the current one, so every global access is a full
 //     coalesced row and the coder runs 64-128 symbols (6-12 us) behind its loads; lane c then reads row c,
 //     16 records at a time, with ds_read_b128 into ping-pong registers;
-//   * the renormalisation count comes from clz; bytes leaving the coder collect in a register and are
-//     stored four at a time;
+//   * the bytes a symbol pushes out of the coder are NOT packed serially: the step leaves one 32-bit code per
+//     symbol -- the top three bytes of `low` and how many of them (0..2) leave -- written over the record array
+//     (code t at byte 4t is always behind the records still to be read), and k_rc_emit, a data-parallel kernel,
+//     prefix-sums the byte counts and stores the bytes;
 //   * RangeEncoder::EncodeFrequency's carry clamp (src/RangeCoder.h:64-74) needs bits 24..39 of `low` to be
 //     all ones; that is accumulated branch-free and checked once per 16 symbols -- if it ever shows, the
 //     group is replayed from a snapshot with the reference's loop, verbatim.
@@ -388,13 +438,18 @@ struct RcChain
 	u32 n;
 	u32 out_byte0, out_cap;
 	u32 blk, is_dna;
-	u32 pad0;
+	u32 force_exact;   // tests: take the reference-loop path for every group (same bytes by construction)
 };
+
+// what k_rc leaves for k_rc_emit besides the per-symbol codes: the bytes of the last (n mod 16) symbols
+// followed by the 8 bytes of RangeEncoder::End
+struct RcFin { u32 n; u8 b[60]; };
 
 #define RC_GROUP 16                    // symbols per register group / clamp check
 #define RC_CHUNK 64                    // symbols per chain per LDS chunk (768 B = 48 lanes x 16 B)
 #define RC_ROW_U4 49                   // LDS row pitch in 16-byte units: 48 of data + 1 so that a 16-lane ds_read_b128 pass covers all 64 banks
 #define RC_OVERREAD (3 * RC_CHUNK)     // records the DMA may touch past the longest chain of a wave (arena slack)
+#define RC_XB 64                       // per-lane byte buffer of the exact path (LDS)
 
 struct alignas(16) U4 { u32 x, y, z, w; };
 
@@ -406,36 +461,25 @@ __device__ __forceinline__ u32 rc_div(u32 range, u32 m_lo, u32 m_hi)
 	return (u32)(((u64)range * m_hi + t) >> 16);
 }
 
-struct RcState { u64 low; u32 range; u64 acc; u32 nbits; u32 pos; };   // acc holds nbits/8 pending output bytes
+struct RcState { u64 low; u32 range; };
 
-typedef u32 __attribute__((aligned(1))) u32_unaligned;
-
-__device__ __forceinline__ void rc_flush4(RcState& s, u8* out)
-{
-	const u32 w = (u32)(s.acc >> (s.nbits - 32));                          // oldest four pending bytes, first byte in the MSB
-	*(u32_unaligned*)(out + s.pos) = ((w >> 24) & 0xFFu) | ((w >> 8) & 0xFF00u) | ((w << 8) & 0xFF0000u) | (w << 24);
-	s.pos += 4; s.nbits -= 32;
-}
-
-// fast step; returns non-zero if the clamp pre-condition was seen
-__device__ __forceinline__ u32 rc_step_fast(RcState& s, u8* out, const RcRec& e)
+// fast step: returns the symbol's code = top three bytes of low << 2 | bytes leaving (0..2: range' >= 2^8 because
+// range >= 2^24 and total <= 2^16); `flag` collects the clamp pre-condition
+__device__ __forceinline__ u32 rc_step_fast(RcState& s, const RcRec& e, u32& flag)
 {
 	const u32 f = e.w_lo & 0xFFFFu;
 	const u32 r = rc_div(s.range, (e.w_lo >> 16) | (e.w_hi << 16), e.w_hi >> 16);
 	const u64 low = s.low + (u64)r * e.cum;                                // r*cum <= range < 2^32: identical to the reference's 32-bit product
 	const u32 range = r * f;
-	const u32 k8 = ((u32)__builtin_clz(range) >> 3) << 3;                    // 8 * bytes leaving the coder (0..24); range != 0
-	const u32 flag = (((u32)(low >> 24) & 0xFFFFu) == 0xFFFFu) ? 1u : 0u;
-	s.acc = (s.acc << k8) | (u32)((low >> 8) >> (56 - k8));
-	s.nbits += k8;
-	s.low = low << k8;
-	s.range = range << k8;
-	if (s.nbits >= 32) rc_flush4(s, out);
-	return flag;
+	const u32 kb = (u32)__builtin_clz(range) >> 3;
+	flag |= (((u32)(low >> 24) & 0xFFFFu) == 0xFFFFu) ? 1u : 0u;
+	s.low = low << (8 * kb);
+	s.range = range << (8 * kb);
+	return ((u32)(low >> 40) << 2) | kb;
 }
 
-// exact step: RangeEncoder::EncodeFrequency, verbatim, on the same output state
-__device__ inline void rc_step_exact(RcState& s, u8* out, const RcRec& e)
+// exact step: RangeEncoder::EncodeFrequency, verbatim; bytes go to the lane's LDS buffer
+__device__ inline void rc_step_exact(RcState& s, const RcRec& e, u8* xb, u32& nb)
 {
 	const u32 f = e.w_lo & 0xFFFFu;
 	const u32 r = rc_div(s.range, (e.w_lo >> 16) | (e.w_hi << 16), e.w_hi >> 16);
@@ -444,8 +488,8 @@ __device__ inline void rc_step_exact(RcState& s, u8* out, const RcRec& e)
 	while (range <= 0x00FFFFFFu)
 	{
 		if ((low ^ (low + range)) & 0xFF00000000000000ull) { const u32 rr = (u32)low; range = (rr | 0x00FFFFFFu) - rr; }
-		s.acc = (s.acc << 8) | (low >> 56); s.nbits += 8;
-		if (s.nbits >= 32) rc_flush4(s, out);
+		if (nb < RC_XB) xb[nb] = (u8)(low >> 56);
+		++nb;
 		low <<= 8; range <<= 8;
 	}
 	s.low = low; s.range = range;
@@ -461,22 +505,37 @@ __device__ __forceinline__ RcRec rc_rec(const RcRegs& g, u32 i)
 	return e;
 }
 
-// `row` = the chain's LDS row the group was read from (still intact while the group is coded)
-__device__ __forceinline__ void rc_group(RcState& s, u8* out, const RcRegs& g, const U4* row, u32 grp)
+// codes of one group -> codes[0..15].  `row` = the chain's LDS row the group was read from (still intact).
+__device__ __forceinline__ void rc_group(RcState& s, u32* codes, const RcRegs& g, const U4* row, u32 grp, u8* xb, u32* err, u32 force_exact)
 {
 	const RcState snap = s;
-	u32 bad = 0;
+	u32 bad = force_exact;
+	u32 c[RC_GROUP];
 #pragma unroll
-	for (u32 i = 0; i < RC_GROUP; ++i) bad |= rc_step_fast(s, out, rc_rec(g, i));
+	for (u32 i = 0; i < RC_GROUP; ++i) c[i] = rc_step_fast(s, rc_rec(g, i), bad);
 	if (bad)
-	{
+	{	// the reference's loop on the same 16 records; its bytes are dealt out three per code slot, in order
 		s = snap;
 		const u32* d = (const u32*)row + 3 * RC_GROUP * grp;
+		u32 nb = 0;
 		for (u32 i = 0; i < RC_GROUP; ++i)
 		{
 			RcRec e; e.w_lo = d[3 * i]; e.w_hi = d[3 * i + 1]; e.cum = d[3 * i + 2];
-			rc_step_exact(s, out, e);
+			rc_step_exact(s, e, xb, nb);
 		}
+		if (nb > 3 * RC_GROUP) atomicOr(err, (u32)DSRC_ERR_OUT_OVERFLOW);
+#pragma unroll
+		for (u32 i = 0; i < RC_GROUP; ++i)
+		{
+			const u32 have = nb > 3 * i ? nb - 3 * i : 0u, take = have < 3 ? have : 3u;
+			c[i] = ((((u32)xb[3 * i] << 16) | ((u32)xb[3 * i + 1] << 8) | (u32)xb[3 * i + 2]) << 2) | take;
+		}
+	}
+#pragma unroll
+	for (u32 i = 0; i < RC_GROUP / 4; ++i)
+	{
+		U4 v; v.x = c[4 * i]; v.y = c[4 * i + 1]; v.z = c[4 * i + 2]; v.w = c[4 * i + 3];
+		((U4*)codes)[i] = v;
 	}
 }
 
@@ -487,79 +546,151 @@ __device__ __forceinline__ void rc_load_group(RcRegs& g, const U4* row, u32 grp)
 }
 
 // LDS-DMA requests for chains [J0, J1) of the wave: lanes 0..47 fetch the 48 x 16 bytes (= 64 records) of chain j
-// that start at byte `byte_off` of its array into row j
+// that start at byte `byte_off` of its array into row j.  Chain j's array starts src_off[j] bytes after `base`
+// (wave-uniform), so the request is one scalar base + one 32-bit lane offset.
 template <int J0, int J1>
-__device__ __forceinline__ void rc_dma(U4* buf, u32 src_lo, u32 src_hi, u32 byte_off)
+__device__ __forceinline__ void rc_dma(U4* buf, const u8* base, u32 src_off, u32 byte_off)
 {
-	u64 base[J1 - J0];
+	u32 o[J1 - J0];
 #pragma unroll
-	for (int j = J0; j < J1; ++j)
-		base[j - J0] = ((u64)(u32)__builtin_amdgcn_readlane((int)src_hi, j) << 32) | (u32)__builtin_amdgcn_readlane((int)src_lo, j);
+	for (int j = J0; j < J1; ++j) o[j - J0] = (u32)__builtin_amdgcn_readlane((int)src_off, j);
 	if (threadIdx.x < 3 * RC_CHUNK / 4)
 	{
 #pragma unroll
-		for (int j = J0; j < J1; ++j) lds_dma16((const u8*)base[j - J0] + byte_off, buf + j * RC_ROW_U4);
+		for (int j = J0; j < J1; ++j) lds_dma16(base + (o[j - J0] + byte_off), buf + j * RC_ROW_U4);
 	}
 }
 
 // one 64-symbol chunk: the chain's records are in `cur` (landed), r0 holds its first group; requests the
 // chunk after it into `nxt` and leaves that chunk's first group in r0
-__device__ __forceinline__ void rc_chunk(RcState& s, u8* out, RcRegs& r0, RcRegs& r1, const U4* cur, U4* nxt, u32 t0, u32 n, u32 src_lo, u32 src_hi)
+__device__ __forceinline__ void rc_chunk(RcState& s, u32* codes, RcRegs& r0, RcRegs& r1, const U4* cur, U4* nxt, u32 t0, u32 n,
+										 const u8* base, u32 src_off, u8* xb, u32* err, u32 fx)
 {
 	const u32 lane = threadIdx.x;
 	const u32 off = (t0 + RC_CHUNK) * (u32)sizeof(RcRec) + lane * 16u;
 	const U4* row = cur + lane * RC_ROW_U4;
+	u32* c = codes + t0;
 	rc_load_group(r1, row, 1);
-	rc_dma<0, 22>(nxt, src_lo, src_hi, off);
-	if (t0 + 1 * RC_GROUP <= n) rc_group(s, out, r0, row, 0);
+	rc_dma<0, 22>(nxt, base, src_off, off);
+	if (t0 + 1 * RC_GROUP <= n) rc_group(s, c, r0, row, 0, xb, err, fx);
 	rc_load_group(r0, row, 2);
-	rc_dma<22, 43>(nxt, src_lo, src_hi, off);
-	if (t0 + 2 * RC_GROUP <= n) rc_group(s, out, r1, row, 1);
+	rc_dma<22, 43>(nxt, base, src_off, off);
+	if (t0 + 2 * RC_GROUP <= n) rc_group(s, c + RC_GROUP, r1, row, 1, xb, err, fx);
 	rc_load_group(r1, row, 3);
-	rc_dma<43, 64>(nxt, src_lo, src_hi, off);
-	if (t0 + 3 * RC_GROUP <= n) rc_group(s, out, r0, row, 2);
+	rc_dma<43, 64>(nxt, base, src_off, off);
+	if (t0 + 3 * RC_GROUP <= n) rc_group(s, c + 2 * RC_GROUP, r0, row, 2, xb, err, fx);
 	lds_dma_wait();                                                        // the requests above have landed before row 0 of `nxt` is read
 	rc_load_group(r0, nxt + lane * RC_ROW_U4, 0);
-	if (t0 + 4 * RC_GROUP <= n) rc_group(s, out, r1, row, 3);
+	if (t0 + 4 * RC_GROUP <= n) rc_group(s, c + 3 * RC_GROUP, r1, row, 3, xb, err, fx);
 }
 
-__global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, const RcRec* rec_pool, u32* word_pool, BlkState* st)
+__global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, RcRec* rec_pool, RcFin* fin, BlkState* st)
 {
 	__shared__ U4 s_a[64 * RC_ROW_U4];
 	__shared__ U4 s_b[64 * RC_ROW_U4];
+	__shared__ u8 s_xb[64 * RC_XB];
 	const u32 lane = threadIdx.x, id = blockIdx.x * 64 + lane;
 	const bool have = id < n_chains;
 	const RcChain c = chains[have ? id : n_chains - 1];                        // idle lanes shadow a real chain's addresses and code nothing
 	const u32 n = have ? c.n : 0;
-	const RcRec* p = rec_pool + c.trip;
-	u8* out = (u8*)(word_pool + c.out_words);
+	RcRec* p = rec_pool + c.trip;
+	u32* codes = (u32*)p;                                                      // code t overwrites bytes 4t..4t+3 of the chain's own array
+	u8* xb = s_xb + lane * RC_XB;
+	u32* err = &st[c.blk].err;
 	RcState s;
-	s.low = 0; s.range = 0xFFFFFFFFu; s.pos = c.out_byte0; s.acc = 0; s.nbits = 0;
+	s.low = 0; s.range = 0xFFFFFFFFu;
 
 	const u32 n_full = n & ~(u32)(RC_GROUP - 1);
 	const u32 wave_full = wave_max(n_full);
 	if (wave_full)
 	{
-		const u32 src_lo = (u32)(u64)p, src_hi = (u32)((u64)p >> 32);
+		// the 64 arrays of a wave lie within 4 GiB (checked on the host): scalar base + 32-bit offsets
+		const u64 first = __shfl((u64)p, 0);
+		const u8* base = (const u8*)first;
+		const u32 src_off = (u32)((u64)p - first);
 		RcRegs r0, r1;
-		rc_dma<0, 64>(s_a, src_lo, src_hi, lane * 16u);
+		rc_dma<0, 64>(s_a, base, src_off, lane * 16u);
 		lds_dma_wait();
 		rc_load_group(r0, s_a + lane * RC_ROW_U4, 0);
 		for (u32 t0 = 0; t0 < wave_full; t0 += 2 * RC_CHUNK)
 		{
-			rc_chunk(s, out, r0, r1, s_a, s_b, t0, n, src_lo, src_hi);
-			rc_chunk(s, out, r0, r1, s_b, s_a, t0 + RC_CHUNK, n, src_lo, src_hi);
+			rc_chunk(s, codes, r0, r1, s_a, s_b, t0, n, base, src_off, xb, err, c.force_exact);
+			rc_chunk(s, codes, r0, r1, s_b, s_a, t0 + RC_CHUNK, n, base, src_off, xb, err, c.force_exact);
 		}
 	}
-	for (u32 t = n_full; t < n; ++t) { const RcRec e = p[t]; rc_step_exact(s, out, e); }
 	if (!have) return;
+	// the last n mod 16 symbols and RangeEncoder::End
+	u32 nb = 0;
+	for (u32 t = n_full; t < n; ++t) { const RcRec e = p[t]; rc_step_exact(s, e, xb, nb); }
+	if (nb + 8 > sizeof(fin->b)) { atomicOr(err, (u32)DSRC_ERR_OUT_OVERFLOW); nb = 0; }
+	RcFin* F = &fin[id];
+	for (u32 k = 0; k < nb; ++k) F->b[k] = xb[k];
+	for (u32 k = 0; k < 8; ++k) { F->b[nb + k] = (u8)(s.low >> 56); s.low <<= 8; }
+	F->n = nb + 8;
+}
 
-	const u32 nb = s.nbits >> 3;
-	for (u32 k = 0; k < nb; ++k) out[s.pos + k] = (u8)(s.acc >> (8 * (nb - 1 - k)));
-	s.pos += nb;
-	for (u32 k = 0; k < 8; ++k) { out[s.pos++] = (u8)(s.low >> 56); s.low <<= 8; }      // RangeEncoder::End
-	if (c.is_dna) st[c.blk].dna_bytes = s.pos; else st[c.blk].qua_bytes = s.pos;
-	if (s.pos > c.out_byte0 + c.out_cap) atomicOr(&st[c.blk].err, (u32)DSRC_ERR_OUT_OVERFLOW);
+// ---- byte emitter: codes -> stream bytes (data-parallel) ------------------------------------------
+// One workgroup per chain: every thread takes 8 consecutive codes, a workgroup scan of the byte counts gives
+// each code its position, the bytes are stored; then the tail left in RcFin.  Sets the stream size.
+#define RC_EMIT_WG 256
+#define RC_EMIT_ITEMS 8
+__global__ void __launch_bounds__(RC_EMIT_WG) k_rc_emit(const RcChain* chains, const RcRec* rec_pool, const RcFin* fin, u32* word_pool, BlkState* st)
+{
+	__shared__ u32 s_w[RC_EMIT_WG / 64];
+	const RcChain c = chains[blockIdx.x];
+	const u32* codes = (const u32*)(rec_pool + c.trip);
+	u8* out = (u8*)(word_pool + c.out_words);
+	const u32 n_codes = c.n & ~(u32)(RC_GROUP - 1);
+	const u32 limit = c.out_byte0 + c.out_cap;
+	u32 pos = c.out_byte0;                                  // workgroup-uniform running position
+	bool over = false;
+	for (u32 tile = 0; tile < n_codes; tile += RC_EMIT_WG * RC_EMIT_ITEMS)
+	{
+		const u32 t0 = tile + threadIdx.x * RC_EMIT_ITEMS;
+		u32 cd[RC_EMIT_ITEMS]; u32 mine = 0;
+		if (t0 < n_codes)                                   // n_codes and t0 are multiples of 8: whole 32-byte pieces
+		{
+			const U4 a = ((const U4*)(codes + t0))[0], b = ((const U4*)(codes + t0))[1];
+			cd[0] = a.x; cd[1] = a.y; cd[2] = a.z; cd[3] = a.w; cd[4] = b.x; cd[5] = b.y; cd[6] = b.z; cd[7] = b.w;
+#pragma unroll
+			for (u32 k = 0; k < RC_EMIT_ITEMS; ++k) mine += cd[k] & 3u;
+		}
+		else
+		{
+#pragma unroll
+			for (u32 k = 0; k < RC_EMIT_ITEMS; ++k) cd[k] = 0;
+		}
+		const u32 inc = wave_incl_scan(mine);
+		if (lane_id() == 63) s_w[wave_id()] = inc;
+		__syncthreads();
+		u32 wbase = 0, total = 0;
+		for (u32 w = 0; w < RC_EMIT_WG / 64; ++w) { const u32 x = s_w[w]; if (w < wave_id()) wbase += x; total += x; }
+		__syncthreads();
+		u32 at = pos + wbase + inc - mine;
+		if (at + mine > limit) over = true;
+		else
+		{
+#pragma unroll
+			for (u32 k = 0; k < RC_EMIT_ITEMS; ++k)
+			{
+				const u32 kb = cd[k] & 3u, v = cd[k] >> 2;
+				if (kb >= 1) out[at] = (u8)(v >> 16);
+				if (kb >= 2) out[at + 1] = (u8)(v >> 8);
+				if (kb >= 3) out[at + 2] = (u8)v;
+				at += kb;
+			}
+		}
+		pos += total;
+	}
+	if (threadIdx.x == 0)
+	{
+		const RcFin* F = &fin[blockIdx.x];
+		if (pos + F->n > limit) over = true;
+		else for (u32 k = 0; k < F->n; ++k) out[pos + k] = F->b[k];
+		pos += F->n;
+		if (c.is_dna) st[c.blk].dna_bytes = pos; else st[c.blk].qua_bytes = pos;
+	}
+	if (over) atomicOr(&st[c.blk].err, (u32)DSRC_ERR_OUT_OVERFLOW);
 }
 
 // ---- stream prologues ---------------------------------------------------------------------------

@@ -112,6 +112,16 @@ def test_hot_contexts_rescale(emu, oracle):
         assert run(emu, cfg, data) == oracle.compress_block(cfg, data)
 
 
+def test_range_coder_reference_loop_path(emu, oracle, monkeypatch):
+    """The carry-clamp fallback of k_rc (reference loop + byte re-dealing) must give the same stream as the fast
+    path; DSRC_GPU_FORCE_EXACT_RC sends every 16-symbol group through it."""
+    monkeypatch.setenv("DSRC_GPU_FORCE_EXACT_RC", "1")
+    data = synth.illumina_fastq(300)[:-1]
+    for d, q, lossy in [(3, 2, False), (2, 1, True)]:
+        cfg = Config.from_levels(d, q, lossy)
+        assert run(emu, cfg, data) == oracle.compress_block(cfg, data)
+
+
 def test_device_synth_matches_host(emu):
     h = emu.Handle()
     cap = 1 << 20

@@ -105,6 +105,15 @@ def test_hot_contexts_rescale(gpu, oracle):
         _check(gpu, oracle, Config.from_levels(d, q, lossy), [data])
 
 
+def test_range_coder_reference_loop_path(gpu, oracle, monkeypatch):
+    """The carry-clamp fallback of k_rc (reference loop + byte re-dealing) must give the same stream as the fast
+    path; DSRC_GPU_FORCE_EXACT_RC sends every 16-symbol group through it."""
+    monkeypatch.setenv("DSRC_GPU_FORCE_EXACT_RC", "1")
+    chunks = [synth.illumina_fastq(20000, first=1 + 20000 * k)[:-1] for k in range(3)]
+    for d, q, lossy in [(3, 2, False), (2, 1, True)]:
+        _check(gpu, oracle, Config.from_levels(d, q, lossy), chunks)
+
+
 def test_device_synth_matches_host(gpu):
     h = gpu.Handle()
     cap = 2 << 20
