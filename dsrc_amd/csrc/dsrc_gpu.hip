@@ -388,13 +388,24 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	std::vector<RcChain> chains(NJ);
 	{
 		// records of one chain are contiguous: k_replay scatters inside one chain's 12 B x n array (a few chains in
-		// flight stay within the memory-side cache) and k_rc streams it through LDS.  Chains start on 48-byte
-		// boundaries; k_rc's DMA may read RC_OVERREAD records past the longest chain of its wave.
+		// flight stay within the memory-side cache) and k_rc streams it through LDS.  The 64 chains of a k_rc wave
+		// are one pitch apart (a multiple of 4 records: rows stay 16-byte aligned); k_rc's DMA may read RC_OVERREAD
+		// records past the longest chain of its wave.
 		const u32 force_exact = getenv("DSRC_GPU_FORCE_EXACT_RC") ? 1u : 0u;             // tests only (read per batch)
-		size_t trip_words = 0; u32 mxn = 0;
-		std::vector<size_t> cbase(NJ + 1, 0);
-		for (u32 i = 0; i < NJ; ++i) { cbase[i] = trip_words; trip_words += ((size_t)jobs[i].n + 3) / 4 * 4; mxn = std::max(mxn, jobs[i].n); }
-		const size_t o_trip = A.alloc((trip_words + mxn + RC_OVERREAD) * sizeof(RcRec) + 256);
+		size_t trip_words = 0;
+		std::vector<size_t> cbase(NJ + 1, 0); std::vector<u32> cpitch(NJ + 1, 0);
+		for (u32 g = 0; g < NJ; g += 64)
+		{
+			const u32 hi = std::min(NJ, g + 64);
+			u32 mx = 0; for (u32 i = g; i < hi; ++i) mx = std::max(mx, jobs[i].n);
+			const u32 pitch = (mx + 3) / 4 * 4 + 4;
+			if ((u64)pitch * 64 * sizeof(RcRec) >= (1ull << 32))
+				return fail(h, DSRCGPU_E_ARG, "chunks too large for the range-coder stage (64 streams exceed 4 GiB of records); use a smaller buffer size");
+			for (u32 i = g; i < hi; ++i) { cbase[i] = trip_words + (size_t)(i - g) * pitch; cpitch[i] = pitch; }
+			trip_words += (size_t)pitch * (hi - g);
+			if (hi == NJ) trip_words += pitch + RC_OVERREAD;               // over-read slack behind the last array
+		}
+		const size_t o_trip = A.alloc(trip_words * sizeof(RcRec) + 256);
 		const size_t trip0 = (o_trip + 47) / 48 * 4;
 		for (u32 i = 0; i < NJ; ++i)
 		{
@@ -405,13 +416,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			j.trip = trip0 + cbase[i];
 			RcChain& c = chains[i];
 			c.trip = j.trip; c.out_words = j.out_words; c.n = j.n; c.out_byte0 = j.out_byte0; c.out_cap = j.out_cap; c.blk = j.blk; c.is_dna = j.is_dna;
-			c.force_exact = force_exact;
-		}
-		for (u32 i = 0; i < NJ; i += 64)
-		{	// k_rc addresses the 64 arrays of a wave as one base + 32-bit byte offsets
-			const u32 last = std::min(NJ, i + 64) - 1;
-			if ((cbase[last] - cbase[i] + jobs[last].n + mxn + RC_OVERREAD) * sizeof(RcRec) >= (1ull << 32))
-				return fail(h, DSRCGPU_E_ARG, "chunks too large for the range-coder stage (64 streams exceed 4 GiB of records); use a smaller buffer size");
+			c.force_exact = force_exact; c.pitch = cpitch[i]; c.pad0 = 0;
 		}
 	}
 	// The ping-pong sort buffers are only alive from k_ctx to k_replay, so the job list is cut into slices that
@@ -568,7 +573,8 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		HIPCHK(hipEventRecord(h->ev[4], s));
 		HIPCHK(hipStreamWaitEvent(h->rc_stream, h->ev[4], 0));
 		HIPCHK(hipEventRecord(h->ev[2], h->rc_stream));
-		hipLaunchKernelGGL(k_rc, dim3((NJ + 63) / 64), dim3(64), 0, h->rc_stream, d_chains, NJ, AP<RcRec>(h, 0), AP<RcFin>(h, o_fin), d_state); KCHK();
+		if (NJ / 64) { hipLaunchKernelGGL(k_rc<true>, dim3(NJ / 64), dim3(64), 0, h->rc_stream, d_chains, 0u, NJ, AP<RcRec>(h, 0), AP<RcFin>(h, o_fin), d_state); KCHK(); }
+		if (NJ % 64) { hipLaunchKernelGGL(k_rc<false>, dim3(1), dim3(64), 0, h->rc_stream, d_chains, NJ / 64 * 64, NJ, AP<RcRec>(h, 0), AP<RcFin>(h, o_fin), d_state); KCHK(); }
 		hipLaunchKernelGGL(k_rc_emit, dim3(NJ), dim3(RC_EMIT_WG), 0, h->rc_stream, d_chains, AP<RcRec>(h, 0), AP<RcFin>(h, o_fin), wpool, d_state); KCHK();
 		HIPCHK(hipEventRecord(h->ev[3], h->rc_stream));
 		HIPCHK(hipStreamWaitEvent(s, h->ev[3], 0));

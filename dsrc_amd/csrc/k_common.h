@@ -28,11 +28,21 @@ __device__ __forceinline__ u32 wave_max(u32 v)
 	return v;
 }
 
-// LDS DMA (gfx950 global_load_lds_dwordx4): every active lane fetches 16 bytes from its own global address and
-// they land at lds_dst (wave-uniform) + 16 * lane without passing through registers
-__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst)
+// Pointers into LDS keep their address space so that LDS-DMA destinations are plain 32-bit constants
+#define LDS_AS __attribute__((address_space(3)))
+#define GLOBAL_AS __attribute__((address_space(1)))
+
+// LDS DMA (gfx950 global_load_lds_dwordx4): every active lane fetches 16 bytes from sbase (wave-uniform) + voff
+// (its own 32-bit byte offset) and they land at lds_dst (wave-uniform) + 16 * lane without passing through registers
+__device__ __forceinline__ void lds_dma16(const u8* sbase, u32 voff, LDS_AS void* lds_dst)
 {
-	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+	__builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(sbase + voff), lds_dst, 16, 0, 0);
+}
+
+__device__ __forceinline__ const u8* uniform_ptr(const void* p)
+{
+	const u64 v = (u64)p;
+	return (const u8*)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v));
 }
 
 // every LDS-DMA request this wave has issued so far has landed: s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt in bits

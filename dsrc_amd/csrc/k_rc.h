@@ -22,7 +22,7 @@
 #define ELEM_CTX_SHIFT 40
 
 // what the range coder consumes per symbol (written by k_replay in stream order, one contiguous array per chain)
-struct RcRec { u32 w_lo, w_hi, cum; };   // 12 bytes; w = w_hi:w_lo = ceil(2^48/total) << 16 | freq
+struct RcRec { u32 m_lo, mf, cum; };     // 12 bytes; m = ceil(2^48/total): m_lo = m & 0xFFFFFFFF, mf = (m >> 32) << 16 | freq
 
 struct CtxJob     // one (block, stream)
 {
@@ -379,8 +379,8 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 		if (active)
 		{	// what k_rc needs per symbol: the 48-bit reciprocal of `total` (rc_div), freq, cum -- one 16-byte record
 			RcRec rr;
-			const u64 w = ((((1ull << 48) + tot - 1) / tot) << 16) | f;
-			rr.w_lo = (u32)w; rr.w_hi = (u32)(w >> 32); rr.cum = cum;
+			const u64 m = ((1ull << 48) + tot - 1) / tot;
+			rr.m_lo = (u32)m; rr.mf = ((u32)(m >> 32) << 16) | f; rr.cum = cum;
 			recs[(u32)el] = rr;
 		}
 
@@ -439,6 +439,8 @@ struct RcChain
 	u32 out_byte0, out_cap;
 	u32 blk, is_dna;
 	u32 force_exact;   // tests: take the reference-loop path for every group (same bytes by construction)
+	u32 pitch;         // records between the arrays of consecutive chains of this chain's wave (64 chains)
+	u32 pad0;
 };
 
 // what k_rc leaves for k_rc_emit besides the per-symbol codes: the bytes of the last (n mod 16) symbols
@@ -451,40 +453,41 @@ struct RcFin { u32 n; u8 b[60]; };
 #define RC_OVERREAD (3 * RC_CHUNK)     // records the DMA may touch past the longest chain of a wave (arena slack)
 #define RC_XB 64                       // per-lane byte buffer of the exact path (LDS)
 
-struct alignas(16) U4 { u32 x, y, z, w; };
+typedef u32 __attribute__((vector_size(16))) U4;   // one 16-byte LDS / global access
 
 // magic = ceil(2^48 / d): floor(n * magic / 2^48) == floor(n / d) for every n < 2^32, d <= 2^16 (the error term
 // n*e/2^48 < 2^-16 cannot carry the fraction (<= 1 - 1/d) over an integer)
 __device__ __forceinline__ u32 rc_div(u32 range, u32 m_lo, u32 m_hi)
 {
-	const u32 t = __umulhi(range, m_lo);
-	return (u32)(((u64)range * m_hi + t) >> 16);
+	const u64 p = (u64)range * m_hi + __umulhi(range, m_lo);
+	return __builtin_amdgcn_alignbit((u32)(p >> 32), (u32)p, 16);          // (u32)(p >> 16) as one opaque 32-bit value
 }
 
 struct RcState { u64 low; u32 range; };
 
-// fast step: returns the symbol's code = top three bytes of low << 2 | bytes leaving (0..2: range' >= 2^8 because
-// range >= 2^24 and total <= 2^16); `flag` collects the clamp pre-condition
+// fast step: returns the symbol's code = top three bytes of low (bits 31..8) | bytes leaving (0..2: range' >= 2^8
+// because range >= 2^24 and total <= 2^16); `flag` collects the clamp pre-condition as a running 16-bit maximum
 __device__ __forceinline__ u32 rc_step_fast(RcState& s, const RcRec& e, u32& flag)
 {
-	const u32 f = e.w_lo & 0xFFFFu;
-	const u32 r = rc_div(s.range, (e.w_lo >> 16) | (e.w_hi << 16), e.w_hi >> 16);
+	const u32 r = rc_div(s.range, e.m_lo, e.mf >> 16);
 	const u64 low = s.low + (u64)r * e.cum;                                // r*cum <= range < 2^32: identical to the reference's 32-bit product
-	const u32 range = r * f;
-	const u32 kb = (u32)__builtin_clz(range) >> 3;
-	flag |= (((u32)(low >> 24) & 0xFFFFu) == 0xFFFFu) ? 1u : 0u;
-	s.low = low << (8 * kb);
-	s.range = range << (8 * kb);
-	return ((u32)(low >> 40) << 2) | kb;
+	const u32 range = r * (e.mf & 0xFFFFu);
+	__builtin_assume(range != 0);
+	const u32 lz = (u32)__builtin_clz(range);
+	const u32 k8 = lz & 0x18u;                                             // 8 * bytes leaving
+	const u32 z = (u32)(low >> 24) & 0xFFFFu;                              // bits 24..39 all ones <=> z == 0xFFFF
+	flag = z > flag ? z : flag;
+	s.low = low << k8;
+	s.range = range << k8;
+	return ((u32)(low >> 32) & 0xFFFFFF00u) | (lz >> 3);
 }
 
 // exact step: RangeEncoder::EncodeFrequency, verbatim; bytes go to the lane's LDS buffer
 __device__ inline void rc_step_exact(RcState& s, const RcRec& e, u8* xb, u32& nb)
 {
-	const u32 f = e.w_lo & 0xFFFFu;
-	const u32 r = rc_div(s.range, (e.w_lo >> 16) | (e.w_hi << 16), e.w_hi >> 16);
+	const u32 r = rc_div(s.range, e.m_lo, e.mf >> 16);
 	u64 low = s.low + (u64)r * e.cum;
-	u32 range = r * f;
+	u32 range = r * (e.mf & 0xFFFFu);
 	while (range <= 0x00FFFFFFu)
 	{
 		if ((low ^ (low + range)) & 0xFF00000000000000ull) { const u32 rr = (u32)low; range = (rr | 0x00FFFFFFu) - rr; }
@@ -501,26 +504,26 @@ struct RcRegs { U4 q[3 * RC_GROUP / 4]; };
 __device__ __forceinline__ RcRec rc_rec(const RcRegs& g, u32 i)
 {
 	const u32* d = (const u32*)g.q;
-	RcRec e; e.w_lo = d[3 * i]; e.w_hi = d[3 * i + 1]; e.cum = d[3 * i + 2];
+	RcRec e; e.m_lo = d[3 * i]; e.mf = d[3 * i + 1]; e.cum = d[3 * i + 2];
 	return e;
 }
 
 // codes of one group -> codes[0..15].  `row` = the chain's LDS row the group was read from (still intact).
-__device__ __forceinline__ void rc_group(RcState& s, u32* codes, const RcRegs& g, const U4* row, u32 grp, u8* xb, u32* err, u32 force_exact)
+__device__ __forceinline__ void rc_group(RcState& s, u32* codes, const RcRegs& g, const LDS_AS U4* row, u32 grp, u8* xb, u32* err, u32 force_exact)
 {
 	const RcState snap = s;
-	u32 bad = force_exact;
+	u32 zmax = force_exact ? 0xFFFFu : 0u;
 	u32 c[RC_GROUP];
 #pragma unroll
-	for (u32 i = 0; i < RC_GROUP; ++i) c[i] = rc_step_fast(s, rc_rec(g, i), bad);
-	if (bad)
+	for (u32 i = 0; i < RC_GROUP; ++i) c[i] = rc_step_fast(s, rc_rec(g, i), zmax);
+	if (zmax == 0xFFFFu)
 	{	// the reference's loop on the same 16 records; its bytes are dealt out three per code slot, in order
 		s = snap;
-		const u32* d = (const u32*)row + 3 * RC_GROUP * grp;
+		const LDS_AS u32* d = (const LDS_AS u32*)row + 3 * RC_GROUP * grp;
 		u32 nb = 0;
 		for (u32 i = 0; i < RC_GROUP; ++i)
 		{
-			RcRec e; e.w_lo = d[3 * i]; e.w_hi = d[3 * i + 1]; e.cum = d[3 * i + 2];
+			RcRec e; e.m_lo = d[3 * i]; e.mf = d[3 * i + 1]; e.cum = d[3 * i + 2];
 			rc_step_exact(s, e, xb, nb);
 		}
 		if (nb > 3 * RC_GROUP) atomicOr(err, (u32)DSRC_ERR_OUT_OVERFLOW);
@@ -528,70 +531,76 @@ __device__ __forceinline__ void rc_group(RcState& s, u32* codes, const RcRegs& g
 		for (u32 i = 0; i < RC_GROUP; ++i)
 		{
 			const u32 have = nb > 3 * i ? nb - 3 * i : 0u, take = have < 3 ? have : 3u;
-			c[i] = ((((u32)xb[3 * i] << 16) | ((u32)xb[3 * i + 1] << 8) | (u32)xb[3 * i + 2]) << 2) | take;
+			c[i] = ((u32)xb[3 * i] << 24) | ((u32)xb[3 * i + 1] << 16) | ((u32)xb[3 * i + 2] << 8) | take;
 		}
 	}
 #pragma unroll
 	for (u32 i = 0; i < RC_GROUP / 4; ++i)
 	{
-		U4 v; v.x = c[4 * i]; v.y = c[4 * i + 1]; v.z = c[4 * i + 2]; v.w = c[4 * i + 3];
+		const U4 v = {c[4 * i], c[4 * i + 1], c[4 * i + 2], c[4 * i + 3]};
 		((U4*)codes)[i] = v;
 	}
 }
 
-__device__ __forceinline__ void rc_load_group(RcRegs& g, const U4* row, u32 grp)
+__device__ __forceinline__ void rc_load_group(RcRegs& g, const LDS_AS U4* row, u32 grp)
 {
 #pragma unroll
 	for (u32 i = 0; i < 3 * RC_GROUP / 4; ++i) g.q[i] = row[grp * (3 * RC_GROUP / 4) + i];
 }
 
 // LDS-DMA requests for chains [J0, J1) of the wave: lanes 0..47 fetch the 48 x 16 bytes (= 64 records) of chain j
-// that start at byte `byte_off` of its array into row j.  Chain j's array starts src_off[j] bytes after `base`
-// (wave-uniform), so the request is one scalar base + one 32-bit lane offset.
+// that start at byte `chunk_off` (wave-uniform) of its array into row j.  The 64 arrays of a wave are `pitch`
+// bytes apart: a request is a scalar pointer (advanced by scalar adds) + the lane's fixed offset 16 * lane.
 template <int J0, int J1>
-__device__ __forceinline__ void rc_dma(U4* buf, const u8* base, u32 src_off, u32 byte_off)
+__device__ __forceinline__ void rc_dma(LDS_AS U4* buf, const u8* base, u32 pitch, u32 chunk_off, u32 n_live)
 {
-	u32 o[J1 - J0];
-#pragma unroll
-	for (int j = J0; j < J1; ++j) o[j - J0] = (u32)__builtin_amdgcn_readlane((int)src_off, j);
 	if (threadIdx.x < 3 * RC_CHUNK / 4)
 	{
+		const u8* sp = base + chunk_off + (u64)J0 * pitch;
 #pragma unroll
-		for (int j = J0; j < J1; ++j) lds_dma16(base + (o[j - J0] + byte_off), buf + j * RC_ROW_U4);
+		for (int j = J0; j < J1; ++j)
+		{
+			if ((u32)j < n_live) lds_dma16(sp, threadIdx.x * 16u, buf + j * RC_ROW_U4);      // n_live: constant 64 in full waves
+			sp += pitch;
+		}
 	}
 }
 
 // one 64-symbol chunk: the chain's records are in `cur` (landed), r0 holds its first group; requests the
 // chunk after it into `nxt` and leaves that chunk's first group in r0
-__device__ __forceinline__ void rc_chunk(RcState& s, u32* codes, RcRegs& r0, RcRegs& r1, const U4* cur, U4* nxt, u32 t0, u32 n,
-										 const u8* base, u32 src_off, u8* xb, u32* err, u32 fx)
+__device__ __forceinline__ void rc_chunk(RcState& s, u32* codes, RcRegs& r0, RcRegs& r1, const LDS_AS U4* cur, LDS_AS U4* nxt, u32 t0, u32 n,
+										 const u8* base, u32 pitch, u32 n_live, u8* xb, u32* err, u32 fx)
 {
 	const u32 lane = threadIdx.x;
-	const u32 off = (t0 + RC_CHUNK) * (u32)sizeof(RcRec) + lane * 16u;
-	const U4* row = cur + lane * RC_ROW_U4;
+	const u32 off = (t0 + RC_CHUNK) * (u32)sizeof(RcRec);
+	const LDS_AS U4* row = cur + lane * RC_ROW_U4;
 	u32* c = codes + t0;
 	rc_load_group(r1, row, 1);
-	rc_dma<0, 22>(nxt, base, src_off, off);
+	rc_dma<0, 22>(nxt, base, pitch, off, n_live);
 	if (t0 + 1 * RC_GROUP <= n) rc_group(s, c, r0, row, 0, xb, err, fx);
 	rc_load_group(r0, row, 2);
-	rc_dma<22, 43>(nxt, base, src_off, off);
+	rc_dma<22, 43>(nxt, base, pitch, off, n_live);
 	if (t0 + 2 * RC_GROUP <= n) rc_group(s, c + RC_GROUP, r1, row, 1, xb, err, fx);
 	rc_load_group(r1, row, 3);
-	rc_dma<43, 64>(nxt, base, src_off, off);
+	rc_dma<43, 64>(nxt, base, pitch, off, n_live);
 	if (t0 + 3 * RC_GROUP <= n) rc_group(s, c + 2 * RC_GROUP, r0, row, 2, xb, err, fx);
 	lds_dma_wait();                                                        // the requests above have landed before row 0 of `nxt` is read
 	rc_load_group(r0, nxt + lane * RC_ROW_U4, 0);
 	if (t0 + 4 * RC_GROUP <= n) rc_group(s, c + 3 * RC_GROUP, r1, row, 3, xb, err, fx);
 }
 
-__global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, RcRec* rec_pool, RcFin* fin, BlkState* st)
+// FULL: every lane of every wave has a chain (the launch covers floor(n_chains/64) waves); the remaining
+// chains, if any, run in one more wave of the !FULL instantiation, which must not request rows it does not have.
+template <bool FULL>
+__global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 first_chain, u32 n_chains, RcRec* rec_pool, RcFin* fin, BlkState* st)
 {
 	__shared__ U4 s_a[64 * RC_ROW_U4];
 	__shared__ U4 s_b[64 * RC_ROW_U4];
 	__shared__ u8 s_xb[64 * RC_XB];
-	const u32 lane = threadIdx.x, id = blockIdx.x * 64 + lane;
-	const bool have = id < n_chains;
-	const RcChain c = chains[have ? id : n_chains - 1];                        // idle lanes shadow a real chain's addresses and code nothing
+	const u32 lane = threadIdx.x, id = first_chain + blockIdx.x * 64 + lane;
+	const bool have = FULL || id < n_chains;
+	const RcChain c = chains[have ? id : n_chains - 1];                        // idle lanes shadow a real chain's values and code nothing
+	const u32 n_live = FULL ? 64u : n_chains - first_chain;
 	const u32 n = have ? c.n : 0;
 	RcRec* p = rec_pool + c.trip;
 	u32* codes = (u32*)p;                                                      // code t overwrites bytes 4t..4t+3 of the chain's own array
@@ -601,21 +610,22 @@ __global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, 
 	s.low = 0; s.range = 0xFFFFFFFFu;
 
 	const u32 n_full = n & ~(u32)(RC_GROUP - 1);
-	const u32 wave_full = wave_max(n_full);
+	const u32 wave_full = (u32)__builtin_amdgcn_readfirstlane((int)wave_max(n_full));
 	if (wave_full)
 	{
-		// the 64 arrays of a wave lie within 4 GiB (checked on the host): scalar base + 32-bit offsets
-		const u64 first = __shfl((u64)p, 0);
-		const u8* base = (const u8*)first;
-		const u32 src_off = (u32)((u64)p - first);
+		// the 64 arrays of a wave are c.pitch records apart (wave-uniform; idle lanes shadow the last chain's values)
+		const u8* base = uniform_ptr(rec_pool + __shfl(c.trip, 0));
+		const u32 pitch = (u32)__builtin_amdgcn_readfirstlane((int)(c.pitch * (u32)sizeof(RcRec)));
+		LDS_AS U4* buf_a = (LDS_AS U4*)s_a;
+		LDS_AS U4* buf_b = (LDS_AS U4*)s_b;
 		RcRegs r0, r1;
-		rc_dma<0, 64>(s_a, base, src_off, lane * 16u);
+		rc_dma<0, 64>(buf_a, base, pitch, 0, n_live);
 		lds_dma_wait();
-		rc_load_group(r0, s_a + lane * RC_ROW_U4, 0);
+		rc_load_group(r0, buf_a + lane * RC_ROW_U4, 0);
 		for (u32 t0 = 0; t0 < wave_full; t0 += 2 * RC_CHUNK)
 		{
-			rc_chunk(s, codes, r0, r1, s_a, s_b, t0, n, base, src_off, xb, err, c.force_exact);
-			rc_chunk(s, codes, r0, r1, s_b, s_a, t0 + RC_CHUNK, n, base, src_off, xb, err, c.force_exact);
+			rc_chunk(s, codes, r0, r1, buf_a, buf_b, t0, n, base, pitch, n_live, xb, err, c.force_exact);
+			rc_chunk(s, codes, r0, r1, buf_b, buf_a, t0 + RC_CHUNK, n, base, pitch, n_live, xb, err, c.force_exact);
 		}
 	}
 	if (!have) return;
@@ -651,7 +661,7 @@ __global__ void __launch_bounds__(RC_EMIT_WG) k_rc_emit(const RcChain* chains, c
 		if (t0 < n_codes)                                   // n_codes and t0 are multiples of 8: whole 32-byte pieces
 		{
 			const U4 a = ((const U4*)(codes + t0))[0], b = ((const U4*)(codes + t0))[1];
-			cd[0] = a.x; cd[1] = a.y; cd[2] = a.z; cd[3] = a.w; cd[4] = b.x; cd[5] = b.y; cd[6] = b.z; cd[7] = b.w;
+			cd[0] = a[0]; cd[1] = a[1]; cd[2] = a[2]; cd[3] = a[3]; cd[4] = b[0]; cd[5] = b[1]; cd[6] = b[2]; cd[7] = b[3];
 #pragma unroll
 			for (u32 k = 0; k < RC_EMIT_ITEMS; ++k) mine += cd[k] & 3u;
 		}
@@ -673,10 +683,10 @@ __global__ void __launch_bounds__(RC_EMIT_WG) k_rc_emit(const RcChain* chains, c
 #pragma unroll
 			for (u32 k = 0; k < RC_EMIT_ITEMS; ++k)
 			{
-				const u32 kb = cd[k] & 3u, v = cd[k] >> 2;
-				if (kb >= 1) out[at] = (u8)(v >> 16);
-				if (kb >= 2) out[at + 1] = (u8)(v >> 8);
-				if (kb >= 3) out[at + 2] = (u8)v;
+				const u32 kb = cd[k] & 3u, v = cd[k];
+				if (kb >= 1) out[at] = (u8)(v >> 24);
+				if (kb >= 2) out[at + 1] = (u8)(v >> 16);
+				if (kb >= 3) out[at + 2] = (u8)(v >> 8);
 				at += kb;
 			}
 		}

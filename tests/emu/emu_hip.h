@@ -96,10 +96,13 @@ template <typename T> inline T __shfl_xor(T v, int m, int width = 64) { (void)wi
 
 // gfx950 intrinsics used by k_common.h / k_rc.h
 #define __builtin_amdgcn_readlane(v, l) emu_shfl_from((int)(v), (int)(l))
+#define __builtin_amdgcn_readfirstlane(v) emu_shfl_from((int)(v), 0)
+#define __builtin_assume(x) ((void)0)
+#define __builtin_amdgcn_alignbit(hi, lo, sh) ((unsigned)(((((uint64_t)(unsigned)(hi)) << 32) | (unsigned)(lo)) >> ((sh) & 31)))
 #define __builtin_amdgcn_wave_barrier() do { uint64_t g_[64]; emu::wave_exchange(0, g_); } while (0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_fence(...) ((void)0)
-#define __builtin_amdgcn_global_load_lds(g, l, sz, off, aux) memcpy((char*)(l) + (threadIdx.x & 63) * ((sz) == 12 ? 16 : (sz)), (const char*)(g) + (off), (sz))   /* measured on gfx950: the 12-byte form also advances 16 bytes per lane */
+#define __builtin_amdgcn_global_load_lds(g, l, sz, off, aux) memcpy((char*)(void*)(l) + (threadIdx.x & 63) * ((sz) == 12 ? 16 : (sz)), (const char*)(const void*)(g) + (off), (sz))   /* measured on gfx950: the 12-byte form also advances 16 bytes per lane */
 
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
