@@ -27,10 +27,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Every scheduler instance drives two HIP streams (front end + range coder).  The HIP runtime multiplexes streams onto
+# 4 hardware queues by default, which serialises unrelated instances behind each other's 0.3 s range-coder kernel;
+# must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 BUF = 8 << 20                     # -b8 (reference default, src/Common.h:156)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 RECS_PER_BLOCK = 22300
-PMC_RC_BYTES_PER_BLOCK = (13.345e6 * 2 + 0.648e6) * 1024 / 256     # measured, see roofline.traffic below
+PMC_RC_BYTES_PER_BLOCK = (20.0005e6 * 2 + 13.3255e6) * 1024 / 512   # measured, see roofline.traffic below
 MAX_RESIDENT = 4                  # distinct input shards kept in HBM per scheduler instance
 
 
@@ -152,10 +157,10 @@ class StepGate:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)   # 3 x 1200 blocks = 80 % of the 100 M-read set (~4500 blocks of 8 MiB); all inputs stay resident in HBM
+    ap.add_argument("--steps", type=int, default=6)   # 6 x 1400 blocks of 8 MiB ~ 1.9 passes over the 100 M-read set (~4500 blocks); inputs stay resident in HBM
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=int(os.environ.get("DSRC_BENCH_BLOCKS", "1200")), help="8 MiB chunks per step per GPU")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DSRC_BENCH_PIPELINE", "3")), help="scheduler instances per GPU")
+    ap.add_argument("--blocks", type=int, default=int(os.environ.get("DSRC_BENCH_BLOCKS", "1400")), help="8 MiB chunks per step per GPU")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DSRC_BENCH_PIPELINE", "4")), help="scheduler instances per GPU")
     ap.add_argument("--dna", type=int, default=3)
     ap.add_argument("--qua", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
@@ -300,12 +305,12 @@ def main():
                        "ratio_out_in": round(out_bytes / in_bytes, 4), "parity_checked_blocks": checked},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         # HBM bytes of one k_rc launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), 256-block launch:
-                         # FETCH 13.345e6 KiB x 2 (gfx950 under-count of wide coalesced reads) + WRITE 0.648e6 KiB = 106.8 MB per block
-                         # (profiles/r01_pmc_b256_p1_d3q2.txt); scaled to this launch's block count
-                         "traffic": int(PMC_RC_BYTES_PER_BLOCK * sub_blocks), "kernel": "k_rc (range coder, one lane per stream)",
+                         # L2<->fabric bytes of one k_rc launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), 512-block launch:
+                         # FETCH 20.0005e6 KiB x 2 (gfx950 counts 16 B/lane streaming reads at half) + WRITE 13.3255e6 KiB = 106.7 MB per block,
+                         # i.e. exactly the 12-byte records read once + the 4-byte codes written once (profiles/r01_pmc_b512_p1_d3q2.txt)
+                         "traffic": int(PMC_RC_BYTES_PER_BLOCK * sub_blocks), "kernel": "k_rc (range-coder arithmetic, one lane per stream; followed by k_rc_emit)",
                          "kernel_ms": round(rc_ms, 2), "launch_bytes": int(alg), "batch_ms": round(batch_ms, 2),
-                         "note": "algorithmic bytes = chunk bytes in + block bytes out of one sub-batch launch; durations from HIP events on the scheduler stream"},
+                         "note": "algorithmic bytes = chunk bytes in + block bytes out of one sub-batch launch (SURVEY 8d); kernel_ms = k_rc + k_rc_emit from HIP events on the range-coder stream, measured while other scheduler instances share the GPU (alone: 240 ms)"},
         }
         if not args.no_cpu and world == 1:
             ln = lanes[0]

@@ -589,15 +589,14 @@ __device__ __forceinline__ void rc_chunk(RcState& s, u32* codes, RcRegs& r0, RcR
 	if (t0 + 4 * RC_GROUP <= n) rc_group(s, c + 3 * RC_GROUP, r1, row, 3, xb, err, fx);
 }
 
-// FULL: every lane of every wave has a chain (the launch covers floor(n_chains/64) waves); the remaining
-// chains, if any, run in one more wave of the !FULL instantiation, which must not request rows it does not have.
+// FULL: every lane of the wave has a chain; the last wave of a launch may be partial and then must not request rows
+// it does not have (one launch, two instantiations of the body: a wave only ever fetches the code of its own)
 template <bool FULL>
-__global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 first_chain, u32 n_chains, RcRec* rec_pool, RcFin* fin, BlkState* st)
+__device__ __forceinline__ void rc_wave(const RcChain* chains, u32 n_chains, RcRec* rec_pool, RcFin* fin, BlkState* st, LDS_AS U4* buf_a, LDS_AS U4* buf_b, u8* s_xb)
 {
-	__shared__ U4 s_a[64 * RC_ROW_U4];
-	__shared__ U4 s_b[64 * RC_ROW_U4];
-	__shared__ u8 s_xb[64 * RC_XB];
-	const u32 lane = threadIdx.x, id = first_chain + blockIdx.x * 64 + lane;
+	__builtin_amdgcn_s_setprio(3);                                             // the serial wave wins issue arbitration against co-resident data-parallel waves
+	const u32 first_chain = blockIdx.x * 64;
+	const u32 lane = threadIdx.x, id = first_chain + lane;
 	const bool have = FULL || id < n_chains;
 	const RcChain c = chains[have ? id : n_chains - 1];                        // idle lanes shadow a real chain's values and code nothing
 	const u32 n_live = FULL ? 64u : n_chains - first_chain;
@@ -616,8 +615,6 @@ __global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 first_chai
 		// the 64 arrays of a wave are c.pitch records apart (wave-uniform; idle lanes shadow the last chain's values)
 		const u8* base = uniform_ptr(rec_pool + __shfl(c.trip, 0));
 		const u32 pitch = (u32)__builtin_amdgcn_readfirstlane((int)(c.pitch * (u32)sizeof(RcRec)));
-		LDS_AS U4* buf_a = (LDS_AS U4*)s_a;
-		LDS_AS U4* buf_b = (LDS_AS U4*)s_b;
 		RcRegs r0, r1;
 		rc_dma<0, 64>(buf_a, base, pitch, 0, n_live);
 		lds_dma_wait();
@@ -637,6 +634,15 @@ __global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 first_chai
 	for (u32 k = 0; k < nb; ++k) F->b[k] = xb[k];
 	for (u32 k = 0; k < 8; ++k) { F->b[nb + k] = (u8)(s.low >> 56); s.low <<= 8; }
 	F->n = nb + 8;
+}
+
+__global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, RcRec* rec_pool, RcFin* fin, BlkState* st)
+{
+	__shared__ U4 s_a[64 * RC_ROW_U4];
+	__shared__ U4 s_b[64 * RC_ROW_U4];
+	__shared__ u8 s_xb[64 * RC_XB];
+	if (blockIdx.x * 64 + 64 <= n_chains) rc_wave<true>(chains, n_chains, rec_pool, fin, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb);
+	else rc_wave<false>(chains, n_chains, rec_pool, fin, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb);
 }
 
 // ---- byte emitter: codes -> stream bytes (data-parallel) ------------------------------------------

@@ -98,6 +98,7 @@ template <typename T> inline T __shfl_xor(T v, int m, int width = 64) { (void)wi
 #define __builtin_amdgcn_readlane(v, l) emu_shfl_from((int)(v), (int)(l))
 #define __builtin_amdgcn_readfirstlane(v) emu_shfl_from((int)(v), 0)
 #define __builtin_assume(x) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_alignbit(hi, lo, sh) ((unsigned)(((((uint64_t)(unsigned)(hi)) << 32) | (unsigned)(lo)) >> ((sh) & 31)))
 #define __builtin_amdgcn_wave_barrier() do { uint64_t g_[64]; emu::wave_exchange(0, g_); } while (0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
