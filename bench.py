@@ -11,7 +11,8 @@ overlaps the data-parallel front end of the next; the timed region covers all K 
 
 N > 1: one process per GPU (torch.distributed, nccl = RCCL).  Ranks take disjoint record ranges (weak
 scaling, no collective in the data path); after each step the compressed block stream is gathered to
-rank 0 in archive order (dsrc_amd/dist.py), inside the timed region.
+rank 0 in archive order (dsrc_amd/dist.py), inside the timed region and overlapped with the next step's compression
+(two output buffers per scheduler instance).
 """
 from __future__ import annotations
 
@@ -102,7 +103,7 @@ def cpu_baseline(sample: bytes, d: int, q: int):
 class Lane:
     """One scheduler instance: own handle (HIP stream + arena) and its sub-batches."""
 
-    def __init__(self, cfg, device, sub_blocks, n_sub, rank, lane_id, n_lanes, alloc_out):
+    def __init__(self, cfg, device, sub_blocks, n_sub, rank, lane_id, n_lanes, alloc_out, n_out=1):
         from dsrc_amd._lib import Handle
         self.h = Handle(cfg.dna_order, cfg.quality_order, quality_offset=33, device=device)
         self.sub = []
@@ -122,7 +123,8 @@ class Lane:
             starts, sizes = cut_blocks(off, sub_blocks)
             assert len(starts) == sub_blocks
             self.sub.append((d_in, starts, sizes))
-        self.d_out, self.out_keep = alloc_out(self.h, self.cap_out)
+        # two output buffers: with N > 1 the block stream of step s is gathered while step s+1 is being compressed
+        self.outs = [alloc_out(self.h, self.cap_out) for _ in range(n_out)]
         self.results = {}
         self.timing = []
         self.trace = []
@@ -133,7 +135,7 @@ class Lane:
     def run(self, k):
         d_in, starts, sizes = self.shard(k)
         t0 = time.perf_counter()
-        res = self.h.compress_batch_device(d_in, starts, sizes, self.d_out, self.cap_out)
+        res = self.h.compress_batch_device(d_in, starts, sizes, self.outs[k % len(self.outs)][0], self.cap_out)
         t1 = time.perf_counter()
         self.results[k] = res
         self.timing.append(self.h.last_timing())
@@ -141,17 +143,31 @@ class Lane:
         return res
 
 
-class StepGate:
-    """N > 1 only: all lanes of a step finish before its gather (which runs on the main thread)."""
+class StepGates:
+    """N > 1 only.  The gather of step s runs on the main thread once every lane has finished step s, while the lanes
+    already compress step s+1 into their other output buffer; a lane may start step s only after the gather of
+    step s-2 (same buffer) is done."""
 
-    def __init__(self):
-        self.n = 0; self.cv = threading.Condition(); self.gathered = False
+    def __init__(self, n_lanes):
+        self.cv = threading.Condition(); self.done = {}; self.gathered = set(); self.n_lanes = n_lanes
 
-    def wait_lane(self):
+    def lane_may_start(self, s, first):
         with self.cv:
-            self.n += 1; self.cv.notify_all()
-            while not self.gathered:
+            while s - 2 >= first and (s - 2) not in self.gathered:
                 self.cv.wait()
+
+    def lane_done(self, s):
+        with self.cv:
+            self.done[s] = self.done.get(s, 0) + 1; self.cv.notify_all()
+
+    def wait_step(self, s):
+        with self.cv:
+            while self.done.get(s, 0) < self.n_lanes:
+                self.cv.wait()
+
+    def step_gathered(self, s):
+        with self.cv:
+            self.gathered.add(s); self.cv.notify_all()
 
 
 def main():
@@ -170,7 +186,7 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None; torch = None
-    if world > 1:
+    if world > 1 or os.environ.get("DSRC_BENCH_FORCE_DIST"):      # FORCE_DIST: exercise the N > 1 code path with one rank
         import torch as torch_
         import torch.distributed as dist_
         torch = torch_
@@ -190,7 +206,7 @@ def main():
             return t.data_ptr(), t
         return h.dev_alloc(cap), None
 
-    lanes = [Lane(cfg, local, sub_blocks, total_steps, rank, i, P, alloc_out) for i in range(P)]
+    lanes = [Lane(cfg, local, sub_blocks, total_steps, rank, i, P, alloc_out, n_out=2 if dist is not None else 1) for i in range(P)]
 
     def sync_all():
         if torch is not None:
@@ -204,7 +220,7 @@ def main():
         from dsrc_amd.dist import gather_block_stream
         for ln in lanes:
             _, o_sizes, _, _ = ln.results[step]
-            gather_block_stream(o_sizes, ln.out_keep)
+            gather_block_stream(o_sizes, ln.outs[step % len(ln.outs)][1])
 
     # ---- warmup (also sizes the arenas and measures one sub-batch for the stagger) ------------------------
     t_sub = 0.0
@@ -216,25 +232,29 @@ def main():
                 d_in, starts, sizes = ln.shard(s)
                 n = min(args.check, sub_blocks)
                 first_chunks = [ln.h.dev_download(d_in + starts[i], sizes[i]) for i in range(n)]
-                first_blob = (res, ln.h.dev_download(ln.d_out, res[0][n - 1] + res[1][n - 1]))
+                first_blob = (res, ln.h.dev_download(ln.outs[s % len(ln.outs)][0], res[0][n - 1] + res[1][n - 1]))
         gather_step(s)
     for ln in lanes:
         ln.timing.clear()
 
-    # ---- timed region: K steps, lanes half a period apart ---------------------------------------------------
-    step_done = {s: StepGate() for s in range(args.warmup, total_steps)}
+    # ---- timed region: K steps, lanes a fraction of a period apart ------------------------------------------
+    first = args.warmup
+    gates = StepGates(P)
     errors = []
 
     def worker(idx):
         try:
             if idx:
                 time.sleep(t_sub * idx / P)
-            for s in range(args.warmup, total_steps):
-                lanes[idx].run(s)
+            for s in range(first, total_steps):
                 if dist is not None:
-                    step_done[s].wait_lane()
+                    gates.lane_may_start(s, first)
+                lanes[idx].run(s)
+                gates.lane_done(s)
         except Exception as e:      # noqa: BLE001
             errors.append(e)
+            for s in range(first, total_steps):      # do not leave the main thread waiting
+                gates.lane_done(s)
 
     sync_all()
     t_begin = time.perf_counter()
@@ -242,14 +262,11 @@ def main():
     for t in threads:
         t.start()
     if dist is not None:
-        for s in range(args.warmup, total_steps):
-            g = step_done[s]
-            with g.cv:
-                while g.n < P:
-                    g.cv.wait()
-            gather_step(s)
-            with g.cv:
-                g.gathered = True; g.cv.notify_all()
+        for s in range(first, total_steps):
+            gates.wait_step(s)
+            if not errors:
+                gather_step(s)
+            gates.step_gathered(s)
     for t in threads:
         t.join()
     sync_all()

@@ -109,8 +109,8 @@ size_t estimate_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
 	const bool rc = h->set.dna_order > 0 || h->set.quality_order > 0;
 	size_t tot = 0, mx = 0;
 	for (u32 i = 0; i < n; ++i) { tot += (size_t)sizes[i] + 4096; mx = std::max(mx, (size_t)sizes[i]); }
-	const size_t sort_slice = std::min(tot * 14, ((size_t)12288 << 20) + mx * 16);      // see slice_lo in run_batch
-	return tot * (rc ? 15 : 14) + (rc ? sort_slice : 0) + (size_t)n * (1u << 20) + (16u << 20);
+	const size_t sort_slice = std::min(tot * 14, ((size_t)14336 << 20) + mx * 16);      // see slice_lo in run_batch
+	return tot * 14 + (rc ? sort_slice : 0) + (size_t)n * (1u << 20) + (16u << 20);
 }
 
 struct BatchIO
@@ -425,12 +425,17 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	std::vector<u32> slice_lo;
 	{
 		const char* env = getenv("DSRC_GPU_SORT_SLICE_MB");
-		const size_t budget = (env ? (size_t)atol(env) : (size_t)12288) << 20;
+		const size_t budget = (env ? (size_t)atol(env) : (size_t)14336) << 20;      // ~256 streams of an 8 MiB chunk: one k_sort workgroup per CU
+		size_t need_max = 128;
+		for (u32 i = 0; i < NJ; ++i) need_max = std::max(need_max, ((size_t)jobs[i].n * 8 + 64) * 2);
+		const u32 max_jobs = (u32)std::max<size_t>(1, budget / need_max);
+		const u32 n_slices = std::max(1u, (NJ + max_jobs - 1) / max_jobs);
+		const u32 per_slice = std::max(1u, (NJ + n_slices - 1) / n_slices);          // equal slices: no small last launch
 		size_t cur = 0, mx = 0;
 		for (u32 i = 0; i < NJ; ++i)
 		{
 			const size_t need = ((size_t)jobs[i].n * 8 + 64) * 2;
-			if (i == 0 || cur + need > budget) { slice_lo.push_back(i); cur = 0; }
+			if (i % per_slice == 0) { slice_lo.push_back(i); cur = 0; }
 			cur += need; mx = std::max(mx, cur);
 		}
 		slice_lo.push_back(NJ);
@@ -690,7 +695,9 @@ int dsrcgpu_create(const dsrcgpu_settings* settings, const dsrcgpu_dataset* data
 		}
 		else
 		{
-			HIPCHK(hipStreamCreate(&h->stream));
+			// non-blocking: a host framework's work on the legacy default stream (torch, RCCL bookkeeping) must not
+			// serialise with the scheduler's streams
+			HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 			int lo_p = 0, hi_p = 0;
 			HIPCHK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
 			HIPCHK(hipStreamCreateWithPriority(&h->rc_stream, hipStreamNonBlocking, hi_p));
