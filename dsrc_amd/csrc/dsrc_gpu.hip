@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <deque>
 #include <string>
 #include <vector>
@@ -127,6 +128,11 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 {
 	const u32 B = io.n;
 	if (B == 0) return DSRCGPU_OK;
+	// DSRC_GPU_DEBUG=2: host-side timeline of the phases of this batch (ms since the call)
+	static const bool trace = getenv("DSRC_GPU_DEBUG") && atoi(getenv("DSRC_GPU_DEBUG")) >= 2;
+	const auto t_call = std::chrono::steady_clock::now();
+	std::string tl;
+	auto mark = [&](const char* what) { if (trace) { char b[64]; snprintf(b, sizeof b, " %s %.1f", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count()); tl += b; } };
 	hipStream_t s = h->stream;
 	Arena& A = h->arena;
 	const u32 dna_order = h->set.dna_order, qo = h->set.quality_order;
@@ -164,6 +170,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	hipLaunchKernelGGL(k_scan_tiles, dim3(B), dim3(WG), 0, s, d_desc, d_tiles, prm); KCHK();
 	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
+	mark("S1");
 
 	// ---- phase 2: index, statistics, symbol streams --------------------------------------------------
 	u64 lines = 0, recs = 0, qbytes = 0; u32 max_rec_cap = 1;
@@ -200,6 +207,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	if (crc) { hipLaunchKernelGGL(k_crc, dim3(B, 3), dim3(WG), 0, s, d_in, d_desc, d_state, rp, h->d_crc_tab, prm); KCHK(); }
 	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
+	mark("S2");
 
 	// ---- phase 3: scheme selection and buffer carving (host) -------------------------------------------
 	for (u32 b = 0; b < B; ++b)
@@ -458,6 +466,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	// ---- tags: dictionary resources are sized from the finalized field kinds ----------------------------------
 	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
+	mark("S3");
 	std::vector<TagFieldRes> tres((size_t)B * DSRC_MAX_FIELDS);
 	memset(tres.data(), 0, sizeof(TagFieldRes) * tres.size());
 	size_t tz_lo = al(A.top, 256); A.top = tz_lo;
@@ -590,6 +599,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	// ---- sizes -> output layout -> assembly -----------------------------------------------------------------------
 	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
+	mark("S4");
 	u64 total = 0;
 	for (u32 b = 0; b < B; ++b)
 	{
@@ -618,6 +628,8 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	HIPCHK(hipEventRecord(h->ev[1], s));
 	if (io.host_out) HIPCHK(hipMemcpyAsync(io.host_out, d_out, total, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
+	mark("done");
+	if (trace) fprintf(stderr, "[dsrc_gpu] %p timeline:%s\n", (void*)h, tl.c_str());
 	if (getenv("DSRC_GPU_DEBUG")) fprintf(stderr, "[dsrc_gpu] batch of %u chunks, %zu input bytes: arena used %zu of %zu bytes\n", B, in_total, A.top, A.cap);
 	hipEventElapsedTime(&h->batch_ms, h->ev[0], h->ev[1]);
 	if (h->rc_launches) hipEventElapsedTime(&h->rc_ms, h->ev[2], h->ev[3]); else h->rc_ms = 0.f;

@@ -45,6 +45,10 @@ __device__ __forceinline__ const u8* uniform_ptr(const void* p)
 	return (const u8*)(((u64)(u32)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v));
 }
 
+// orders one wave's LDS traffic in program order (no instruction: the lanes of a wave run in lock-step and the LDS
+// executes a wave's instructions in order)
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
 // every LDS-DMA request this wave has issued so far has landed: s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt in bits
 // 3:0 and 15:14, expcnt/lgkmcnt left at their maxima), followed by a wave-scope fence (no instruction; it keeps the
 // compiler from moving LDS reads above the wait).  The compiler's own tracking of LDS DMA is not relied upon.

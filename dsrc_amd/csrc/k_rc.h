@@ -53,35 +53,50 @@ typedef u64 __attribute__((aligned(1))) u64_unaligned;
 // ---- DNA context: hash of the previous `order` symbols, carried across records --------------
 // (TDnaRCOrderModeler::UpdateHash, src/DnaModelerRCO.h:121-131).  Element of symbol t:
 // ctx << 40 | sym << 32 | t.  Symbols before the start of the stream do not enter the hash.
-__device__ __forceinline__ u64 ctx_elem_dna(const CtxJob& j, const u8* s, u32 t, bool* bad)
+
+// eight 2-bit symbols, one per byte (byte i -> bits 2i..2i+1)
+__device__ __forceinline__ u32 pack2x8(u64 x)
 {
-	const u32 ab = j.alpha_bits, n_alpha = 1u << ab, order = j.order;
-	u64 h = 0; u32 sym;
-	if (t >= 15 && order <= 15)
-	{	// s[t-15 .. t] in two unaligned 8-byte loads
-		const u64 lo = *(const u64_unaligned*)(s + t - 15), hi = *(const u64_unaligned*)(s + t - 7);
-		sym = (u32)(hi >> 56);
-		for (u32 k = order; k >= 1; --k)
-		{
-			const u32 v = k <= 7 ? (u32)(hi >> (8 * (7 - k))) & 0xFFu : (u32)(lo >> (8 * (15 - k))) & 0xFFu;
-			h = (h << ab) | v;
-		}
+	x &= 0x0303030303030303ull;
+	x = (x | (x >> 6)) & 0x000F000F000F000Full;
+	x = (x | (x >> 12)) & 0x000000FF000000FFull;
+	return (u32)(x | (x >> 24)) & 0xFFFFu;
+}
+
+// hash of the symbols before t (newest in the lowest bits) and the symbol itself; *sym is the raw stream byte
+__device__ __forceinline__ u32 dna_hash(const CtxJob& j, const u8* s, u32 t, u32* sym)
+{
+	const u32 ab = j.alpha_bits, order = j.order;
+	u32 h = 0;
+	if (t >= 15 && ab == 2 && order <= 15)
+	{	// s[t-15 .. t] in two unaligned 8-byte loads; byte-reversed so that s[t-1] comes first
+		const u64 hi = *(const u64_unaligned*)(s + t - 7), lo = *(const u64_unaligned*)(s + t - 15);
+		*sym = (u32)(hi >> 56);
+		h = pack2x8(__builtin_bswap64(hi) >> 8);                 // s[t-1] .. s[t-7] -> bits 0..13
+		if (order > 7) h |= pack2x8(__builtin_bswap64(lo)) << 14;  // s[t-8] .. s[t-15] -> bits 14..29
 	}
 	else
 	{
 		const u32 k0 = t < order ? t : order;
 		for (u32 k = k0; k >= 1; --k) h = (h << ab) | s[t - k];
-		sym = s[t];
+		*sym = s[t];
 	}
-	h &= (1ull << (ab * order)) - 1ull;
+	return h & (u32)((1ull << (ab * order)) - 1ull);
+}
+
+__device__ __forceinline__ u64 ctx_elem_dna(const CtxJob& j, const u8* s, u32 t, bool* bad)
+{
+	u32 sym;
+	const u32 h = dna_hash(j, s, t, &sym);
+	const u32 n_alpha = 1u << j.alpha_bits;
 	if (sym >= n_alpha) *bad = true;                        // reference UB
-	return (h << ELEM_CTX_SHIFT) | ((u64)(sym & (n_alpha - 1)) << ELEM_SYM_SHIFT) | t;
+	return ((u64)h << ELEM_CTX_SHIFT) | ((u64)(sym & (n_alpha - 1)) << ELEM_SYM_SHIFT) | t;
 }
 
 // ---- quality context (TQualityModelBase::UpdateHash, src/QualityEncoder.h:77-94) -------------
 // Before coding symbol t the hash slots are: k < order/2 : raw s[t-1-k];
 // k >= order/2 : floor((s[t-1-k] + s[t-2-k]) / 2)  (order 1: slot 0 is raw).  Symbols before the
-// start of the block read as 0.  ctx = (slots << alpha_bits) | position_context.
+// start of the block read as 0.  ctx = (slots << alpha_bits) | position_context  (<= 21 bits).
 // rank: 256-entry LDS table (dense rank of a raw quality value, or identity for the lossy model).
 __device__ __forceinline__ u64 ctx_elem_qua(const CtxJob& j, const u8* s, const u8* qp, const u8* rank, u32 t)
 {
@@ -102,17 +117,37 @@ __device__ __forceinline__ u64 ctx_elem_qua(const CtxJob& j, const u8* s, const 
 		for (u32 k = 0; k < 7; ++k) v[k] = (k <= order && t >= k + 1) ? rank[s[t - 1 - k]] : 0;
 	}
 	v[7] = 0;
-	u64 h = 0;
-	for (u32 k = order; k >= 1; --k)
-	{
-		const u32 slot = k - 1;
-		const u32 x = (slot < half || order == 1) ? v[slot] : ((v[slot] + v[slot + 1]) >> 1);
-		h = (h << ab) | x;
-	}
+	u32 h = 0;
+#pragma unroll
+	for (u32 k = 6; k >= 1; --k)
+		if (k <= order)
+		{
+			const u32 slot = k - 1;
+			const u32 x = (slot < half || order == 1) ? v[slot] : ((v[slot] + v[slot + 1]) >> 1);
+			h = (h << ab) | x;
+		}
 	const u32 pctx = qp[t] >> j.rescale_shift;
-	const u64 ctx = (h << ab) | pctx;
+	const u32 ctx = (h << ab) | pctx;
 	const u32 sym = rank[cur] & ((1u << ab) - 1u);
-	return (ctx << ELEM_CTX_SHIFT) | ((u64)sym << ELEM_SYM_SHIFT) | t;
+	return ((u64)ctx << ELEM_CTX_SHIFT) | ((u64)sym << ELEM_SYM_SHIFT) | t;
+}
+
+// lowest `dbits` bits of the context of symbol t (the first sort digit) without building the element
+__device__ __forceinline__ u32 ctx_digit0(const CtxJob& j, const u8* s, const u8* qp, const u8* rank, u32 t, u32 dmask, bool* bad)
+{
+	if (j.is_dna)
+	{
+		u32 sym;
+		const u32 h = dna_hash(j, s, t, &sym);
+		if (sym >= (1u << j.alpha_bits)) *bad = true;
+		return h & dmask;
+	}
+	if (2 * j.alpha_bits >= j.dbits)
+	{	// position context + slot 0, which is always the raw previous symbol
+		const u32 v0 = t >= 1 ? rank[s[t - 1]] : 0u;
+		return ((v0 << j.alpha_bits) | (qp[t] >> j.rescale_shift)) & dmask;
+	}
+	return (u32)(ctx_elem_qua(j, s, qp, rank, t) >> ELEM_CTX_SHIFT) & dmask;
 }
 
 // ---- stable LSD radix sort by ctx; one workgroup owns one stream ------------------------------
@@ -146,8 +181,7 @@ __global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool, cons
 		bool bad = false;
 		for (u32 i = threadIdx.x; i < n; i += blockDim.x)
 		{
-			const u64 e = j.is_dna ? ctx_elem_dna(j, sym_src, i, &bad) : ctx_elem_qua(j, sym_src, qp, s_rank, i);
-			atomicAdd(&s_base[(u32)(e >> ELEM_CTX_SHIFT) & (bins - 1)], 1u);
+			atomicAdd(&s_base[ctx_digit0(j, sym_src, qp, s_rank, i, bins - 1, &bad)], 1u);
 		}
 		if (bad) atomicOr(&st[j.blk].err, (u32)DSRC_ERR_REF_UB);
 	}
@@ -197,7 +231,8 @@ __global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool, cons
 				const bool valid = i < n;
 				const u32 d = (u32)(el[k] >> shift) & (bins - 1);
 				u64 peers = __ballot(valid);
-				for (u32 b = 0; b < j.dbits; ++b)
+#pragma unroll
+				for (u32 b = 0; b < SORT_DIGIT_BITS; ++b)                   // digit bits above dbits are zero for every lane: no effect
 				{
 					const u64 m = __ballot((d >> b) & 1u);
 					peers &= ((d >> b) & 1u) ? m : ~m;
@@ -281,6 +316,8 @@ template <int N> __device__ __forceinline__ void replay_prefix(const ReplayRow<N
 template <int N>
 __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const u64* pool, RcRec* rec_pool)
 {
+	constexpr int BITS = N <= 4 ? 2 : N <= 8 ? 3 : N <= 16 ? 4 : N <= 32 ? 5 : N <= 64 ? 6 : 7;
+	__shared__ u32 s_tail[REPLAY_WG / 64][128];
 	const CtxJob j = jobs[blockIdx.y];
 	const u64* src = pool + (j.sorted_in_b ? j.elems_b : j.elems);
 	RcRec* recs = rec_pool + j.trip;
@@ -357,18 +394,28 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 		const bool last_is_cont = cont && hm == 0;
 		const u64 lastmask = tmask & ~((1ull << last_start) - 1ull);
 
-		u32 same = 0, less = 0, add_a = 0, add_b = 0;
-#pragma unroll 4
-		for (u32 v = 0; v < (u32)N; ++v)
+		// lanes of the window whose symbol equals mine (EQ) / is smaller than mine (LT): one ballot per symbol BIT,
+		// refined from the most significant bit down (radix compare) -- log2(N) steps instead of N
+		u64 EQ = tmask, LT = 0;
+#pragma unroll
+		for (int k = BITS - 1; k >= 0; --k)
 		{
-			const u64 m = __ballot(active && sym == v);
-			const u32 pm = (u32)__popcll(m & segmask_lt);
-			if (v < sym) less += pm;
-			if (v == sym) same = pm;
-			const u32 tail = (u32)__popcll(m & lastmask);
-			if (v == lane) add_a = tail;
-			if (N > 64 && v == lane + 64) add_b = tail;
+			const bool bit = (sym >> k) & 1u;
+			const u64 m = __ballot(active && bit);
+			const u64 sb = bit ? ~0ull : 0ull;
+			LT |= EQ & ~m & sb;
+			EQ &= ~(m ^ sb);
 		}
+		const u32 same = (u32)__popcll(EQ & segmask_lt), less = (u32)__popcll(LT & segmask_lt);
+		// counts carried by the segment that stays open: the last lane of each symbol inside it publishes that
+		// symbol's count to the lane that holds the symbol's counter
+		u32* tl = s_tail[wave_id()];
+		tl[lane] = 0; if (N > 64) tl[lane + 64] = 0;
+		wave_fence();
+		const u64 eq_last = EQ & lastmask;
+		if (active && ((lastmask >> lane) & 1ull) && (eq_last >> lane) == 1ull) tl[sym] = (u32)__popcll(eq_last);
+		wave_fence();
+		const u32 add_a = tl[lane], add_b = (N > 64) ? tl[lane + 64] : 0u;
 		const u32 in_seg = (u32)__popcll(segmask_lt & tmask);
 		u32 f, cum, tot;
 		{
