@@ -173,7 +173,7 @@ class StepGates:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)   # 6 x 1400 blocks of 8 MiB ~ 1.9 passes over the 100 M-read set (~4500 blocks); inputs stay resident in HBM
+    ap.add_argument("--steps", type=int, default=10)  # 10 x 1400 blocks of 8 MiB ~ 3 passes over the 100 M-read set (~4500 blocks); inputs stay resident in HBM
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--blocks", type=int, default=int(os.environ.get("DSRC_BENCH_BLOCKS", "1400")), help="8 MiB chunks per step per GPU")
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DSRC_BENCH_PIPELINE", "4")), help="scheduler instances per GPU")
@@ -294,6 +294,20 @@ def main():
         for i, ch in enumerate(first_chunks):
             want = o.compress_block(cfg, ch)[0]
             assert blob[res[0][i]: res[0][i] + res[1][i]] == want, f"bench parity check failed on block {i}"
+            checked += 1
+    # ... and of what the timed region itself produced while all scheduler instances were running concurrently:
+    # the last block of every instance's final sub-batch (still in its output buffer)
+    if rank == 0 and args.check:
+        from tests._oracle import Oracle
+        o = Oracle()
+        last = total_steps - 1
+        for li, ln in enumerate(lanes):
+            d_in, starts, sizes = ln.shard(last)
+            o_offs, o_sizes, _, _ = ln.results[last]
+            i = len(starts) - 1
+            chunk = ln.h.dev_download(d_in + starts[i], sizes[i])
+            got = ln.h.dev_download(ln.outs[last % len(ln.outs)][0] + o_offs[i], o_sizes[i])
+            assert got == o.compress_block(cfg, chunk)[0], f"bench parity check failed: instance {li}, last block of the timed region"
             checked += 1
 
     if dist is not None:

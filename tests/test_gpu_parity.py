@@ -114,6 +114,38 @@ def test_range_coder_reference_loop_path(gpu, oracle, monkeypatch):
         _check(gpu, oracle, Config.from_levels(d, q, lossy), chunks)
 
 
+def test_concurrent_scheduler_instances(gpu, oracle):
+    """Several handles driven from several host threads at once (what bench.py does) give the same blocks as one
+    handle alone: no state is shared between instances."""
+    import threading
+    cfg = Config.from_levels(3, 2)
+    batches = [[synth.illumina_fastq(6000, first=1 + 100000 * t + 6000 * k)[:-1] for k in range(3)] for t in range(3)]
+    want = []
+    for b in batches:
+        h = gpu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
+        want.append(h.compress_batch(b)); h.close()
+    assert want[0][0][0] == oracle.compress_block(cfg, batches[0][0])[0]
+    got = [None] * 3; errs = []
+
+    def work(t):
+        try:
+            for _ in range(3):          # a fresh handle each time: block-to-block state starts like `want`'s
+                h = gpu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
+                got[t] = h.compress_batch(batches[t])
+                h.close()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    for t in range(3):
+        assert [g[0] for g in got[t]] == [w[0] for w in want[t]]
+
+
 def test_device_synth_matches_host(gpu):
     h = gpu.Handle()
     cap = 2 << 20
