@@ -18,7 +18,8 @@ EXPORTS = [
     "dsrcgpu_create", "dsrcgpu_destroy", "dsrcgpu_last_error", "dsrcgpu_compress_block", "dsrcgpu_compress_batch",
     "dsrcgpu_compress_batch_device", "dsrcgpu_submit", "dsrcgpu_flush", "dsrcgpu_collect", "dsrcgpu_release",
     "dsrcgpu_last_timing", "dsrcgpu_synth_illumina", "dsrcgpu_dev_alloc", "dsrcgpu_dev_free", "dsrcgpu_dev_upload",
-    "dsrcgpu_dev_download",
+    "dsrcgpu_dev_download", "dsrcgpu_chain_create", "dsrcgpu_chain_destroy", "dsrcgpu_set_chain", "dsrcgpu_host_alloc",
+    "dsrcgpu_host_free",
 ]
 
 
@@ -58,8 +59,27 @@ def load():
     L.dsrcgpu_last_error.argtypes = [C.c_void_p]
     L.dsrcgpu_destroy.restype = None
     L.dsrcgpu_destroy.argtypes = [C.c_void_p]
+    L.dsrcgpu_chain_destroy.restype = None
+    L.dsrcgpu_chain_destroy.argtypes = [C.c_void_p]
+    L.dsrcgpu_set_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     _lib = L
     return L
+
+
+class Chain:
+    """Hands DSRC's block-to-block state from batch seq to batch seq+1 across handles (include/dsrc_gpu.h)."""
+
+    def __init__(self):
+        self.L = load()
+        self.c = C.c_void_p()
+        rc = self.L.dsrcgpu_chain_create(C.byref(self.c))
+        if rc != 0:
+            raise DsrcGpuError(rc, "dsrcgpu_chain_create failed")
+
+    def close(self):
+        if getattr(self, "c", None):
+            self.L.dsrcgpu_chain_destroy(self.c)
+            self.c = None
 
 
 class Handle:
@@ -94,6 +114,10 @@ class Handle:
         if rc < 0:
             raise DsrcGpuError(rc, self.L.dsrcgpu_last_error(self.h).decode())
         return rc
+
+    def set_chain(self, chain, seq: int):
+        """The next batch call on this handle is batch number `seq` of `chain` (None detaches)."""
+        self._chk(self.L.dsrcgpu_set_chain(self.h, chain.c if chain is not None else None, C.c_uint64(seq)))
 
     def compress_block(self, data: bytes):
         cap = len(data) + (1 << 16)

@@ -14,7 +14,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <condition_variable>
 #include <deque>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -51,6 +53,15 @@ struct Done { int64_t part_id; u8* block; u64 size; u64 raw[4]; u64 comp[4]; };
 
 } // namespace
 
+// block-to-block state handed from batch to batch when several handles work on one archive (include/dsrc_gpu.h)
+struct dsrcgpu_chain
+{
+	std::mutex m; std::condition_variable cv;
+	uint64_t next_seq = 0;           // the batch whose turn it is to read `fields_cap`
+	u32 fields_cap = 0;
+	bool failed = false;
+};
+
 struct dsrcgpu_handle
 {
 	dsrcgpu_settings set;
@@ -61,6 +72,8 @@ struct dsrcgpu_handle
 	Arena arena;
 	u64 arena_fixed = 0;
 	u32 fields_cap = 0;              // capacity of the reference's TagStats::fields vector, carried block to block
+	dsrcgpu_chain* chain = nullptr;  // if set: fields_cap comes from / goes to the chain, in batch order
+	uint64_t chain_seq = 0; bool chain_taken = false; u32 chain_cap_in = 0;
 	u32* d_crc_tab = nullptr;
 	u64* d_rc_magic = nullptr;      // ceil(2^48 / d), d < 65536 (k_rc)
 	std::string err;
@@ -222,17 +235,46 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	static const u32 QN[8] = {16, 32, 64, 128, 16, 32, 64, 128};
 	static const u32 ORD1[4] = {3, 2, 1, 1}, ORD2[4] = {4, 3, 2, 1};
 
+	// chained handles: take the state batch seq-1 left (once per batch, also when the batch is re-run with a larger
+	// arena), publish ours as soon as every chunk's field count has been folded in (below)
+	struct ChainTurn
+	{
+		dsrcgpu_handle* h; bool published = false;
+		~ChainTurn()
+		{
+			if (!h->chain || published) return;
+			std::lock_guard<std::mutex> g(h->chain->m);     // leaving without publishing = failure: release the waiters
+			h->chain->failed = true; h->chain->cv.notify_all();
+		}
+	} turn{h};
+	if (h->chain && !h->chain_taken)
+	{
+		std::unique_lock<std::mutex> g(h->chain->m);
+		h->chain->cv.wait(g, [&] { return h->chain->failed || h->chain->next_seq == h->chain_seq; });
+		if (h->chain->failed) { turn.published = true; return fail(h, DSRCGPU_E_STATE, "an earlier batch of the chain failed"); }
+		h->chain_cap_in = h->chain->fields_cap; h->chain_taken = true;
+	}
+	if (h->chain) h->fields_cap = h->chain_cap_in;
+	else turn.published = true;
+	for (u32 b = 0; b < B; ++b)
+	{	// TagStats::fields capacity emulation (see oracle/dsrc_oracle.c tags_init)
+		u32 cap = h->fields_cap; int last = -1;
+		for (u32 i = 0; i < st[b].n_fields; ++i) if (i == cap) { last = (int)i; cap = cap ? cap * 2 : 1; }
+		desc[b].fields_keep_from = last < 0 ? 0u : (u32)last;
+		h->fields_cap = cap;
+	}
+	if (h->chain && !turn.published)
+	{
+		std::lock_guard<std::mutex> g(h->chain->m);
+		if (h->chain->next_seq == h->chain_seq) { h->chain->fields_cap = h->fields_cap; h->chain->next_seq = h->chain_seq + 1; }
+		turn.published = true;
+		h->chain->cv.notify_all();
+	}
+
 	for (u32 b = 0; b < B; ++b)
 	{
 		const BlkState& S = st[b];
 		BlkDesc& D = desc[b];
-		// TagStats::fields capacity emulation (see oracle/dsrc_oracle.c tags_init)
-		{
-			u32 cap = h->fields_cap; int last = -1;
-			for (u32 i = 0; i < S.n_fields; ++i) if (i == cap) { last = (int)i; cap = cap ? cap * 2 : 1; }
-			D.fields_keep_from = last < 0 ? 0u : (u32)last;
-			h->fields_cap = cap;
-		}
 		// DNA scheme: DnaNormalModelerProxy / DnaOrderModelerProxy::SelectSchemeId (src/DnaModelerProxy.h:88-123,160-172)
 		if (S.d_count == 0) D.d_scheme = 255;
 		else if (dna_order == 0) D.d_scheme = S.d_count <= 4 ? 0 : 1;
@@ -407,8 +449,8 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			const u32 hi = std::min(NJ, g + 64);
 			u32 mx = 0; for (u32 i = g; i < hi; ++i) mx = std::max(mx, jobs[i].n);
 			const u32 pitch = (mx + 3) / 4 * 4 + 4;
-			if ((u64)pitch * 64 * sizeof(RcRec) >= (1ull << 32))
-				return fail(h, DSRCGPU_E_ARG, "chunks too large for the range-coder stage (64 streams exceed 4 GiB of records); use a smaller buffer size");
+			if ((u64)pitch * sizeof(RcRec) >= (1ull << 32))      // k_rc: 32-bit byte offsets inside one stream's array
+				return fail(h, DSRCGPU_E_ARG, "chunk too large for the range-coder stage (a stream of %u symbols exceeds 4 GiB of records); use a smaller buffer size", mx);
 			for (u32 i = g; i < hi; ++i) { cbase[i] = trip_words + (size_t)(i - g) * pitch; cpitch[i] = pitch; }
 			trip_words += (size_t)pitch * (hi - g);
 			if (hi == NJ) trip_words += pitch + RC_OVERREAD;               // over-read slack behind the last array
@@ -638,7 +680,23 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 
 // Arena sizes are estimated from the input sizes; if carving runs out (A.failed) the batch is simply
 // re-run with a larger arena.  Compressor state is restored so that the retry is invisible.
+// a batch that ends in an error before it has published its state must not leave the chain's later batches waiting
+void chain_abort(dsrcgpu_handle* h)
+{
+	if (!h->chain) return;
+	std::lock_guard<std::mutex> g(h->chain->m);
+	if (h->chain->next_seq <= h->chain_seq) { h->chain->failed = true; h->chain->cv.notify_all(); }
+}
+
+template <typename F> int with_arena_retry_(dsrcgpu_handle* h, size_t initial, F&& body);
 template <typename F> int with_arena_retry(dsrcgpu_handle* h, size_t initial, F&& body)
+{
+	const int rc = with_arena_retry_(h, initial, body);
+	if (rc != DSRCGPU_OK) chain_abort(h);
+	return rc;
+}
+
+template <typename F> int with_arena_retry_(dsrcgpu_handle* h, size_t initial, F&& body)
 {
 	size_t need = initial;
 	const u32 saved_cap = h->fields_cap;
@@ -839,6 +897,31 @@ int dsrcgpu_collect(dsrcgpu_handle* h, int64_t* part_id, uint8_t** block, uint64
 }
 
 int dsrcgpu_release(dsrcgpu_handle* h, uint8_t* block) { (void)h; free(block); return DSRCGPU_OK; }
+
+int dsrcgpu_chain_create(dsrcgpu_chain** out)
+{
+	if (!out) return DSRCGPU_E_ARG;
+	*out = new (std::nothrow) dsrcgpu_chain();
+	return *out ? DSRCGPU_OK : DSRCGPU_E_NOMEM;
+}
+
+void dsrcgpu_chain_destroy(dsrcgpu_chain* c) { delete c; }
+
+int dsrcgpu_set_chain(dsrcgpu_handle* h, dsrcgpu_chain* c, uint64_t seq)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	h->chain = c; h->chain_seq = seq; h->chain_taken = false;
+	return DSRCGPU_OK;
+}
+
+int dsrcgpu_host_alloc(uint64_t bytes, void** out)
+{
+	if (!out) return DSRCGPU_E_ARG;
+	*out = nullptr;
+	return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? DSRCGPU_OK : DSRCGPU_E_NOMEM;
+}
+
+int dsrcgpu_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? DSRCGPU_OK : DSRCGPU_E_HIP; }
 
 int dsrcgpu_last_timing(const dsrcgpu_handle* h, float* batch_ms, float* rc_ms, uint32_t* rc_launches)
 {

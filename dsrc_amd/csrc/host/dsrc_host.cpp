@@ -2,9 +2,20 @@
 #include "dsrc_host.h"
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <iomanip>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <sstream>
+#include <thread>
+#include <chrono>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "dsrc_gpu.h"
 
@@ -164,20 +175,89 @@ void ArchiveWriter::Finish(const fq::FastqDatasetType& type, const CompressionSe
 ArchiveWriter::~ArchiveWriter() { if (f) fclose(f); }
 
 // ---- operator -----------------------------------------------------------------------------------------------
-bool DsrcCompressorGPU::Process(const InputParameters& args)
+// File -> archive as a pipeline: the calling thread cuts chunk boundaries (two 8 KiB reads per chunk),
+// `instances` worker threads each own one GPU scheduler instance and, per batch, pread() their chunks straight into
+// page-locked memory, compress (host->device, kernels, device->host all on that instance's stream, overlapping the
+// other instances), and hand the blocks to the writer thread, which restores batch order.  The block-to-block state
+// travels through a dsrcgpu_chain, so the archive is the one a single instance -- and `dsrc c -t1` -- writes.
+namespace
 {
+struct Pinned
+{
+	uchar* p = nullptr; uint64 cap = 0;
+	void Reserve(uint64 n)
+	{
+		if (n <= cap) return;
+		if (p) dsrcgpu_host_free(p);
+		p = nullptr; cap = 0;
+		void* q = nullptr;
+		if (dsrcgpu_host_alloc(n, &q) != DSRCGPU_OK) throw DsrcException("cannot allocate page-locked host memory");
+		p = (uchar*)q; cap = n;
+	}
+	~Pinned() { if (p) dsrcgpu_host_free(p); }
+};
+
+struct Job          // one batch
+{
+	uint64 seq = 0;
+	std::vector<uint64> fileOff; std::vector<uint64_t> sizes;          // chunk i = file[fileOff[i], +sizes[i])
+	// filled by a reader thread
+	Pinned* in = nullptr; std::vector<uint64> at; uint64 inBytes = 0;
+	// results
+	Pinned* out = nullptr;
+	std::vector<uint64_t> offs, osz, raw, comp;
+};
+
+struct Pipeline
+{
+	std::mutex m; std::condition_variable cv;
+	std::deque<Job*> todo; bool noMore = false;          // cut, waiting for a reader
+	std::map<uint64, Job*> ready; uint64 nextStart = 0;  // read into page-locked memory, waiting for a scheduler instance (taken in order)
+	std::vector<Pinned*> freeIn;                         // input buffers not in use
+	std::map<uint64, Job*> done;
+	std::string error;
+	bool Failed() { std::lock_guard<std::mutex> g(m); return !error.empty(); }
+	void Fail(const std::string& e) { std::lock_guard<std::mutex> g(m); if (error.empty()) error = e; cv.notify_all(); }
+};
+
+// chunk boundaries of a regular file, same decisions as FastqChunker::ReadNextChunk
+struct FileCutter
+{
+	int fd; uint64 fileSize, bufSize, pos = 0, bufEnd = 0; bool eof = false, crlf = false, first = true;
+	std::vector<uchar> win;
+	FileCutter(int fd_, uint64 size_, uint64 buf_) : fd(fd_), fileSize(size_), bufSize(buf_), win(8192) {}
+	bool Next(uint64& start, uint64& size)
+	{
+		if (eof) return false;
+		const uint64 rem = fileSize - pos;
+		start = pos;
+		if (rem >= bufSize)
+		{
+			if (pread(fd, win.data(), 8192, (off_t)(pos + bufSize - 8192)) != 8192) throw DsrcException("read error");
+			const uint64 end = FastqChunker::NextRecordPos(win.data() - (bufSize - 8192), bufSize - 8192, bufSize, crlf);
+			size = end - 1 - (crlf ? 1 : 0);
+			bufEnd = pos + bufSize; pos += end; first = false;
+			return true;
+		}
+		eof = true;
+		const uint64 have = first ? 0 : bufEnd - pos;          // bytes the stream reader would have carried over
+		if (rem == have) { size = have; return true; }          // nothing left to read: the carried bytes as they are
+		size = rem - 1 - (crlf ? 1 : 0);
+		return true;
+	}
+};
+} // namespace
+
+bool DsrcCompressorGPU::ProcessStream(const InputParameters& args, FILE* in)
+{	// stdin: one scheduler instance, batches one after the other
 	dsrcgpu_handle* h = nullptr;
-	FILE* in = nullptr;
 	try
 	{
-		in = args.useFastqStdIo ? stdin : fopen(args.inputFilename.c_str(), "rb");
-		if (!in) throw DsrcException("Cannot open file to read:" + args.inputFilename);
 		const CompressionSettings settings = GetCompressionSettings(args);
 		const uint64 bufSize = (uint64)args.fastqBufferSizeMB << 20;
 		FastqChunker chunker(in, bufSize);
 		ArchiveWriter writer;
 		writer.Start(args.outputFilename);
-
 		std::vector<std::vector<uchar>> chunks;
 		chunks.emplace_back();
 		fq::FastqDatasetType type;
@@ -185,15 +265,7 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 		if (!findOffset) type.qualityOffset = args.qualityOffset;
 		if (!chunker.ReadNextChunk(chunks[0]) || !AnalyzeFirstChunk(chunks[0].data(), chunks[0].size(), type, findOffset))
 			throw DsrcException("Error analyzing FASTQ dataset");
-
-		dsrcgpu_settings gs; memset(&gs, 0, sizeof(gs));
-		gs.dna_order = settings.dnaOrder; gs.quality_order = settings.qualityOrder; gs.tag_preserve_flags = settings.tagPreserveFlags;
-		gs.lossy = settings.lossy; gs.calculate_crc32 = settings.calculateCrc32;
-		dsrcgpu_dataset gd; memset(&gd, 0, sizeof(gd));
-		gd.quality_offset = type.qualityOffset; gd.plus_repetition = type.plusRepetition; gd.color_space = type.colorSpace;
-		if (dsrcgpu_create(&gs, &gd, args.device, 0, &h) != DSRCGPU_OK)
-			throw DsrcException(std::string(h ? dsrcgpu_last_error(h) : "cannot create the GPU compressor"));
-
+		h = CreateInstance(args, settings, type);
 		const uint32 batch = args.batchBlocks ? args.batchBlocks : (uint32)std::max<uint64>(1, (2048ull << 20) / bufSize);
 		bool more = true;
 		while (more || !chunks.empty())
@@ -211,29 +283,294 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 			std::vector<uchar> out(cap);
 			if (dsrcgpu_compress_batch(h, n, ptrs.data(), sizes.data(), out.data(), cap, offs.data(), osz.data(), raw.data(), comp.data()) != DSRCGPU_OK)
 				throw DsrcException(dsrcgpu_last_error(h));
-			for (uint32 i = 0; i < n; ++i)
-			{
-				uint64 r4[4], c4[4];
-				for (int k = 0; k < 4; ++k) { r4[k] = raw[4 * i + k]; c4[k] = comp[4 * i + k]; }
-				writer.WriteBlock(out.data() + offs[i], osz[i], r4, c4);
-			}
+			for (uint32 i = 0; i < n; ++i) writer.WriteBlock(out.data() + offs[i], osz[i], (const uint64*)&raw[4 * i], (const uint64*)&comp[4 * i]);
 			chunks.clear();
 		}
 		writer.Finish(type, settings);
-
-		std::ostringstream ss;          // same text as the reference's -v log (src/DsrcOperator.cpp:362-375)
-		const fq::StreamsInfo& rawS = writer.Raw(); const fq::StreamsInfo& compS = writer.Comp();
-		ss << "Compressed streams sizes (in bytes)\n";
-		ss << "TAG: " << std::setw(16) << compS.sizes[fq::StreamsInfo::MetaStream] + compS.sizes[fq::StreamsInfo::TagStream]
-		   << " / " << std::setw(16) << rawS.sizes[fq::StreamsInfo::TagStream] << '\n';
-		ss << "DNA: " << std::setw(16) << compS.sizes[fq::StreamsInfo::DnaStream] << " / " << std::setw(16) << rawS.sizes[fq::StreamsInfo::DnaStream] << '\n';
-		ss << "QUA: " << std::setw(16) << compS.sizes[fq::StreamsInfo::QualityStream] << " / " << std::setw(16) << rawS.sizes[fq::StreamsInfo::QualityStream] << '\n';
-		AddLog(ss.str());
+		LogSizes(writer);
 	}
 	catch (const DsrcException& e) { AddError(e.what()); }
 	catch (const std::exception& e) { AddError(e.what()); }
 	if (h) dsrcgpu_destroy(h);
-	if (in && in != stdin) fclose(in);
+	return !IsError();
+}
+
+dsrcgpu_handle* DsrcCompressorGPU::CreateInstance(const InputParameters& args, const CompressionSettings& settings, const fq::FastqDatasetType& type)
+{
+	dsrcgpu_settings gs; memset(&gs, 0, sizeof(gs));
+	gs.dna_order = settings.dnaOrder; gs.quality_order = settings.qualityOrder; gs.tag_preserve_flags = settings.tagPreserveFlags;
+	gs.lossy = settings.lossy; gs.calculate_crc32 = settings.calculateCrc32;
+	dsrcgpu_dataset gd; memset(&gd, 0, sizeof(gd));
+	gd.quality_offset = type.qualityOffset; gd.plus_repetition = type.plusRepetition; gd.color_space = type.colorSpace;
+	dsrcgpu_handle* h = nullptr;
+	if (dsrcgpu_create(&gs, &gd, args.device, 0, &h) != DSRCGPU_OK)
+	{
+		const std::string msg = h ? dsrcgpu_last_error(h) : "cannot create the GPU compressor";
+		if (h) dsrcgpu_destroy(h);
+		throw DsrcException(msg);
+	}
+	return h;
+}
+
+void DsrcCompressorGPU::LogSizes(const ArchiveWriter& writer)
+{
+	std::ostringstream ss;          // same text as the reference's -v log (src/DsrcOperator.cpp:362-375)
+	const fq::StreamsInfo& rawS = writer.Raw(); const fq::StreamsInfo& compS = writer.Comp();
+	ss << "Compressed streams sizes (in bytes)\n";
+	ss << "TAG: " << std::setw(16) << compS.sizes[fq::StreamsInfo::MetaStream] + compS.sizes[fq::StreamsInfo::TagStream]
+	   << " / " << std::setw(16) << rawS.sizes[fq::StreamsInfo::TagStream] << '\n';
+	ss << "DNA: " << std::setw(16) << compS.sizes[fq::StreamsInfo::DnaStream] << " / " << std::setw(16) << rawS.sizes[fq::StreamsInfo::DnaStream] << '\n';
+	ss << "QUA: " << std::setw(16) << compS.sizes[fq::StreamsInfo::QualityStream] << " / " << std::setw(16) << rawS.sizes[fq::StreamsInfo::QualityStream] << '\n';
+	AddLog(ss.str());
+}
+
+bool DsrcCompressorGPU::Process(const InputParameters& args)
+{
+	if (args.useFastqStdIo) return ProcessStream(args, stdin);
+	int fd = -1;
+	dsrcgpu_chain* chain = nullptr;
+	std::vector<std::thread> workers, readers;
+	std::thread writerThread;
+	Pipeline pl;
+	// everything the threads refer to outlives them (they are joined at the bottom, also on errors)
+	fq::FastqDatasetType type;
+	CompressionSettings settings;
+	ArchiveWriter writer;
+	std::vector<std::unique_ptr<Pinned>> inBufs;
+	uint64 totalBatches = ~0ull;                     // known once the cutter is through (guarded by pl.m)
+	try
+	{
+		fd = open(args.inputFilename.c_str(), O_RDONLY);
+		struct stat sb;
+		if (fd < 0 || fstat(fd, &sb) != 0) throw DsrcException("Cannot open file to read:" + args.inputFilename);
+		if (!S_ISREG(sb.st_mode))
+		{	// pipes and devices go through the stream reader
+			close(fd); fd = -1;
+			FILE* f = fopen(args.inputFilename.c_str(), "rb");
+			if (!f) throw DsrcException("Cannot open file to read:" + args.inputFilename);
+			const bool ok = ProcessStream(args, f);
+			fclose(f);
+			return ok;
+		}
+		const uint64 fileSize = (uint64)sb.st_size;
+		settings = GetCompressionSettings(args);
+		const uint64 bufSize = (uint64)args.fastqBufferSizeMB << 20;
+		FileCutter cutter(fd, fileSize, bufSize);
+
+		// first chunk: dataset analysis (FastqParser::Analyze)
+		uint64 start0 = 0, size0 = 0;
+		const bool findOffset = args.qualityOffset == fq::FastqDatasetType::AutoQualityOffset;
+		if (!findOffset) type.qualityOffset = args.qualityOffset;
+		{
+			if (!cutter.Next(start0, size0)) throw DsrcException("Error analyzing FASTQ dataset");
+			std::vector<uchar> first(size0);
+			if (size0 && pread(fd, first.data(), size0, (off_t)start0) != (ssize_t)size0) throw DsrcException("read error");
+			if (!AnalyzeFirstChunk(first.data(), first.size(), type, findOffset)) throw DsrcException("Error analyzing FASTQ dataset");
+		}
+
+		const uint32 batch = args.batchBlocks ? args.batchBlocks : (uint32)std::max<uint64>(1, (1536ull << 20) / bufSize);
+		const uint64 nBatchesMax = (fileSize / bufSize + batch) / batch;
+		const uint32 instances = (uint32)std::max<uint64>(1, std::min<uint64>(std::min<uint32>(std::max(1u, args.threadNum), 8u), nBatchesMax));
+		if (dsrcgpu_chain_create(&chain) != DSRCGPU_OK) throw DsrcException("cannot create the batch chain");
+		writer.Start(args.outputFilename);
+
+		const bool trace = getenv("DSRC_HOST_TRACE") != nullptr;
+		const auto tStart = std::chrono::steady_clock::now();
+		// ---- workers ------------------------------------------------------------------------------------------
+		auto work = [&](uint32 /*idx*/)
+		{
+			dsrcgpu_handle* h = nullptr;
+			Pinned out[2];
+			std::vector<Job*> inFlight(2, nullptr);       // the job whose blocks still sit in out[k]
+			try
+			{
+				h = CreateInstance(args, settings, type);
+				for (uint32 turn = 0;; ++turn)
+				{
+					Job* job = nullptr;
+					{	// batches start in order: the chain makes batch s+1 wait for batch s early in its course
+						std::unique_lock<std::mutex> g(pl.m);
+						pl.cv.wait(g, [&] { return !pl.error.empty() || pl.ready.count(pl.nextStart) || (pl.noMore && pl.nextStart >= totalBatches); });
+						if (!pl.error.empty() || !pl.ready.count(pl.nextStart)) break;
+						job = pl.ready[pl.nextStart]; pl.ready.erase(pl.nextStart); ++pl.nextStart;
+						pl.cv.notify_all();
+					}
+					const auto t0 = std::chrono::steady_clock::now();
+					const uint32 n = (uint32)job->sizes.size();
+					const uint64 inBytes = job->inBytes;
+					std::vector<const uint8_t*> ptrs(n);
+					for (uint32 i = 0; i < n; ++i) ptrs[i] = job->in->p + job->at[i];
+					const auto t1 = t0;
+					// the output buffer of two batches ago must have been written out
+					Pinned& ob = out[turn & 1];
+					{
+						std::unique_lock<std::mutex> g(pl.m);
+						pl.cv.wait(g, [&] { return !pl.error.empty() || inFlight[turn & 1] == nullptr || inFlight[turn & 1]->out == nullptr; });
+						if (!pl.error.empty()) { delete job; break; }
+					}
+					delete inFlight[turn & 1]; inFlight[turn & 1] = nullptr;
+					uint64 cap = inBytes * 2 / 5 + (uint64)n * (1u << 16);     // typical ratio 0.2-0.33; grown below if the data needs it
+					job->offs.resize(n); job->osz.resize(n); job->raw.resize(4 * n); job->comp.resize(4 * n);
+					int rc;
+					for (;;)
+					{
+						ob.Reserve(cap);
+						dsrcgpu_set_chain(h, chain, job->seq);
+						rc = dsrcgpu_compress_batch(h, n, ptrs.data(), job->sizes.data(), ob.p, ob.cap, job->offs.data(), job->osz.data(), job->raw.data(), job->comp.data());
+						if (rc != DSRCGPU_E_CAPACITY || cap >= inBytes + (uint64)n * (1u << 16)) break;
+						cap = inBytes + (uint64)n * (1u << 16);        // incompressible input: room for the worst case, once
+					}
+					{
+						std::lock_guard<std::mutex> g(pl.m);
+						pl.freeIn.push_back(job->in); job->in = nullptr;
+						pl.cv.notify_all();
+					}
+					if (rc != DSRCGPU_OK) { const std::string e = dsrcgpu_last_error(h); delete job; throw DsrcException(e); }
+					if (trace)
+					{
+						const auto t2 = std::chrono::steady_clock::now();
+						auto ms = [&](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+						fprintf(stderr, "[dsrc-amd] batch %llu (%u chunks, %.2f GB): start %.0f ms, compress %.0f ms\n", (unsigned long long)job->seq, n, inBytes / 1e9, ms(tStart, t0), ms(t1, t2));
+					}
+					job->out = &ob; inFlight[turn & 1] = job;
+					{
+						std::lock_guard<std::mutex> g(pl.m);
+						pl.done[job->seq] = job;
+						pl.cv.notify_all();
+					}
+				}
+				// blocks still owned by the writer
+				std::unique_lock<std::mutex> g(pl.m);
+				pl.cv.wait(g, [&] { return !pl.error.empty() || ((!inFlight[0] || !inFlight[0]->out) && (!inFlight[1] || !inFlight[1]->out)); });
+			}
+			catch (const std::exception& e) { pl.Fail(e.what()); }
+			for (Job* j : inFlight) if (j && !j->out) delete j;
+			if (h) dsrcgpu_destroy(h);
+		};
+		for (uint32 i = 0; i < instances; ++i) workers.emplace_back(work, i);
+
+		// ---- readers: file -> page-locked memory, ahead of the scheduler instances -----------------------------------
+		const uint32 nReaders = std::min<uint32>(2, instances);
+		for (uint32 i = 0; i < instances + 1; ++i) { inBufs.emplace_back(new Pinned()); pl.freeIn.push_back(inBufs.back().get()); }
+		auto readLoop = [&]()
+		{
+			try
+			{
+				for (;;)
+				{
+					Job* job = nullptr; Pinned* buf = nullptr;
+					{
+						std::unique_lock<std::mutex> g(pl.m);
+						pl.cv.wait(g, [&] { return !pl.error.empty() || (!pl.todo.empty() && !pl.freeIn.empty()) || (pl.noMore && pl.todo.empty()); });
+						if (!pl.error.empty() || pl.todo.empty()) return;
+						job = pl.todo.front(); pl.todo.pop_front();
+						buf = pl.freeIn.back(); pl.freeIn.pop_back();
+						pl.cv.notify_all();
+					}
+					const uint32 n = (uint32)job->sizes.size();
+					job->at.resize(n); job->inBytes = 0;
+					for (uint32 i = 0; i < n; ++i) { job->at[i] = job->inBytes; job->inBytes += (job->sizes[i] + 4096) & ~(uint64)4095; }
+					buf->Reserve(job->inBytes);
+					for (uint32 i = 0; i < n; ++i)
+					{
+						uint64 got = 0;
+						while (got < job->sizes[i])
+						{
+							const ssize_t r = pread(fd, buf->p + job->at[i] + got, job->sizes[i] - got, (off_t)(job->fileOff[i] + got));
+							if (r <= 0) throw DsrcException("read error");
+							got += (uint64)r;
+						}
+					}
+					job->in = buf;
+					std::lock_guard<std::mutex> g(pl.m);
+					pl.ready[job->seq] = job;
+					pl.cv.notify_all();
+				}
+			}
+			catch (const std::exception& e) { pl.Fail(e.what()); }
+		};
+		for (uint32 i = 0; i < nReaders; ++i) readers.emplace_back(readLoop);
+
+		// ---- writer: batches in order ---------------------------------------------------------------------------
+		writerThread = std::thread([&]()
+		{
+			try
+			{
+				for (uint64 next = 0;; ++next)
+				{
+					Job* job = nullptr;
+					{
+						std::unique_lock<std::mutex> g(pl.m);
+						pl.cv.wait(g, [&] { return !pl.error.empty() || pl.done.count(next) || next >= totalBatches; });
+						if (!pl.error.empty() || next >= totalBatches) return;
+						job = pl.done[next]; pl.done.erase(next);
+					}
+					const uint32 n = (uint32)job->sizes.size();
+					for (uint32 i = 0; i < n; ++i) writer.WriteBlock(job->out->p + job->offs[i], job->osz[i], (const uint64*)&job->raw[4 * i], (const uint64*)&job->comp[4 * i]);
+					{
+						std::lock_guard<std::mutex> g(pl.m);
+						job->out = nullptr;                    // the worker may reuse the buffer (and frees the job)
+						pl.cv.notify_all();
+					}
+				}
+			}
+			catch (const std::exception& e) { pl.Fail(e.what()); }
+		});
+
+		// ---- cutter (this thread) -------------------------------------------------------------------------------
+		uint64 seq = 0;
+		bool more = true;
+		uint64 start = start0, size = size0;
+		bool havePending = true;
+		while (more && !pl.Failed())
+		{
+			Job* job = new Job(); job->seq = seq;
+			while (job->sizes.size() < batch)
+			{
+				if (!havePending) { if (!cutter.Next(start, size)) { more = false; break; } }
+				havePending = false;
+				job->fileOff.push_back(start); job->sizes.push_back(size);
+			}
+			if (job->sizes.empty()) { delete job; break; }
+			{
+				std::unique_lock<std::mutex> g(pl.m);
+				pl.cv.wait(g, [&] { return !pl.error.empty() || pl.todo.size() < 2 * instances; });
+				pl.todo.push_back(job); ++seq;
+				pl.cv.notify_all();
+			}
+		}
+		{
+			std::lock_guard<std::mutex> g(pl.m);
+			pl.noMore = true; totalBatches = seq;
+			pl.cv.notify_all();
+		}
+		auto stamp = [&](const char* what) { if (trace) fprintf(stderr, "[dsrc-amd] %s at %.0f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tStart).count()); };
+		stamp("cutter done");
+		writerThread.join();
+		stamp("writer done");
+		for (auto& t : workers) t.join();
+		for (auto& t : readers) t.join();
+		workers.clear(); readers.clear();
+		stamp("instances released");
+		if (!pl.error.empty()) throw DsrcException(pl.error);
+		writer.Finish(type, settings);
+		LogSizes(writer);
+		inBufs.clear();
+		stamp("archive closed, buffers released");
+	}
+	catch (const DsrcException& e) { AddError(e.what()); pl.Fail(e.what()); }
+	catch (const std::exception& e) { AddError(e.what()); pl.Fail(e.what()); }
+	{
+		std::lock_guard<std::mutex> g(pl.m);
+		pl.noMore = true; pl.cv.notify_all();
+	}
+	if (writerThread.joinable()) writerThread.join();
+	for (auto& t : workers) if (t.joinable()) t.join();
+	for (auto& t : readers) if (t.joinable()) t.join();
+	for (Job* j : pl.todo) delete j;
+	for (auto& kv : pl.ready) delete kv.second;
+	if (chain) dsrcgpu_chain_destroy(chain);
+	if (fd >= 0) close(fd);
 	return !IsError();
 }
 

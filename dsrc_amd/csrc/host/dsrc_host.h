@@ -18,6 +18,8 @@
 #include <string>
 #include <vector>
 
+struct dsrcgpu_handle;
+
 namespace dsrc
 {
 
@@ -69,7 +71,7 @@ struct InputParameters          // src/Common.h:149-193, plus the GPU knobs at t
 	uint32 qualityOffset = 0;
 	uint32 dnaCompressionLevel = 0;
 	uint32 qualityCompressionLevel = 0;
-	uint32 threadNum = 2;          // kept for source compatibility; the GPU scheduler ignores it
+	uint32 threadNum = 4;          // here: GPU scheduler instances (host threads) working on consecutive batches, 1..8
 	uint64 tagPreserveFlags = 0;
 	uint32 fastqBufferSizeMB = 8;
 	bool lossyCompression = false;
@@ -79,7 +81,7 @@ struct InputParameters          // src/Common.h:149-193, plus the GPU knobs at t
 	std::string outputFilename;
 	// GPU path
 	int device = 0;
-	uint32 batchBlocks = 0;        // chunks per scheduler pass; 0 = as many as fit ~2 GiB of input
+	uint32 batchBlocks = 0;        // chunks per scheduler pass; 0 = as many as fit ~1.5 GiB of input
 };
 
 class IDsrcOperator
@@ -103,10 +105,15 @@ protected:
 };
 
 // Drop-in for DsrcCompressorMT / DsrcCompressorST (src/DsrcOperator.cpp:55-395)
+class ArchiveWriter;
 class DsrcCompressorGPU : public IDsrcOperator
 {
 public:
 	bool Process(const InputParameters& args_);
+private:
+	bool ProcessStream(const InputParameters& args_, FILE* in_);      // stdin / pipes: one scheduler instance
+	static dsrcgpu_handle* CreateInstance(const InputParameters& args_, const CompressionSettings& settings_, const fq::FastqDatasetType& type_);
+	void LogSizes(const ArchiveWriter& writer_);
 };
 
 // ---- pieces (exposed for tests) -----------------------------------------------------------------------------
@@ -118,12 +125,12 @@ public:
 	FastqChunker(FILE* f, uint64 bufferSize);
 	// returns false at end of input; chunk.size() is FastqDataChunk::size (final newline not included)
 	bool ReadNextChunk(std::vector<uchar>& chunk);
+	static uint64 NextRecordPos(const uchar* d, uint64 pos, uint64 size, bool& crlf);
 private:
 	FILE* file;
 	uint64 bufSize;
 	std::vector<uchar> carry;
 	bool eof = false, usesCrlf = false;
-	static uint64 NextRecordPos(const uchar* d, uint64 pos, uint64 size, bool& crlf);
 };
 
 // FastqParser::Analyze (src/FastqParser.cpp:27-138)

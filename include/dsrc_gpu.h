@@ -99,6 +99,23 @@ int dsrcgpu_collect(dsrcgpu_handle* h, int64_t* part_id, uint8_t** block, uint64
 					uint64_t raw_sizes[4], uint64_t comp_sizes[4]);
 int dsrcgpu_release(dsrcgpu_handle* h, uint8_t* block);
 
+/* Several handles may compress consecutive batches of ONE archive at the same time (one host thread each); this is
+ * what hides the serial range-coder stage.  The only state DSRC carries from block to block -- the capacity of
+ * TagStats::fields inside one BlockCompressor (src/TagModeler.h:124) -- is then handed from
+ * batch `seq` to batch `seq + 1` through a chain, so the blocks equal those of a single handle fed in order, i.e.
+ * `dsrc c -t1`.  dsrcgpu_set_chain(h, chain, seq) declares that the NEXT batch call on h is batch number `seq`
+ * (0, 1, 2, ... without gaps across all handles of the chain); that call waits, early in its course, for batch
+ * seq - 1 to have published the state.  A batch that fails marks the chain failed and releases the waiters. */
+typedef struct dsrcgpu_chain dsrcgpu_chain;
+int dsrcgpu_chain_create(dsrcgpu_chain** out);
+void dsrcgpu_chain_destroy(dsrcgpu_chain* c);
+int dsrcgpu_set_chain(dsrcgpu_handle* h, dsrcgpu_chain* c, uint64_t seq);
+
+/* Page-locked host memory for chunk / block buffers: host<->device copies from it run at PCIe speed and
+ * asynchronously to the other handles' kernels (the entry points accept any host pointer; pageable ones are slower). */
+int dsrcgpu_host_alloc(uint64_t bytes, void** out);
+int dsrcgpu_host_free(void* p);
+
 /* Timing of the last batch measured with HIP events on the scheduler's stream: total ms of the batch's
  * kernels, ms of the range-coder kernel (k_rc), number of k_rc launches. */
 int dsrcgpu_last_timing(const dsrcgpu_handle* h, float* batch_ms, float* rc_ms, uint32_t* rc_launches);

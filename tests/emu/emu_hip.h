@@ -135,6 +135,7 @@ template <typename T> inline hipError_t hipMalloc(T** p, size_t n) { return hipM
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return hipSuccess; }
 template <typename T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipHostMalloc((void**)p, n, f); }
+enum { hipHostMallocDefault = 0 };
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = 0) { memcpy(d, s, n); return hipSuccess; }

@@ -97,6 +97,44 @@ def test_batch_state_and_queue_api(emu, oracle):
         assert got[i][2] == list(raw) and got[i][3] == list(comp)
 
 
+def test_chain_hands_state_between_handles(emu, oracle):
+    """Two handles taking consecutive batches of one archive through a chain give the blocks of one handle fed in
+    order (the reference's -t1 history of TagStats::fields' capacity)."""
+    import ctypes as C
+    from tests._oracle import _orc_cfg
+    # field counts 5, 9, 9, 17: the capacity grows across batches
+    import random
+    rng = random.Random(11)
+
+    def fq(nf, n, first):
+        recs = []
+        for i in range(n):
+            title = f"@r.{first + i}" + "".join(f":{(7 * i + k) % 90 + 10}" for k in range(nf - 2))
+            seq = "".join(rng.choice("ACGT") for _ in range(40))
+            qua = "".join(chr(33 + rng.randint(20, 40)) for _ in range(40))
+            recs.append(f"{title}\n{seq}\n+\n{qua}")
+        return "\n".join(recs).encode()
+    chunks = [fq(5, 30, 1), fq(9, 30, 100), fq(9, 30, 200), fq(17, 30, 300)]
+    cfg = Config.from_levels(0, 0)
+    want = []
+    cap = C.c_uint32(0); c = _orc_cfg(cfg)
+    for ch in chunks:
+        out = (C.c_uint8 * (len(ch) + 65536))(); osz = C.c_uint64(); raw = (C.c_uint64 * 4)(); comp = (C.c_uint64 * 4)()
+        assert oracle.lib.orc_compress_block_state(C.byref(c), C.byref(cap), ch, C.c_uint64(len(ch)), out, C.c_uint64(len(out)), C.byref(osz), raw, comp) == 0
+        want.append(bytes(out[:osz.value]))
+    chain = emu.Chain()
+    ha = emu.Handle(cfg.dna_order, cfg.quality_order); hb = emu.Handle(cfg.dna_order, cfg.quality_order)
+    ha.set_chain(chain, 0); got = [r[0] for r in ha.compress_batch(chunks[:2])]
+    hb.set_chain(chain, 1); got += [r[0] for r in hb.compress_batch(chunks[2:3])]
+    ha.set_chain(chain, 2); got += [r[0] for r in ha.compress_batch(chunks[3:])]
+    ha.close(); hb.close(); chain.close()
+    assert got == want
+    # without the chain the second handle starts from an empty history and (for this input) codes differently
+    hc = emu.Handle(cfg.dna_order, cfg.quality_order)
+    alone = hc.compress_batch(chunks[2:3])[0][0]; hc.close()
+    assert alone != want[2]
+
+
 def test_hot_contexts_rescale(emu, oracle):
     """One context with ~40k symbols: exercises the epoch/rescale path of k_replay and multi-wave ranges."""
     import random

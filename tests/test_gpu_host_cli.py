@@ -57,3 +57,17 @@ def test_iontorrent_lossy_archive_identical(files):
     _run([CLI, "c", "-d2", "-q1", "-l", "-b1", ion, ours])
     _run([REF_BIN, "c", "-d2", "-q1", "-l", "-b1", "-t1", ion, theirs])
     assert md5(ours) == md5(theirs)
+
+
+@pytest.mark.parametrize("flags,which", [(["-d3", "-q2"], "ill"), (["-d0", "-q1"], "ion"), (["-d2", "-q1", "-l"], "ion")])
+def test_pipelined_instances_write_the_t1_archive(files, flags, which):
+    """Several scheduler instances on consecutive small batches (-n2 chunks per batch, -t4 instances): the chain hands
+    the block-to-block state along, so the archive is still the one `dsrc c -t1` writes."""
+    if not os.path.exists(CLI) or not os.path.exists(REF_BIN):
+        pytest.skip("CLI missing")
+    d, ill, ion = files
+    src = ill if which == "ill" else ion
+    ours = str(d / "p.dsrc"); theirs = str(d / "pr.dsrc")
+    _run([CLI, "c", *flags, "-b1", "-n2", "-t4", src, ours])
+    _run([REF_BIN, "c", *flags, "-b1", "-t1", src, theirs])
+    assert md5(ours) == md5(theirs)

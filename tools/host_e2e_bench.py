@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""File -> archive throughput of the dsrc-amd CLI (C++ host pipeline over the C ABI, PCIe and file I/O included),
+next to the reference CLI on the same file.  Input: the synthetic Illumina set written to tmpfs.
+Usage: tools/host_e2e_bench.py [GB of input, default 6] [instances, default 4]"""
+import hashlib
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+from dsrc_amd._lib import Handle  # noqa: E402
+
+CLI = os.path.join(ROOT, "dsrc_amd", "csrc", "dsrc-amd")
+REF = os.path.join(ROOT, "oracle", "_ref", "dsrc_ref")
+
+
+def md5(path):
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for b in iter(lambda: f.read(1 << 24), b""):
+            h.update(b)
+    return h.hexdigest()
+
+
+def main():
+    gb = float(sys.argv[1]) if len(sys.argv) > 1 else 6.0
+    inst = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    d = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+    src = os.path.join(d, "e2e.fastq"); ours = os.path.join(d, "e2e_ours.dsrc"); theirs = os.path.join(d, "e2e_ref.dsrc")
+    h = Handle()
+    recs_per_piece = 2_000_000
+    total = 0; first = 1
+    with open(src, "wb") as f:
+        while total < gb * 1e9:
+            cap = recs_per_piece * 400
+            dptr = h.dev_alloc(cap)
+            n = h.synth_illumina(first, recs_per_piece, dptr, cap)
+            f.write(h.dev_download(dptr, n)); h.dev_free(dptr)
+            total += n; first += recs_per_piece
+    h.close()
+    size = os.path.getsize(src)
+    res = {}
+    extra = sys.argv[3:]          # e.g. -n384, or several instance counts as "-t6"
+    runs = [("dsrc-amd -t%d %s" % (inst, " ".join(extra)), [CLI, "c", "-d3", "-q2", f"-t{inst}", *extra, src, ours])]
+    runs.append((runs[0][0] + " (2nd run)", runs[0][1]))
+    if not os.environ.get("E2E_NO_REF"):
+        runs.append(("reference -t60", [REF, "c", "-d3", "-q2", "-t60", src, theirs]))
+    for name, cmd in runs:
+        if not os.path.exists(cmd[0]):
+            continue
+        t = time.time(); subprocess.check_call(cmd); dt = time.time() - t
+        res[name] = size / dt / 1e6
+        print(f"{name:30s}: {size / 1e9:.2f} GB in {dt:6.2f} s = {size / dt / 1e6:8.1f} MB/s")
+    if os.path.exists(theirs):
+        same = md5(ours) == md5(theirs)
+        print("archives identical:", same)
+        assert same
+    for p in (src, ours, theirs):
+        if os.path.exists(p):
+            os.remove(p)
+
+
+if __name__ == "__main__":
+    main()
