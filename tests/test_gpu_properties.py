@@ -82,3 +82,29 @@ def test_full_size_blocks(gpu, oracle, d, q):
     assert blob2[o2[0][2]: o2[0][2] + o2[1][2]] == blob[o_offs[3]: o_offs[3] + o_sizes[3]]
     h2.close()
     h.dev_free(d_in); h.dev_free(d_out); h.close()
+
+
+def test_large_chunks_and_mixed_sizes(gpu, oracle):
+    """Chunk sizes other than the default 8 MiB in one batch (a 40 MB chunk = `-b40`, a 1 MB one, a 300-byte one):
+    the range-coder stage lays the streams of a wave out with the longest stream's pitch."""
+    bench = _bench_helpers()
+    cfg = Config.from_levels(3, 2)
+    h = gpu.Handle(cfg.dna_order, cfg.quality_order)
+    recs = 125000
+    cap = recs * 384
+    d_in = h.dev_alloc(cap); d_out = h.dev_alloc(cap)
+    first = 7
+    nbytes = h.synth_illumina(first, recs, d_in, cap)
+    off = bench.record_offsets(first, recs)
+    assert off[-1] == nbytes
+    cuts = [0, 105000, 107800, 107801, 125000]                  # records per chunk: 105000 (~40 MB), 2800, 1, 17199
+    starts = [int(off[a]) for a in cuts[:-1]]; sizes = [int(off[b] - off[a] - 1) for a, b in zip(cuts[:-1], cuts[1:])]
+    o_offs, o_sizes, raw, comp = h.compress_batch_device(d_in, starts, sizes, d_out, cap)
+    blob = h.dev_download(d_out, o_offs[-1] + o_sizes[-1])
+    capst = C.c_uint32(0); c = _orc_cfg(cfg)
+    for i in range(len(starts)):
+        ch = h.dev_download(d_in + starts[i], sizes[i])
+        out = (C.c_uint8 * (len(ch) + 65536))(); osz = C.c_uint64(); r4 = (C.c_uint64 * 4)(); c4 = (C.c_uint64 * 4)()
+        assert oracle.lib.orc_compress_block_state(C.byref(c), C.byref(capst), ch, C.c_uint64(len(ch)), out, C.c_uint64(len(out)), C.byref(osz), r4, c4) == 0
+        assert blob[o_offs[i]: o_offs[i] + o_sizes[i]] == bytes(out[:osz.value]), f"chunk {i} ({sizes[i]} bytes)"
+    h.dev_free(d_in); h.dev_free(d_out); h.close()
