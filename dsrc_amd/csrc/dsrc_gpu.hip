@@ -797,6 +797,7 @@ int dsrcgpu_create(const dsrcgpu_settings* settings, const dsrcgpu_dataset* data
 void dsrcgpu_destroy(dsrcgpu_handle* h)
 {
 	if (!h) return;
+	(void)hipSetDevice(h->device);
 	for (auto& d : h->done) free(d.block);
 	if (h->arena.base) hipFree(h->arena.base);
 	if (h->d_crc_tab) hipFree(h->d_crc_tab);
@@ -948,8 +949,8 @@ int dsrcgpu_dev_alloc(dsrcgpu_handle* h, uint64_t bytes, void** d_ptr)
 	if (e != hipSuccess) return fail(h, DSRCGPU_E_NOMEM, "hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
 	return DSRCGPU_OK;
 }
-int dsrcgpu_dev_free(dsrcgpu_handle* h, void* d_ptr) { if (!h) return DSRCGPU_E_ARG; HIPCHK(hipFree(d_ptr)); return DSRCGPU_OK; }
-int dsrcgpu_dev_upload(dsrcgpu_handle* h, void* d_dst, const void* src, uint64_t bytes) { if (!h) return DSRCGPU_E_ARG; HIPCHK(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice)); return DSRCGPU_OK; }
-int dsrcgpu_dev_download(dsrcgpu_handle* h, void* dst, const void* d_src, uint64_t bytes) { if (!h) return DSRCGPU_E_ARG; HIPCHK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost)); return DSRCGPU_OK; }
+int dsrcgpu_dev_free(dsrcgpu_handle* h, void* d_ptr) { if (!h) return DSRCGPU_E_ARG; HIPCHK(hipSetDevice(h->device)); HIPCHK(hipFree(d_ptr)); return DSRCGPU_OK; }
+int dsrcgpu_dev_upload(dsrcgpu_handle* h, void* d_dst, const void* src, uint64_t bytes) { if (!h) return DSRCGPU_E_ARG; HIPCHK(hipSetDevice(h->device)); HIPCHK(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice)); return DSRCGPU_OK; }
+int dsrcgpu_dev_download(dsrcgpu_handle* h, void* dst, const void* d_src, uint64_t bytes) { if (!h) return DSRCGPU_E_ARG; HIPCHK(hipSetDevice(h->device)); HIPCHK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost)); return DSRCGPU_OK; }
 
 } // extern "C"
