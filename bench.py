@@ -37,7 +37,7 @@ BUF = 8 << 20                     # -b8 (reference default, src/Common.h:156)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 RECS_PER_BLOCK = 22300
 PMC_RC_BYTES_PER_BLOCK = (20.0005e6 * 2 + 13.3255e6) * 1024 / 512   # measured, see roofline.traffic below
-MAX_RESIDENT = 4                  # distinct input shards kept in HBM per scheduler instance
+MAX_RESIDENT = 3                  # distinct input shards kept in HBM per scheduler instance (2 when N > 1: rank 0 also holds the gathered streams)
 
 
 def title_len(i: np.ndarray) -> np.ndarray:
@@ -112,7 +112,7 @@ class Lane:
         self.cap_out = cap_in // 2
         # all inputs of the timed region stay resident in HBM; beyond MAX_RESIDENT distinct shards per lane they are
         # reused cyclically (a shard is ~3.4 GB, far beyond any cache)
-        self.n_res = min(n_sub, MAX_RESIDENT)
+        self.n_res = min(n_sub, MAX_RESIDENT if n_out == 1 else 2)
         for k in range(self.n_res):
             gid = (rank * n_lanes + lane_id) * MAX_RESIDENT + k     # disjoint record range per (rank, lane, shard)
             first = 1 + gid * recs
@@ -328,7 +328,7 @@ def main():
             "metric": "raw FASTQ MB/s compressed (bit-identical .dsrc)", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16/u32 integer",
-            "data": f"synthetic (counter-based generator, in HBM; {min(total_steps, MAX_RESIDENT)} distinct ~{sub_blocks * 8.4 / 1e3:.1f} GB shards per scheduler instance, cycled)",
+            "data": f"synthetic (counter-based generator, in HBM; {lanes[0].n_res} distinct ~{sub_blocks * 8.4 / 1e3:.1f} GB shards per scheduler instance, cycled)",
             "config": {"workload": f"Synthetic Illumina 150 bp FASTQ, 100M-read data set shape (BASELINE configs[2]), -d{args.dna} -q{args.qua} -b8; "
                                    f"step = {args.blocks} consecutive 8 MiB chunks per GPU, device-resident, {P} scheduler instances per GPU",
                        "blocks_per_step": args.blocks, "pipeline": P,
