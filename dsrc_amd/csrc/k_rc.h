@@ -159,7 +159,9 @@ __device__ __forceinline__ u32 ctx_digit0(const CtxJob& j, const u8* s, const u8
 // scan over the waves turns the rows into global offsets once per tile.
 #define SORT_MAX_BINS 512
 #define SORT_DIGIT_BITS 9
+#ifndef SORT_ITEMS
 #define SORT_ITEMS 8
+#endif
 __global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool, const u8* d_stream, const u8* q_stream, const u8* qp_stream, BlkState* st)
 {
 	__shared__ u32 s_base[SORT_MAX_BINS];
