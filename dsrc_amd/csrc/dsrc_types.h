@@ -18,7 +18,8 @@ typedef int64_t i64;
 #define DSRC_WG 1024            // threads per workgroup for the block-owning kernels (16 waves)
 #endif
 #define DSRC_WAVES (DSRC_WG / 64)
-#define DSRC_TILE_BYTES (DSRC_WG * 16)   // bytes of FASTQ text one workgroup indexes per step (16 B / lane)
+#define DSRC_LANE_BYTES 64               // bytes of FASTQ text one lane classifies (eight 8-byte words)
+#define DSRC_TILE_BYTES (DSRC_WG * DSRC_LANE_BYTES)   // bytes one workgroup indexes
 
 #define DSRC_MAX_FIELDS 64      // read-id fields per title (reference stores the count in one byte)
 #define DSRC_MAX_STRF 129       // per-position statistics of a string field: 128 positions + overflow bucket

@@ -10,42 +10,74 @@
 
 // A byte is the LAST byte of a line terminator iff it is '\n', or a '\r' not followed by '\n'
 // (SkipLine, src/FastqParser.h:93-115: "\r\n", "\n" and a lone "\r" all end a line).
-__device__ __forceinline__ bool is_term_last(const u8* p, u64 i, u64 size)
+//
+// One lane classifies 64 consecutive bytes with word arithmetic: per 8-byte word an exact byte-equality mask
+// (bit 7 of every byte that equals c), gathered to 8 bits by a multiply, gives 64-bit maps of the '\n' and '\r'
+// positions; terminators and "\r\n" pairs are then two shifts and three logic ops.
+typedef u64 __attribute__((aligned(1))) u64_text;
+
+__device__ __forceinline__ u32 byte_eq8(u64 w, u64 c_rep)
 {
-	const u8 c = p[i];
-	if (c == '\n') return true;
-	if (c == '\r') return !(i + 1 < size && p[i + 1] == '\n');
-	return false;
+	const u64 x = w ^ c_rep;
+	const u64 y = (((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x) | 0x7F7F7F7F7F7F7F7Full;   // 0xFF.. except 0x7F where the byte of x is 0
+	return (u32)((((~y) >> 7) * 0x0102040810204080ull) >> 56);                                            // bit k = byte k matched
 }
 
-// ---- pass 1: count terminators per 16 KiB tile -------------------------------------------
+struct LineBits { u64 term, crlf; };   // bit i: byte base+i is the last byte of a terminator / is the '\n' of a "\r\n"
+
+__device__ __forceinline__ LineBits classify64(const u8* p, u64 base, u64 size)
+{
+	LineBits r; r.term = 0; r.crlf = 0;
+	if (base >= size) return r;
+	u64 lf = 0, cr = 0;
+	if (base + DSRC_LANE_BYTES <= size)
+	{
+#pragma unroll
+		for (u32 k = 0; k < DSRC_LANE_BYTES / 8; ++k)
+		{
+			const u64 w = *(const u64_text*)(p + base + 8 * k);
+			lf |= (u64)byte_eq8(w, 0x0A0A0A0A0A0A0A0Aull) << (8 * k);
+			cr |= (u64)byte_eq8(w, 0x0D0D0D0D0D0D0D0Dull) << (8 * k);
+		}
+	}
+	else
+	{	// last lane of the chunk: byte by byte, never past `size`
+		for (u32 k = 0; base + k < size; ++k)
+		{
+			const u8 c = p[base + k];
+			if (c == '\n') lf |= 1ull << k;
+			if (c == '\r') cr |= 1ull << k;
+		}
+	}
+	const u64 n_valid = size - base;
+	const u64 valid = n_valid >= 64 ? ~0ull : ((1ull << n_valid) - 1ull);
+	const bool lf_next = base + DSRC_LANE_BYTES < size && p[base + DSRC_LANE_BYTES] == '\n';
+	const bool cr_prev = base > 0 && p[base - 1] == '\r';
+	const u64 lf_after = (lf >> 1) | (lf_next ? 1ull << 63 : 0ull);      // bit i: byte i+1 is '\n'
+	const u64 cr_before = (cr << 1) | (cr_prev ? 1ull : 0ull);          // bit i: byte i-1 is '\r'
+	r.term = (lf | (cr & ~lf_after)) & valid;
+	r.crlf = (lf & cr_before) & valid;
+	return r;
+}
+
+// ---- pass 1: count terminators per tile --------------------------------------------------------
 __global__ void __launch_bounds__(WG) k_count_lines(const u8* in, const BlkDesc* desc, BlkState* st, u32* tile_cnt, DsrcParams prm)
 {
+	__shared__ u32 s_tot[2];
 	const u32 b = blockIdx.y, tile = blockIdx.x;
 	const BlkDesc d = desc[b];
 	if (tile >= d.n_tiles) return;
-	const u8* p = in + d.in_off;
-	const u64 size = d.in_size;
-	const u64 base = (u64)tile * DSRC_TILE_BYTES + (u64)threadIdx.x * 16;
-	u32 cnt = 0, crlf = 0;
-	for (u32 k = 0; k < 16; ++k)
-	{
-		const u64 i = base + k;
-		if (i < size)
-		{
-			cnt += is_term_last(p, i, size) ? 1u : 0u;
-			crlf += (p[i] == '\n' && i > 0 && p[i - 1] == '\r') ? 1u : 0u;
-		}
-	}
-	u32 total;
-	block_excl_scan(cnt, &total);
-	u32 total_crlf;
-	block_excl_scan(crlf, &total_crlf);
+	if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
+	__syncthreads();
+	const LineBits lb = classify64(in + d.in_off, (u64)tile * DSRC_TILE_BYTES + (u64)threadIdx.x * DSRC_LANE_BYTES, d.in_size);
+	const u32 cnt = wave_sum((u32)__popcll(lb.term)), crlf = wave_sum((u32)__popcll(lb.crlf));
+	if (lane_id() == 0) { if (cnt) atomicAdd(&s_tot[0], cnt); if (crlf) atomicAdd(&s_tot[1], crlf); }
+	__syncthreads();
 	if (threadIdx.x == 0)
 	{
-		tile_cnt[(u64)b * prm.max_tiles + tile] = total;
-		atomicAdd(&st[b].n_term, total);
-		if (total_crlf) atomicAdd(&st[b].n_crlf, total_crlf);
+		tile_cnt[(u64)b * prm.max_tiles + tile] = s_tot[0];
+		atomicAdd(&st[b].n_term, s_tot[0]);
+		if (s_tot[1]) atomicAdd(&st[b].n_crlf, s_tot[1]);
 	}
 }
 
@@ -73,22 +105,15 @@ __global__ void __launch_bounds__(WG) k_index_lines(const u8* in, const BlkDesc*
 	const u32 b = blockIdx.y, tile = blockIdx.x;
 	const BlkDesc d = desc[b];
 	if (tile >= d.n_tiles) return;
-	const u8* p = in + d.in_off;
-	const u64 size = d.in_size;
-	const u64 base = (u64)tile * DSRC_TILE_BYTES + (u64)threadIdx.x * 16;
-	u32 mask = 0;
-	for (u32 k = 0; k < 16; ++k)
-	{
-		const u64 i = base + k;
-		if (i < size && is_term_last(p, i, size)) mask |= 1u << k;
-	}
+	const u64 base = (u64)tile * DSRC_TILE_BYTES + (u64)threadIdx.x * DSRC_LANE_BYTES;
+	u64 mask = classify64(in + d.in_off, base, d.in_size).term;
 	u32 total;
-	u32 rank = block_excl_scan((u32)__popc(mask), &total) + tile_base[(u64)b * prm.max_tiles + tile];
+	u32 rank = block_excl_scan((u32)__popcll(mask), &total) + tile_base[(u64)b * prm.max_tiles + tile];
 	u32* ls = line_start + d.line_base;
 	if (tile == 0 && threadIdx.x == 0) ls[0] = 0;
 	while (mask)
 	{
-		const u32 k = (u32)__ffs((int)mask) - 1;
+		const u32 k = (u32)__ffsll((long long)mask) - 1;
 		mask &= mask - 1;
 		ls[++rank] = (u32)(base + k + 1);
 	}
