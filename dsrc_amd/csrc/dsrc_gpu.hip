@@ -75,7 +75,6 @@ struct dsrcgpu_handle
 	dsrcgpu_chain* chain = nullptr;  // if set: fields_cap comes from / goes to the chain, in batch order
 	uint64_t chain_seq = 0; bool chain_taken = false; u32 chain_cap_in = 0;
 	u32* d_crc_tab = nullptr;
-	u64* d_rc_magic = nullptr;      // ceil(2^48 / d), d < 65536 (k_rc)
 	std::string err;
 	std::vector<Pending> pending;
 	std::deque<Done> done;
@@ -784,12 +783,6 @@ int dsrcgpu_create(const dsrcgpu_settings* settings, const dsrcgpu_dataset* data
 		HIPCHK(hipMalloc((void**)&h->d_crc_tab, sizeof(tab)));
 		HIPCHK(hipMemcpy(h->d_crc_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
 	}
-	{
-		std::vector<u64> mg(65536, 0);
-		for (u32 d = 1; d < 65536; ++d) mg[d] = ((1ull << 48) + d - 1) / d;
-		HIPCHK(hipMalloc((void**)&h->d_rc_magic, mg.size() * 8));
-		HIPCHK(hipMemcpy(h->d_rc_magic, mg.data(), mg.size() * 8, hipMemcpyHostToDevice));
-	}
 	if (arena_bytes) { rc = ensure_arena(h, (size_t)arena_bytes); if (rc) return rc; }
 	return DSRCGPU_OK;
 }
@@ -801,7 +794,6 @@ void dsrcgpu_destroy(dsrcgpu_handle* h)
 	for (auto& d : h->done) free(d.block);
 	if (h->arena.base) hipFree(h->arena.base);
 	if (h->d_crc_tab) hipFree(h->d_crc_tab);
-	if (h->d_rc_magic) hipFree(h->d_rc_magic);
 	for (int i = 0; i < 5; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
 	if (h->rc_stream) hipStreamDestroy(h->rc_stream);
 	if (h->stream) hipStreamDestroy(h->stream);
