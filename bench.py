@@ -28,10 +28,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Every scheduler instance drives two HIP streams (front end + range coder).  The HIP runtime multiplexes streams onto
-# 4 hardware queues by default, which serialises unrelated instances behind each other's 0.3 s range-coder kernel;
-# must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 BUF = 8 << 20                     # -b8 (reference default, src/Common.h:156)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -173,16 +169,20 @@ class StepGates:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)  # 10 x 1400 blocks of 8 MiB ~ 3 passes over the 100 M-read set (~4500 blocks); inputs stay resident in HBM
+    ap.add_argument("--steps", type=int, default=10)  # 10 x 1500 blocks of 8 MiB ~ 3.3 passes over the 100 M-read set (~4500 blocks); inputs stay resident in HBM
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=int(os.environ.get("DSRC_BENCH_BLOCKS", "1400")), help="8 MiB chunks per step per GPU")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DSRC_BENCH_PIPELINE", "4")), help="scheduler instances per GPU")
+    ap.add_argument("--blocks", type=int, default=int(os.environ.get("DSRC_BENCH_BLOCKS", "1500")), help="8 MiB chunks per step per GPU")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DSRC_BENCH_PIPELINE", "5")), help="scheduler instances per GPU")
     ap.add_argument("--dna", type=int, default=3)
     ap.add_argument("--qua", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--check", type=int, default=2, help="blocks of the first sub-batch to verify against the oracle")
     args = ap.parse_args()
 
+    # Every scheduler instance drives two HIP streams (front end + range coder).  The HIP runtime multiplexes streams onto
+    # 4 hardware queues by default, which serialises unrelated instances behind each other's 0.25 s range-coder kernel
+    # (and behind the host framework's own streams when N > 1); must be set before the runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(2 * max(1, args.pipeline) + 6))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None; torch = None

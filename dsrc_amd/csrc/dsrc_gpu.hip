@@ -122,7 +122,7 @@ size_t estimate_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
 	const bool rc = h->set.dna_order > 0 || h->set.quality_order > 0;
 	size_t tot = 0, mx = 0;
 	for (u32 i = 0; i < n; ++i) { tot += (size_t)sizes[i] + 4096; mx = std::max(mx, (size_t)sizes[i]); }
-	const size_t sort_slice = std::min(tot * 14, ((size_t)14336 << 20) + mx * 16);      // see slice_lo in run_batch
+	const size_t sort_slice = std::min(tot * 14, ((size_t)7168 << 20) + mx * 16);       // see slice_lo in run_batch
 	return tot * 13 + (rc ? sort_slice : 0) + (size_t)n * (1u << 20) + (16u << 20);      // measured: 12.7 x input + slice at -d3 -q2
 }
 
@@ -474,7 +474,10 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	std::vector<u32> slice_lo;
 	{
 		const char* env = getenv("DSRC_GPU_SORT_SLICE_MB");
-		const size_t budget = (env ? (size_t)atol(env) : (size_t)14336) << 20;      // ~256 streams of an 8 MiB chunk: one k_sort workgroup per CU
+		// ~128 streams of an 8 MiB chunk per slice.  Larger slices (one k_sort workgroup per CU) are no faster for one
+		// instance, and with several instances sharing the GPU shorter launches interleave better (measured: 14 GiB
+		// 17.5, 7 GiB 19.6, 3.5 GiB 19.0 GB/s with four instances)
+		const size_t budget = (env ? (size_t)atol(env) : (size_t)7168) << 20;
 		size_t need_max = 128;
 		for (u32 i = 0; i < NJ; ++i) need_max = std::max(need_max, ((size_t)jobs[i].n * 8 + 64) * 2);
 		const u32 max_jobs = (u32)std::max<size_t>(1, budget / need_max);

@@ -10,6 +10,7 @@ using namespace dsrc;
 
 int main(int argc, const char* argv[])
 {
+	setenv("GPU_MAX_HW_QUEUES", "24", 0);      // two HIP streams per scheduler instance; before the runtime starts
 	if (argc < 4 || argv[1][0] != 'c')
 	{
 		std::cerr << "usage: dsrc-amd c [-d<0-3>] [-q<0-2>] [-l] [-c] [-o<offset>] [-b<MB>] [-m<0-2>] [-v] [-g<device>] [-n<blocks per batch>] <in.fastq> <out.dsrc>\n"

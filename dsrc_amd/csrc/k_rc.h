@@ -166,7 +166,8 @@ __global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool, cons
 {
 	__shared__ u32 s_base[SORT_MAX_BINS];
 	__shared__ u32 s_next[SORT_MAX_BINS];
-	__shared__ u32 s_cnt[WAVES][SORT_MAX_BINS];
+	__shared__ u16 s_cnt[WAVES][SORT_MAX_BINS];      // per tile a wave ranks 64*SORT_ITEMS elements: 16 bits are plenty, and with
+	                                                 // 56 KB in all a k_sort workgroup fits on a CU next to a k_rc wave's 104 KB
 	__shared__ u32 s_off[WAVES][SORT_MAX_BINS];
 	__shared__ u8 s_rank[256];
 	const CtxJob j = jobs[blockIdx.x];
@@ -243,7 +244,7 @@ __global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool, cons
 				const u32 r = (u32)__popcll(peers & lanemask_lt());
 				rk[k] = before + r;
 				const u64 sync = __ballot(true);                       // every lane has read its counter before a leader bumps it
-				if (valid && r == 0 && sync) s_cnt[wv][d] = before + (u32)__popcll(peers);
+				if (valid && r == 0 && sync) s_cnt[wv][d] = (u16)(before + (u32)__popcll(peers));
 			}
 			__syncthreads();
 			for (u32 dd = threadIdx.x; dd < bins; dd += blockDim.x)
