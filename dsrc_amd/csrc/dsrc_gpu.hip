@@ -612,7 +612,8 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 				u32 mxn = 1; for (u32 i = lo; i < hi; ++i) mxn = std::max(mxn, jobs[i].n);
 				// REPLAY_WG/64 waves per part.  Many waves per chain = few chains in flight: the scattered 12-byte records of
 				// a chain then merge in the memory-side cache (measured: 32 parts 164 ms, 512 parts 71 ms per 512 DNA chains)
-				const u32 parts = std::max(1u, std::min(512u, mxn / 1024u));
+				static const u32 max_parts = getenv("DSRC_GPU_REPLAY_PARTS") ? (u32)atoi(getenv("DSRC_GPU_REPLAY_PARTS")) : 512u;   // tuning knob
+				const u32 parts = std::max(1u, std::min(max_parts, mxn / 1024u));
 				switch (jobs[lo].n_alpha)
 				{
 				case 4:   hipLaunchKernelGGL(k_replay<4>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
