@@ -443,9 +443,9 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		const u32 force_exact = getenv("DSRC_GPU_FORCE_EXACT_RC") ? 1u : 0u;             // tests only (read per batch)
 		size_t trip_words = 0;
 		std::vector<size_t> cbase(NJ + 1, 0); std::vector<u32> cpitch(NJ + 1, 0);
-		for (u32 g = 0; g < NJ; g += 64)
+		for (u32 g = 0; g < NJ; g += RC_LANES)
 		{
-			const u32 hi = std::min(NJ, g + 64);
+			const u32 hi = std::min(NJ, g + RC_LANES);
 			u32 mx = 0; for (u32 i = g; i < hi; ++i) mx = std::max(mx, jobs[i].n);
 			const u32 pitch = (mx + 3) / 4 * 4 + 4;
 			if ((u64)pitch * sizeof(RcRec) >= (1ull << 32))      // k_rc: 32-bit byte offsets inside one stream's array
@@ -632,7 +632,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		HIPCHK(hipEventRecord(h->ev[4], s));
 		HIPCHK(hipStreamWaitEvent(h->rc_stream, h->ev[4], 0));
 		HIPCHK(hipEventRecord(h->ev[2], h->rc_stream));
-		hipLaunchKernelGGL(k_rc, dim3((NJ + 63) / 64), dim3(64), 0, h->rc_stream, d_chains, NJ, AP<RcRec>(h, 0), AP<RcFin>(h, o_fin), d_state); KCHK();
+		hipLaunchKernelGGL(k_rc, dim3((NJ + RC_LANES - 1) / RC_LANES), dim3(64), 0, h->rc_stream, d_chains, NJ, AP<RcRec>(h, 0), AP<RcFin>(h, o_fin), d_state); KCHK();
 		hipLaunchKernelGGL(k_rc_emit, dim3(NJ), dim3(RC_EMIT_WG), 0, h->rc_stream, d_chains, AP<RcRec>(h, 0), AP<RcFin>(h, o_fin), wpool, d_state); KCHK();
 		HIPCHK(hipEventRecord(h->ev[3], h->rc_stream));
 		HIPCHK(hipStreamWaitEvent(s, h->ev[3], 0));

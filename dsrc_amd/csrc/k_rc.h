@@ -498,6 +498,9 @@ struct RcChain
 struct RcFin { u32 n; u8 b[60]; };
 
 #define RC_GROUP 16                    // symbols per register group / clamp check
+#ifndef RC_LANES
+#define RC_LANES 32                    // chains per wave (lanes beyond idle): half a wave keeps the LDS at 52 KB, so a k_rc wave shares a
+#endif                                 // CU with two k_sort workgroups, and it issues half as many DMA requests per symbol
 #define RC_CHUNK 64                    // symbols per chain per LDS chunk (768 B = 48 lanes x 16 B)
 #define RC_ROW_U4 49                   // LDS row pitch in 16-byte units: 48 of data + 1 so that a 16-lane ds_read_b128 pass covers all 64 banks
 #define RC_OVERREAD (3 * RC_CHUNK)     // records the DMA may touch past the longest chain of a wave (arena slack)
@@ -610,7 +613,7 @@ __device__ __forceinline__ void rc_dma(LDS_AS U4* buf, const u8* base, u32 pitch
 #pragma unroll
 		for (int j = J0; j < J1; ++j)
 		{
-			if ((u32)j < n_live) lds_dma16(sp, threadIdx.x * 16u, buf + j * RC_ROW_U4);      // n_live: constant 64 in full waves
+			if ((u32)j < n_live) lds_dma16(sp, threadIdx.x * 16u, buf + j * RC_ROW_U4);      // n_live: constant RC_LANES in full waves
 			sp += pitch;
 		}
 	}
@@ -623,19 +626,20 @@ __device__ __forceinline__ void rc_chunk(RcState& s, u32* codes, RcRegs& r0, RcR
 {
 	const u32 lane = threadIdx.x;
 	const u32 off = (t0 + RC_CHUNK) * (u32)sizeof(RcRec);
-	const LDS_AS U4* row = cur + lane * RC_ROW_U4;
+	const u32 rowi = lane < RC_LANES ? lane : RC_LANES - 1;               // idle lanes read a valid row and code nothing
+	const LDS_AS U4* row = cur + rowi * RC_ROW_U4;
 	u32* c = codes + t0;
 	rc_load_group(r1, row, 1);
-	rc_dma<0, 22>(nxt, base, pitch, off, n_live);
+	rc_dma<0, RC_LANES / 3>(nxt, base, pitch, off, n_live);
 	if (t0 + 1 * RC_GROUP <= n) rc_group(s, c, r0, row, 0, xb, err, fx);
 	rc_load_group(r0, row, 2);
-	rc_dma<22, 43>(nxt, base, pitch, off, n_live);
+	rc_dma<RC_LANES / 3, 2 * RC_LANES / 3>(nxt, base, pitch, off, n_live);
 	if (t0 + 2 * RC_GROUP <= n) rc_group(s, c + RC_GROUP, r1, row, 1, xb, err, fx);
 	rc_load_group(r1, row, 3);
-	rc_dma<43, 64>(nxt, base, pitch, off, n_live);
+	rc_dma<2 * RC_LANES / 3, RC_LANES>(nxt, base, pitch, off, n_live);
 	if (t0 + 3 * RC_GROUP <= n) rc_group(s, c + 2 * RC_GROUP, r0, row, 2, xb, err, fx);
 	lds_dma_wait();                                                        // the requests above have landed before row 0 of `nxt` is read
-	rc_load_group(r0, nxt + lane * RC_ROW_U4, 0);
+	rc_load_group(r0, nxt + rowi * RC_ROW_U4, 0);
 	if (t0 + 4 * RC_GROUP <= n) rc_group(s, c + 3 * RC_GROUP, r1, row, 3, xb, err, fx);
 }
 
@@ -645,11 +649,11 @@ template <bool FULL>
 __device__ __forceinline__ void rc_wave(const RcChain* chains, u32 n_chains, RcRec* rec_pool, RcFin* fin, BlkState* st, LDS_AS U4* buf_a, LDS_AS U4* buf_b, u8* s_xb)
 {
 	__builtin_amdgcn_s_setprio(3);                                             // the serial wave wins issue arbitration against co-resident data-parallel waves
-	const u32 first_chain = blockIdx.x * 64;
+	const u32 first_chain = blockIdx.x * RC_LANES;
 	const u32 lane = threadIdx.x, id = first_chain + lane;
-	const bool have = FULL || id < n_chains;
+	const bool have = lane < RC_LANES && (FULL || id < n_chains);
 	const RcChain c = chains[have ? id : n_chains - 1];                        // idle lanes shadow a real chain's values and code nothing
-	const u32 n_live = FULL ? 64u : n_chains - first_chain;
+	const u32 n_live = FULL ? (u32)RC_LANES : n_chains - first_chain;
 	const u32 n = have ? c.n : 0;
 	RcRec* p = rec_pool + c.trip;
 	u32* codes = (u32*)p;                                                      // code t overwrites bytes 4t..4t+3 of the chain's own array
@@ -662,13 +666,13 @@ __device__ __forceinline__ void rc_wave(const RcChain* chains, u32 n_chains, RcR
 	const u32 wave_full = (u32)__builtin_amdgcn_readfirstlane((int)wave_max(n_full));
 	if (wave_full)
 	{
-		// the 64 arrays of a wave are c.pitch records apart (wave-uniform; idle lanes shadow the last chain's values)
+		// the arrays of a wave's chains are c.pitch records apart (wave-uniform; idle lanes shadow the last chain's values)
 		const u8* base = uniform_ptr(rec_pool + __shfl(c.trip, 0));
 		const u32 pitch = (u32)__builtin_amdgcn_readfirstlane((int)(c.pitch * (u32)sizeof(RcRec)));
 		RcRegs r0, r1;
-		rc_dma<0, 64>(buf_a, base, pitch, 0, n_live);
+		rc_dma<0, RC_LANES>(buf_a, base, pitch, 0, n_live);
 		lds_dma_wait();
-		rc_load_group(r0, buf_a + lane * RC_ROW_U4, 0);
+		rc_load_group(r0, buf_a + (lane < RC_LANES ? lane : RC_LANES - 1) * RC_ROW_U4, 0);
 		for (u32 t0 = 0; t0 < wave_full; t0 += 2 * RC_CHUNK)
 		{
 			rc_chunk(s, codes, r0, r1, buf_a, buf_b, t0, n, base, pitch, n_live, xb, err, c.force_exact);
@@ -688,10 +692,10 @@ __device__ __forceinline__ void rc_wave(const RcChain* chains, u32 n_chains, RcR
 
 __global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, RcRec* rec_pool, RcFin* fin, BlkState* st)
 {
-	__shared__ U4 s_a[64 * RC_ROW_U4];
-	__shared__ U4 s_b[64 * RC_ROW_U4];
+	__shared__ U4 s_a[RC_LANES * RC_ROW_U4];
+	__shared__ U4 s_b[RC_LANES * RC_ROW_U4];
 	__shared__ u8 s_xb[64 * RC_XB];
-	if (blockIdx.x * 64 + 64 <= n_chains) rc_wave<true>(chains, n_chains, rec_pool, fin, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb);
+	if (blockIdx.x * RC_LANES + RC_LANES <= n_chains) rc_wave<true>(chains, n_chains, rec_pool, fin, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb);
 	else rc_wave<false>(chains, n_chains, rec_pool, fin, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb);
 }
 
