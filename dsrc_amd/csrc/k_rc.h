@@ -11,7 +11,7 @@
 //               the first pass of a stable LSD radix sort of (ctx, sym, t) by ctx -> each context's history is contiguous
 //   k_replay  : one lane replays one context's history on a private counter row in LDS and
 //               emits (total, cum, freq) for every symbol, scattered back to stream order
-//   k_rc      : the integer range-coder recurrence, one LANE per stream (64 streams per wave); each
+//   k_rc      : the integer range-coder recurrence, one LANE per stream (RC_LANES = 32 streams per wave); each
 //               stream's records are contiguous, the wave pulls them through LDS 768 B at a time (LDS DMA)
 // No adaptive table ever exists in HBM (the reference clears 2-64 MiB per block).
 #pragma once
@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 // and on the GPU its cost is instruction issue, so the serial kernel (k_rc) does the arithmetic and nothing
 // else:
 //   * floor(range/total) is a multiply by the 48-bit reciprocal k_replay stored (exact, see rc_div);
-//   * a wave owns 64 chains whose records lie in 64 different arrays.  Per 64 symbols it issues one LDS-DMA
+//   * a wave owns RC_LANES (32) chains whose records lie in as many arrays.  Per 64 symbols it issues one LDS-DMA
 //     load per chain (global_load_lds_dwordx4 on 48 lanes = 768 contiguous bytes = 64 records of ONE chain,
 //     landing in that chain's LDS row) for the chunk after the current one, so every global access is a full
 //     coalesced row and the coder runs 64-128 symbols (6-12 us) behind its loads; lane c then reads row c,
@@ -489,7 +489,7 @@ struct RcChain
 	u32 out_byte0, out_cap;
 	u32 blk, is_dna;
 	u32 force_exact;   // tests: take the reference-loop path for every group (same bytes by construction)
-	u32 pitch;         // records between the arrays of consecutive chains of this chain's wave (64 chains)
+	u32 pitch;         // records between the arrays of consecutive chains of this chain's wave (RC_LANES chains)
 	u32 pad0;
 };
 
@@ -602,7 +602,7 @@ __device__ __forceinline__ void rc_load_group(RcRegs& g, const LDS_AS U4* row, u
 }
 
 // LDS-DMA requests for chains [J0, J1) of the wave: lanes 0..47 fetch the 48 x 16 bytes (= 64 records) of chain j
-// that start at byte `chunk_off` (wave-uniform) of its array into row j.  The 64 arrays of a wave are `pitch`
+// that start at byte `chunk_off` (wave-uniform) of its array into row j.  The arrays of a wave's chains are `pitch`
 // bytes apart: a request is a scalar pointer (advanced by scalar adds) + the lane's fixed offset 16 * lane.
 template <int J0, int J1>
 __device__ __forceinline__ void rc_dma(LDS_AS U4* buf, const u8* base, u32 pitch, u32 chunk_off, u32 n_live)
