@@ -19,7 +19,7 @@ EXPORTS = [
     "dsrcgpu_compress_batch_device", "dsrcgpu_submit", "dsrcgpu_flush", "dsrcgpu_collect", "dsrcgpu_release",
     "dsrcgpu_last_timing", "dsrcgpu_synth_illumina", "dsrcgpu_dev_alloc", "dsrcgpu_dev_free", "dsrcgpu_dev_upload",
     "dsrcgpu_dev_download", "dsrcgpu_chain_create", "dsrcgpu_chain_destroy", "dsrcgpu_set_chain", "dsrcgpu_host_alloc",
-    "dsrcgpu_host_free",
+    "dsrcgpu_host_free", "dsrcgpu_selftest",
 ]
 
 
@@ -163,6 +163,11 @@ class Handle:
         data = bytes(C.cast(blk, C.POINTER(C.c_uint8 * sz.value)).contents) if sz.value else b""
         self.L.dsrcgpu_release(self.h, blk)
         return pid.value, data, list(raw), list(comp)
+
+    def selftest(self) -> int:
+        n = C.c_uint32(1)
+        self._chk(self.L.dsrcgpu_selftest(self.h, C.byref(n)))
+        return n.value
 
     def last_timing(self):
         ms = C.c_float(); rc_ms = C.c_float(); n = C.c_uint32()

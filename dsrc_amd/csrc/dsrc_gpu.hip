@@ -895,6 +895,20 @@ int dsrcgpu_collect(dsrcgpu_handle* h, int64_t* part_id, uint8_t** block, uint64
 
 int dsrcgpu_release(dsrcgpu_handle* h, uint8_t* block) { (void)h; free(block); return DSRCGPU_OK; }
 
+int dsrcgpu_selftest(dsrcgpu_handle* h, uint32_t* mismatches)
+{
+	if (!h || !mismatches) return DSRCGPU_E_ARG;
+	HIPCHK(hipSetDevice(h->device));
+	u32* d_bad = nullptr;
+	HIPCHK(hipMalloc((void**)&d_bad, 4));
+	HIPCHK(hipMemsetAsync(d_bad, 0, 4, h->stream));
+	hipLaunchKernelGGL(k_selftest, dim3(256), dim3(256), 0, h->stream, d_bad); KCHK();
+	HIPCHK(hipMemcpyAsync(mismatches, d_bad, 4, hipMemcpyDeviceToHost, h->stream));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	HIPCHK(hipFree(d_bad));
+	return DSRCGPU_OK;
+}
+
 int dsrcgpu_chain_create(dsrcgpu_chain** out)
 {
 	if (!out) return DSRCGPU_E_ARG;

@@ -277,6 +277,38 @@ __global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool, cons
 	}
 }
 
+// ceil(2^48 / d) for 2 <= d < 2^16 without a 64-bit integer division (a ~100-instruction sequence on this machine):
+// with inv = fl(fl(1/d) * (1 + 2^-50)), p = 2^48 * inv = Q * (1 + e), Q = 2^48/d, 0.6 * 2^-50 < e < 1.4 * 2^-50
+// (three roundings of 2^-53 each around the 2^-50 bias; the multiplication by 2^48 is exact).  So p > Q, and
+// p - Q < 1.4 * 2^-50 * 2^48 / d = 0.35 / d <= the distance from Q to the next integer (>= 1/d unless Q is one, and
+// then 0.35/d < 1): trunc(p) == floor(Q).  The quotient is exact only for powers of two.
+__device__ __forceinline__ u64 recip48(u32 d)
+{
+	const double inv = (1.0 / (double)d) * (1.0 + 0x1p-50);
+	const double p = inv * 0x1p48;
+	const u32 hi = (u32)(p * 0x1p-32);                         // p < 2^47: hi < 2^15
+	const u32 lo = (u32)(p - (double)hi * 0x1p32);             // the subtraction is exact (p < 2^47 keeps >= 6 fraction bits); the cast truncates
+	const u64 q = ((u64)hi << 32) | lo;
+	return q + ((d & (d - 1u)) ? 1ull : 0ull);
+}
+
+// device self-test (dsrcgpu_selftest): recip48 against the integer division for every divisor, and rc_div against
+// the hardware division on a spread of numerators
+__device__ __forceinline__ u32 rc_div(u32 range, u32 m_lo, u32 m_hi);
+__global__ void __launch_bounds__(256) k_selftest(u32* bad)
+{
+	const u32 d = blockIdx.x * blockDim.x + threadIdx.x + 2;
+	if (d >= 65536) return;
+	const u64 m = recip48(d);
+	u32 wrong = m != ((1ull << 48) + d - 1) / d ? 1u : 0u;
+	for (u32 k = 0; k < 64; ++k)
+	{
+		const u32 n = k < 32 ? (0xFFFFFFFFu >> k) : (u32)((u64)d * (k * 2654435761u | 1u) - (k & 1u));
+		if (rc_div(n, (u32)m, (u32)(m >> 32)) != n / d) wrong = 1;
+	}
+	if (wrong) atomicAdd(bad, 1u);
+}
+
 // ---- model replay ---------------------------------------------------------------------------
 // After the sort every context's history is a contiguous *segment*.  One wave walks a range of
 // the sorted array 64 elements at a time and replays all segments inside the window at once:
@@ -429,7 +461,7 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 		if (active)
 		{	// what k_rc needs per symbol: the 48-bit reciprocal of `total` (rc_div), freq, cum -- one 16-byte record
 			RcRec rr;
-			const u64 m = ((1ull << 48) + tot - 1) / tot;
+			const u64 m = recip48(tot);
 			rr.m_lo = (u32)m; rr.mf = ((u32)(m >> 32) << 16) | f; rr.cum = cum;
 			recs[(u32)el] = rr;
 		}

@@ -116,6 +116,11 @@ int dsrcgpu_set_chain(dsrcgpu_handle* h, dsrcgpu_chain* c, uint64_t seq);
 int dsrcgpu_host_alloc(uint64_t bytes, void** out);
 int dsrcgpu_host_free(void* p);
 
+/* Device arithmetic self-test: the exact-division identities the range-coder stage relies on (reciprocal of every
+ * possible model total, quotients on a spread of numerators) are checked against the hardware integer division.
+ * *mismatches must come back 0. */
+int dsrcgpu_selftest(dsrcgpu_handle* h, uint32_t* mismatches);
+
 /* Timing of the last batch measured with HIP events on the scheduler's stream: total ms of the batch's
  * kernels, ms of the range-coder kernel (k_rc), number of k_rc launches. */
 int dsrcgpu_last_timing(const dsrcgpu_handle* h, float* batch_ms, float* rc_ms, uint32_t* rc_launches);

@@ -160,6 +160,12 @@ def test_range_coder_reference_loop_path(emu, oracle, monkeypatch):
         assert run(emu, cfg, data) == oracle.compress_block(cfg, data)
 
 
+def test_exact_division_selftest(emu):
+    h = emu.Handle()
+    assert h.selftest() == 0
+    h.close()
+
+
 def test_device_synth_matches_host(emu):
     h = emu.Handle()
     cap = 1 << 20

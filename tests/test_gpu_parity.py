@@ -146,6 +146,12 @@ def test_concurrent_scheduler_instances(gpu, oracle):
         assert [g[0] for g in got[t]] == [w[0] for w in want[t]]
 
 
+def test_exact_division_selftest(gpu):
+    h = gpu.Handle()
+    assert h.selftest() == 0
+    h.close()
+
+
 def test_device_synth_matches_host(gpu):
     h = gpu.Handle()
     cap = 2 << 20
