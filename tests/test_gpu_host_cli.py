@@ -71,3 +71,21 @@ def test_pipelined_instances_write_the_t1_archive(files, flags, which):
     _run([CLI, "c", *flags, "-b1", "-n2", "-t4", src, ours])
     _run([REF_BIN, "c", *flags, "-b1", "-t1", src, theirs])
     assert md5(ours) == md5(theirs)
+
+
+def test_pydsrc_module_names(files):
+    """The reference's Python module names (py/Interface.cpp) on top of the GPU path: same archive as `dsrc c -t1`."""
+    if not os.path.exists(CLI) or not os.path.exists(REF_BIN):
+        pytest.skip("CLI missing")
+    from dsrc_amd import pydsrc
+    d, ill, _ = files
+    m = pydsrc.DsrcModule()
+    m.DNACompressionLevel = 2; m.QualityCompressionLevel = 2; m.FastqBufferSizeMB = 1; m.ThreadsNumber = 3
+    ours = str(d / "py.dsrc"); theirs = str(d / "pyr.dsrc")
+    m.Compress(ill, ours)
+    _run([REF_BIN, "c", "-d2", "-q2", "-b1", "-t1", ill, theirs])
+    assert md5(ours) == md5(theirs)
+    with pytest.raises(RuntimeError):
+        m.DNACompressionLevel = 4
+    with pytest.raises(RuntimeError):
+        m.Decompress(ours, str(d / "x.fastq"))
