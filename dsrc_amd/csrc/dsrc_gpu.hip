@@ -468,7 +468,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			c.force_exact = force_exact; c.pitch = cpitch[i]; c.pad0 = 0;
 		}
 	}
-	// The ping-pong sort buffers are only alive from k_ctx to k_replay, so the job list is cut into slices that
+	// The ping-pong sort buffers are only alive from k_sort to k_replay, so the job list is cut into slices that
 	// reuse one region (kernels of consecutive slices are ordered on the stream).  What persists per block until
 	// the range coder has run is the record array, which keeps many more blocks in flight per GiB of HBM.
 	std::vector<u32> slice_lo;

@@ -82,17 +82,9 @@ struct BlkDesc   // host -> device
 	u32 rec_cap;
 	u32 fields_keep_from;   // first field index whose record-0 double count survives
 	u64 q_base, d_base;     // quality / DNA symbol streams (bytes)
-	u64 tagval_base;        // u32 index: [num_slot][rec]
-	u64 tagscr_base;        // u32 index: tag scratch (histograms, codes, trees)
-	u32 tagscr_words;
 	// per-stream staging of the compressed block (u32 words, MSB-first "logical big-endian")
 	u64 tag_out, qua_out, dna_out;        // u32 index
 	u32 tag_cap, qua_cap, dna_cap;        // words
-	u64 sortA, sortB;       // u64 index: ping-pong sort buffers (quality first, then DNA)
-	u64 trip_q, trip_d;     // u64 index: (total,cum,freq) triples, lane-interleaved per 64-chain group
-	u32 chain_q, chain_d;   // chain ids (group = id / 64, lane = id % 64)
-	u32 qscr_base_lo, qscr_base_hi;   // u32 index: quality scratch (position histograms / run arrays / code tables)
-	u32 qscr_words;
 	u32 q_scheme;           // host-decided stream schemes (IQualityModelerProxy / IDnaModelerProxy::SelectSchemeId)
 	u32 d_scheme;
 	u32 plain_mask;         // bit0: quality stream staged as plain bytes, bit1: DNA stream (range-coder output)

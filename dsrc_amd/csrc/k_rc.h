@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 			else { f = 1 + 2 * same; cum = sym + 2 * less; tot = N + 2 * in_seg; }
 		}
 		if (active)
-		{	// what k_rc needs per symbol: the 48-bit reciprocal of `total` (rc_div), freq, cum -- one 16-byte record
+		{	// what k_rc needs per symbol: the 48-bit reciprocal of `total` (rc_div), freq, cum -- one 12-byte record
 			RcRec rr;
 			const u64 m = recip48(tot);
 			rr.m_lo = (u32)m; rr.mf = ((u32)(m >> 32) << 16) | f; rr.cum = cum;
