@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off soak: many more fuzz seeds than the test-suite runs, GPU path vs oracle, for a bounded time.
-Usage: tools/fuzz_soak.py [first_seed] [seconds]"""
+Usage: tools/fuzz_soak.py [first_seed] [seconds] [batch]"""
 import os
 import sys
 import time
@@ -12,7 +12,44 @@ from tests._oracle import Config, Oracle  # noqa: E402
 from tests.cases import fuzz_fastq  # noqa: E402
 
 
+def batch_mode(seed, limit):
+    """Batches of 40-70 heterogeneous chunks per scheduler pass: range-coder waves with chains of very different
+    lengths (full and partial waves), block-to-block state carried in chunk order."""
+    import ctypes as C
+    import random
+    from tests._oracle import _orc_cfg
+    o = Oracle()
+    t0 = time.time(); n = 0; nb = 0
+    cfgs = [(3, 2, False, False), (2, 1, True, False), (1, 1, False, True), (0, 2, False, False), (3, 0, False, False)]
+    while time.time() - t0 < limit:
+        rng = random.Random(seed)
+        d, q, lossy, crc = cfgs[seed % len(cfgs)]
+        cfg = Config.from_levels(d, q, lossy, crc)
+        chunks = []
+        want_n = rng.randrange(40, 71)
+        s2 = seed * 1000
+        while len(chunks) < want_n:
+            data, _ = fuzz_fastq(s2, rng.choice([None, None, 2000, 6000])); s2 += 1
+            try:
+                o.compress_block(cfg, data)      # reference-UB inputs cannot be part of a batch
+            except RuntimeError:
+                continue
+            chunks.append(data)
+        h = _lib.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc)
+        got = h.compress_batch(chunks); h.close()
+        cap = C.c_uint32(0); c = _orc_cfg(cfg)
+        for i, ch in enumerate(chunks):
+            out = (C.c_uint8 * (len(ch) + 65536))(); osz = C.c_uint64(); raw = (C.c_uint64 * 4)(); comp = (C.c_uint64 * 4)()
+            assert o.lib.orc_compress_block_state(C.byref(c), C.byref(cap), ch, C.c_uint64(len(ch)), out, C.c_uint64(len(out)), C.byref(osz), raw, comp) == 0
+            assert got[i][0] == bytes(out[:osz.value]), f"batch seed {seed} chunk {i} -d{d} -q{q} lossy={lossy}: GPU block differs from the oracle"
+            n += 1
+        nb += 1; seed += 1
+    print(f"fuzz soak (batches): {nb} batches, {n} blocks identical, {time.time() - t0:.0f} s")
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "batch":
+        return batch_mode(int(sys.argv[1]), float(sys.argv[2]))
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     limit = float(sys.argv[2]) if len(sys.argv) > 2 else 180.0
     o = Oracle()
