@@ -603,7 +603,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		for (size_t sl = 0; sl + 1 < slice_lo.size(); ++sl)
 		{
 			const u32 s_lo = slice_lo[sl], s_hi = slice_lo[sl + 1];
-			hipLaunchKernelGGL(k_sort, dim3(s_hi - s_lo), dim3(WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state); KCHK();
+			hipLaunchKernelGGL(k_sort, dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state); KCHK();
 			for (u32 lo = s_lo; lo < s_hi;)
 			{
 				u32 hi = lo;

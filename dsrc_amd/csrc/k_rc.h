@@ -162,13 +162,17 @@ __device__ __forceinline__ u32 ctx_digit0(const CtxJob& j, const u8* s, const u8
 #ifndef SORT_ITEMS
 #define SORT_ITEMS 8
 #endif
-__global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool, const u8* d_stream, const u8* q_stream, const u8* qp_stream, BlkState* st)
+#ifndef SORT_WG
+#define SORT_WG WG
+#endif
+#define SORT_WAVES (SORT_WG / 64)
+__global__ void __launch_bounds__(SORT_WG) k_sort(const CtxJob* jobs, u64* pool, const u8* d_stream, const u8* q_stream, const u8* qp_stream, BlkState* st)
 {
 	__shared__ u32 s_base[SORT_MAX_BINS];
 	__shared__ u32 s_next[SORT_MAX_BINS];
-	__shared__ u16 s_cnt[WAVES][SORT_MAX_BINS];      // per tile a wave ranks 64*SORT_ITEMS elements: 16 bits are plenty, and with
+	__shared__ u16 s_cnt[SORT_WAVES][SORT_MAX_BINS];      // per tile a wave ranks 64*SORT_ITEMS elements: 16 bits are plenty, and with
 	                                                 // 56 KB in all a k_sort workgroup fits on a CU next to a k_rc wave's 104 KB
-	__shared__ u32 s_off[WAVES][SORT_MAX_BINS];
+	__shared__ u32 s_off[SORT_WAVES][SORT_MAX_BINS];
 	__shared__ u8 s_rank[256];
 	const CtxJob j = jobs[blockIdx.x];
 	const u32 n = j.n, bins = 1u << j.dbits;
@@ -212,7 +216,7 @@ __global__ void __launch_bounds__(WG) k_sort(const CtxJob* jobs, u64* pool, cons
 			}
 		}
 		for (u32 i = threadIdx.x; i < bins; i += blockDim.x) s_next[i] = 0;
-		for (u32 i = threadIdx.x; i < WAVES * SORT_MAX_BINS; i += blockDim.x) (&s_cnt[0][0])[i] = 0;
+		for (u32 i = threadIdx.x; i < SORT_WAVES * SORT_MAX_BINS; i += blockDim.x) (&s_cnt[0][0])[i] = 0;
 		__syncthreads();
 
 		for (u32 tile = 0; tile < n; tile += tile_elems)
