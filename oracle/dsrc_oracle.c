@@ -383,6 +383,48 @@ static int p_next_record(parser_t* p, rec_t* r)
 	return plus > 0 && r->seq_len == r->qual_len;
 }
 
+/* FastqParserExt::ReadNextRecord (src/FastqParser.cpp:198-251): with -f the title is rewritten in place to the fields
+ * whose number (1-based) is set in the mask; a field ends at one of " ._,=:/-#" or NUL or at the end of the title and
+ * is copied INCLUDING that end byte -- for the last field that is the line terminator, which thereby becomes part
+ * of the title.  Titles longer than the reference's 512-byte scratch are undefined behaviour there. */
+static int p_next_record_ext(parser_t* p, rec_t* r, u64 flags, u64* cut)
+{
+	if (p->pos == p->size) return 0;
+	r->title = (u32)p->pos; r->title_len = (u16)p_skip_line(p);
+	if (r->title_len == 0 || p->mem[r->title] != '@') return 0;
+	{
+		static const char seps[10] = " ._,=:/-#";          /* the tenth byte is the NUL */
+		u8 buf[1024];
+		u8* t = p->mem + r->title;
+		const u32 tl = r->title_len;
+		u32 field_no = 0, begin = 0, bp = 0;
+		if (tl > 512) g_ref_ub = 1;
+		for (u32 i = 0; i <= tl; ++i)
+		{
+			if (i != tl && !memchr(seps, t[i], 10)) continue;
+			field_no++;
+			if (field_no < 31 && (flags & (1u << field_no)))       /* BIT(x) is a 32-bit int shift in the reference */
+			{
+				if (bp + (i + 1 - begin) <= sizeof(buf)) memcpy(buf + bp, t + begin, i + 1 - begin);
+				bp += i + 1 - begin;
+			}
+			if (field_no >= 31) g_ref_ub = 1;
+			begin = i + 1;
+		}
+		if (bp > 512) g_ref_ub = 1;                              /* overruns the reference's scratch */
+		/* with the last field kept bp may be tl + 1 (title + terminator): the release build has no assert and the
+		 * unsigned subtraction wraps, i.e. the cut total goes DOWN by one */
+		*cut += (u64)tl - (u64)bp;
+		if (bp > 0 && bp <= sizeof(buf)) memcpy(t, buf, bp);
+		r->title_len = (u16)bp;
+	}
+	r->seq = (u32)p->pos; r->seq_len = (u16)p_skip_line(p);
+	u32 plus = p_skip_line(p);
+	r->qual = (u32)p->pos; r->qual_len = (u16)p_skip_line(p);
+	r->trunc_len = 0;
+	return plus > 0 && r->seq_len == r->qual_len;
+}
+
 /* ------------------------------------------------------------------------
  * stats: src/Stats.h:44-101
  * ---------------------------------------------------------------------- */
@@ -413,13 +455,14 @@ static const char DNA_ORDER[] = "AGCTNRWSKMDVHBYXU.-";   /* src/RecordsProcessor
 static void block_parse(block_t* b)
 {
 	parser_t p = { b->mem, b->size, 0, 0 };
+	u64 cut = 0;
 	b->recs_cap = 8 * 1024; b->recs = (rec_t*)malloc(b->recs_cap * sizeof(rec_t));
 	b->n_recs = 0;
 	memset(b->raw, 0, sizeof(b->raw));
 	while (p.pos < p.size)
 	{
 		rec_t r;
-		if (!p_next_record(&p, &r)) break;
+		if (!(b->cfg->tag_preserve_flags ? p_next_record_ext(&p, &r, b->cfg->tag_preserve_flags, &cut) : p_next_record(&p, &r))) break;
 		if (b->n_recs + 1 >= b->recs_cap)
 		{
 			b->recs_cap *= 2; b->recs = (rec_t*)realloc(b->recs, b->recs_cap * sizeof(rec_t));
@@ -427,7 +470,7 @@ static void block_parse(block_t* b)
 		b->recs[b->n_recs++] = r;
 		b->raw[1] += r.title_len; b->raw[2] += r.seq_len; b->raw[3] += r.qual_len;
 	}
-	b->chunk_size = b->size - p.skipped;
+	b->chunk_size = b->size - cut - p.skipped;
 }
 
 /* PreprocessRecords: IRecordsProcessor::ProcessForward + Lossless/Lossy
@@ -484,6 +527,7 @@ static void block_preprocess(block_t* b)
 				if (sidx >= 4) { q = 0; keep = 0; }
 				else { if (q == 0) q = 1; keep = 1; }
 			}
+			seq[i] = sidx;                                       /* every base becomes its index in place, kept ones are then compacted */
 			if (keep) { seq[kept++] = sidx; s->d_freq[sidx < 20 ? sidx : 19]++; }
 			qua[i] = q;
 			s->q_freq[q]++;
@@ -1318,7 +1362,7 @@ static void tags_emit(block_t* b, bw_t* w)
  * ---------------------------------------------------------------------- */
 static int block_run(const orc_config* cfg, const u8* in, u64 size, bw_t* w, u64 raw[4], u64 comp[4], block_t* keep, u32* fields_cap)
 {
-	if (cfg->color_space || cfg->tag_preserve_flags) return ORC_E_UNSUPPORTED;
+	if (cfg->color_space) return ORC_E_UNSUPPORTED;
 	block_t b;
 	memset(&b, 0, sizeof(b));
 	b.cfg = cfg;
@@ -1328,7 +1372,7 @@ static int block_run(const orc_config* cfg, const u8* in, u64 size, bw_t* w, u64
 	memset(b.mem + size, '\n', 16);
 	b.size = size;
 	if (cfg->calc_crc32)
-		b.crc_flags = 1 | 2 | (cfg->lossy ? 0 : 4);
+		b.crc_flags = (cfg->tag_preserve_flags ? 0 : 1) | 2 | (cfg->lossy ? 0 : 4);      /* src/BlockCompressor.cpp:84-93 */
 
 	block_parse(&b);
 	if (b.n_recs == 0) { free(b.mem); free(b.recs); return ORC_E_INPUT; }
@@ -1346,7 +1390,7 @@ static int block_run(const orc_config* cfg, const u8* in, u64 size, bw_t* w, u64
 	if (b.flags & 2) bw_word(w, b.min_qlen);
 	if (cfg->calc_crc32)
 	{
-		bw_word(w, b.crc_tag);
+		if (b.crc_flags & 1) bw_word(w, b.crc_tag);
 		bw_word(w, b.crc_seq);
 		if (!cfg->lossy) bw_word(w, b.crc_qual);
 	}

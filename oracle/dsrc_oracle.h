@@ -24,7 +24,7 @@ typedef struct orc_config
 {
 	uint32_t dna_order;          /* CompressionSettings::dnaOrder     (src/Common.h:118) = level*3 */
 	uint32_t quality_order;      /* CompressionSettings::qualityOrder = level (lossless) / level*3 (lossy) */
-	uint64_t tag_preserve_flags; /* must be 0 (the -f filter is out of scope) */
+	uint64_t tag_preserve_flags; /* -f mask: bit k set = keep title field k (1-based), 0 = keep titles as they are */
 	int32_t  lossy;
 	int32_t  calc_crc32;
 	uint32_t quality_offset;     /* FastqDatasetType (src/Common.h:56-80) */
