@@ -151,7 +151,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	const bool lossy = h->set.lossy != 0, crc = h->set.calculate_crc32 != 0;
 
 	DsrcParams prm;
-	prm.dna_order = dna_order; prm.quality_order = qo; prm.lossy = lossy; prm.crc = crc;
+	prm.dna_order = dna_order; prm.quality_order = qo; prm.lossy = lossy; prm.crc = crc; prm.tag_flags = (u32)h->set.tag_preserve_flags;
 	prm.quality_offset = h->ds.quality_offset; prm.n_blocks = B; prm.max_tiles = 1;
 
 	std::vector<BlkDesc> desc(B);
@@ -209,14 +209,16 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(BlkDesc) * B, hipMemcpyHostToDevice, s));
 	hipLaunchKernelGGL(k_index_lines, dim3(prm.max_tiles, B), dim3(WG), 0, s, d_in, d_desc, d_tiles, d_lines, prm); KCHK();
 	hipLaunchKernelGGL(k_records, dim3((max_rec_cap + WG - 1) / WG, B), dim3(WG), 0, s, d_in, d_desc, d_state, d_lines, rp); KCHK();
+	if (prm.tag_flags) { hipLaunchKernelGGL(k_tag_filter, dim3((max_rec_cap + WG - 1) / WG, B), dim3(WG), 0, s, const_cast<u8*>(d_in), d_desc, d_state, rp, prm); KCHK(); }
 	hipLaunchKernelGGL(k_prep_stats, dim3(B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, prm); KCHK();
 	hipLaunchKernelGGL(k_rec_offsets, dim3(B), dim3(WG), 0, s, d_desc, d_state, rp); KCHK();
 	{
 		const u32 gx = std::max(1u, std::min(64u, (max_rec_cap + 4 * WAVES - 1) / (4 * WAVES)));
 		hipLaunchKernelGGL(k_prep_write, dim3(gx, B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, d_q, d_qp, d_d, prm); KCHK();
 	}
-	hipLaunchKernelGGL(k_tag_template, dim3((B + 63) / 64), dim3(64), 0, s, d_in, d_desc, d_state, rp, B); KCHK();
 	if (crc) { hipLaunchKernelGGL(k_crc, dim3(B, 3), dim3(WG), 0, s, d_in, d_desc, d_state, rp, h->d_crc_tab, prm); KCHK(); }
+	if (prm.tag_flags) { hipLaunchKernelGGL(k_tag_poke, dim3((max_rec_cap + WG - 1) / WG, B), dim3(WG), 0, s, const_cast<u8*>(d_in), d_desc, d_state, rp, prm); KCHK(); }
+	hipLaunchKernelGGL(k_tag_template, dim3((B + 63) / 64), dim3(64), 0, s, d_in, d_desc, d_state, rp, B); KCHK();
 	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
 	mark("S2");
@@ -718,7 +720,7 @@ template <typename F> int with_arena_retry_(dsrcgpu_handle* h, size_t initial, F
 int check_settings(dsrcgpu_handle* h, const dsrcgpu_settings* s, const dsrcgpu_dataset* d)
 {
 	if (!s || !d) return fail(h, DSRCGPU_E_ARG, "null settings/dataset");
-	if (s->tag_preserve_flags != 0) return fail(h, DSRCGPU_E_ARG, "tag field filter (-f) is not supported on the GPU path");
+	if (s->tag_preserve_flags & ~0x7FFFFFFEull) return fail(h, DSRCGPU_E_ARG, "tag field filter (-f): field numbers 1..30 only (the reference shifts a 32-bit int)");
 	if (d->color_space) return fail(h, DSRCGPU_E_ARG, "colour-space data sets are not supported on the GPU path");
 	if (d->quality_offset < 33 || d->quality_offset > 64) return fail(h, DSRCGPU_E_ARG, "quality offset %u outside [33,64]", d->quality_offset);
 	if (s->dna_order > 9) return fail(h, DSRCGPU_E_ARG, "dna_order %u > 9", s->dna_order);

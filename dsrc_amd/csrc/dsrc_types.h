@@ -44,6 +44,7 @@ struct DsrcParams   // uniform over a batch
 	u32 quality_offset;
 	u32 n_blocks;
 	u32 max_tiles;          // tiles per block upper bound (grid.x of the tile kernels)
+	u32 tag_flags;          // -f mask (bit k: keep title field k, 1-based); 0 = titles as they are
 };
 
 // numeric-field coding schemes, Field::NumericSchemeEnum (src/TagModeler.h:73)
@@ -95,6 +96,7 @@ struct BlkState  // device -> host (and device scratch)
 {
 	u32 err;
 	u32 n_term, n_crlf, n_lines;
+	i32 title_cut;          // -f: title bytes removed (FastqParserExt::totalBytesCut; -1 per record whose kept last field took its terminator along)
 	u32 first_bad, n_recs;
 	u32 q_total, d_total;
 	u32 raw_tag, raw_dna, raw_qua;      // fq::StreamsInfo raw sizes (src/FastqParser.cpp:152-158)

@@ -13,7 +13,7 @@ int main(int argc, const char* argv[])
 	setenv("GPU_MAX_HW_QUEUES", "24", 0);      // two HIP streams per scheduler instance; before the runtime starts
 	if (argc < 4 || argv[1][0] != 'c')
 	{
-		std::cerr << "usage: dsrc-amd c [-d<0-3>] [-q<0-2>] [-l] [-c] [-o<offset>] [-b<MB>] [-m<0-2>] [-v] [-g<device>] [-n<blocks per batch>] <in.fastq> <out.dsrc>\n"
+		std::cerr << "usage: dsrc-amd c [-d<0-3>] [-q<0-2>] [-l] [-c] [-f<fields>] [-o<offset>] [-b<MB>] [-m<0-2>] [-v] [-g<device>] [-n<blocks per batch>] <in.fastq> <out.dsrc>\n"
 					 "       (decompression: use the reference `dsrc d`; archives are bit-identical)\n";
 		return -1;
 	}
@@ -26,6 +26,19 @@ int main(int argc, const char* argv[])
 		const int v = strlen(a) > 2 ? atoi(a + 2) : -1;
 		switch (a[1])
 		{
+		case 'f':       // -f<1,2,...>: keep only these title fields (reference src/main.cpp:177-194)
+		{
+			const char* q = a + 2;
+			while (*q)
+			{
+				const int f = atoi(q);
+				if (f >= 1 && f <= 30) p.tagPreserveFlags |= 1ull << f;
+				else { std::cerr << "Error: invalid field number in -f (1-30)\n"; return -1; }
+				while (*q && *q != ',') ++q;
+				if (*q == ',') ++q;
+			}
+			break;
+		}
 		case 'o': p.qualityOffset = v; break;
 		case 'd': p.dnaCompressionLevel = v; break;
 		case 'q': p.qualityCompressionLevel = v; break;

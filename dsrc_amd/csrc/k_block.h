@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(64) k_meta_plan(BlkState* st, DsrcParams prm)
 	if ((u16)S->max_len != (u16)S->min_len) flags |= 2u;          // FLAG_VARIABLE_LENGTH
 	S->flags = flags;
 	u32 m = 16 + ((flags & 2u) ? 4u : 0u);
-	if (prm.crc) m += 4 + 4 + (prm.lossy ? 0u : 4u);
+	if (prm.crc) m += (prm.tag_flags ? 0u : 4u) + 4 + (prm.lossy ? 0u : 4u);      // CALC_TAG only without -f (src/BlockCompressor.cpp:84-93)
 	S->meta_bytes = m;
 }
 
@@ -35,11 +35,11 @@ __global__ void __launch_bounds__(WG) k_assemble(const BlkDesc* desc, const BlkS
 		store_be32(o + at, S->n_recs); at += 4;
 		store_be32(o + at, (u16)S->max_len); at += 4;
 		store_be32(o + at, S->flags); at += 4;
-		store_be32(o + at, d.in_size - S->n_crlf); at += 4;       // chunkSize = size - skipped LFs (src/FastqParser.cpp:163)
+		store_be32(o + at, (u32)((i32)(d.in_size - S->n_crlf) - S->title_cut)); at += 4;       // chunkSize = size - cut - skipped LFs (src/FastqParser.cpp:163,196)
 		if (S->flags & 2u) { store_be32(o + at, (u16)S->min_len); at += 4; }
 		if (prm.crc)
 		{
-			store_be32(o + at, S->crc_tag); at += 4;
+			if (!prm.tag_flags) { store_be32(o + at, S->crc_tag); at += 4; }
 			store_be32(o + at, S->crc_seq); at += 4;
 			if (!prm.lossy) { store_be32(o + at, S->crc_qua); at += 4; }
 		}

@@ -64,6 +64,72 @@ __device__ __forceinline__ bool tag_is_num(const u8* s, u32 len, u32* val)
 	return i == len && (len == 1 || (len == 0 ? true : s[0] != '0'));
 }
 
+// ---- -f: title field filter (FastqParserExt::ReadNextRecord, src/FastqParser.cpp:198-251) -----------------------
+// One lane per record rewrites its title IN PLACE, as the reference does: a field ends at a separator (or NUL) or at
+// the end of the title and is kept, including that end byte, iff its 1-based number is set in the mask.  The end
+// byte of the last field is the line terminator, so a kept last field makes the title one byte longer than the
+// text before it was; the unsigned "bytes cut" total then goes down by one (no assert in the release build).
+// The chunk text is modified (BlockCompressor::Store destroys its input as well).
+__global__ void __launch_bounds__(WG) k_tag_filter(u8* in, const BlkDesc* desc, BlkState* st, RecPools rp, DsrcParams prm)
+{
+	const u32 b = blockIdx.y;
+	const BlkDesc d = desc[b];
+	BlkState* S = &st[b];
+	u32 n_cand = (S->n_term + 1 + 3) / 4;
+	if (n_cand > d.rec_cap) n_cand = d.rec_cap;
+	const u32 n_recs = S->first_bad < n_cand ? S->first_bad : n_cand;
+	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_recs) return;
+	const u64 g = (u64)d.rec_base + r;
+	u8* t = in + d.in_off + rp.title_off[g];
+	const u32 tl = rp.title_len[g];
+	u32 field_no = 0, begin = 0, bp = 0;
+	bool ub = tl > 512;                                      // the reference's scratch buffer
+	// pieces move towards the front only (bp <= begin), so the copy can be done in place, front to back
+	for (u32 i = 0; i <= tl; ++i)
+	{
+		if (i != tl && !(tag_is_sep(t[i]) || t[i] == 0)) continue;
+		++field_no;
+		if (field_no >= 31) ub = true;                       // BIT(x) is a 32-bit shift in the reference
+		else if (prm.tag_flags & (1u << field_no))
+		{
+			const u32 end = (i == tl && (u64)rp.title_off[g] + tl >= d.in_size) ? i : i + 1;     // never touch bytes past the chunk
+			for (u32 k = begin; k < end; ++k) t[bp + (k - begin)] = t[k];
+			bp += i + 1 - begin;
+		}
+		begin = i + 1;
+	}
+	if (bp > 512) ub = true;
+	if (ub) { atomicOr(&S->err, (u32)DSRC_ERR_REF_UB); return; }
+	rp.title_len[g] = (u16)bp;
+	const i32 cut = (i32)tl - (i32)bp;
+	if (cut) atomicAdd(&S->title_cut, cut);
+}
+
+// A title that swallowed its one-byte terminator ends where the sequence line begins, and the tag tokenizer reads
+// the byte after a title as the last field's separator -- after ProcessForward has turned the sequence into base
+// indices in place (every base becomes its index, kept ones are then compacted to the front).  Reproduce that byte:
+// index of the first kept base, or of base 0 if none is kept.  Runs after every kernel that reads the sequence text.
+__global__ void __launch_bounds__(WG) k_tag_poke(u8* in, const BlkDesc* desc, const BlkState* st, RecPools rp, DsrcParams prm)
+{
+	const u32 b = blockIdx.y;
+	const BlkDesc d = desc[b];
+	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= st[b].n_recs) return;
+	const u64 g = (u64)d.rec_base + r;
+	const u32 so = rp.seq_off[g], len = rp.len[g];
+	if (rp.title_off[g] + rp.title_len[g] != so || len == 0) return;        // the title does not reach the sequence line
+	u8* p = in + d.in_off;
+	u32 first = 255;
+	for (u32 j = 0; j < len && first == 255; ++j)
+	{
+		u32 sidx; bool keep;
+		transform_base(p[so + j], p[rp.qual_off[g] + j], prm.quality_offset, prm.lossy, &sidx, &keep);
+		if (keep) first = sidx;
+	}
+	p[so] = (u8)(first != 255 ? first : dna_index(p[so]));
+}
+
 // ---- record 0 -> field template -----------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_tag_template(const u8* in, const BlkDesc* desc, BlkState* st, RecPools rp, u32 n_blocks)
 {

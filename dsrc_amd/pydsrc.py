@@ -75,8 +75,9 @@ class DsrcModule:
         self._threads = int(v)
 
     def Compress(self, inputFilename: str, outputFilename: str) -> None:
-        if self.TagFieldFilterMask:
-            raise RuntimeError("tag field filter (-f) is not supported on the GPU path")
+        mask = int(self.TagFieldFilterMask)
+        if mask & ~0x7FFFFFFE:
+            raise RuntimeError("TagFieldFilterMask: field numbers 1..30 only")
         if not os.path.exists(_CLI):
             raise RuntimeError(f"{_CLI} not built: python -c 'import __graft_entry__ as g; g.build()'")
         cmd = [_CLI, "c", f"-d{self._dna}", f"-q{self._qua}", f"-b{self._buf}", f"-t{min(self._threads, 8)}", f"-g{int(self.Device)}"]
@@ -84,6 +85,8 @@ class DsrcModule:
             cmd.append("-l")
         if self.Crc32Checking:
             cmd.append("-c")
+        if mask:
+            cmd.append("-f" + ",".join(str(k) for k in range(1, 31) if mask >> k & 1))
         r = subprocess.run(cmd + [inputFilename, outputFilename], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(r.stderr.strip() or "dsrc-amd failed")

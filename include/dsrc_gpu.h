@@ -30,7 +30,9 @@ typedef struct dsrcgpu_settings
 {
 	uint32_t dna_order;
 	uint32_t quality_order;
-	uint64_t tag_preserve_flags;   /* must be 0: the -f field filter (FastqParserExt) is not on the GPU path */
+	uint64_t tag_preserve_flags;   /* -f mask (FastqParserExt, src/FastqParser.cpp:167-251): bit k set = keep title field k, k = 1..30;
+	                                * 0 = titles as they are.  With a mask the chunk text is rewritten in place (device copy / the
+	                                * caller's device buffer in the *_device entry point), as BlockCompressor::Store does to its input */
 	uint8_t  lossy;
 	uint8_t  calculate_crc32;
 	uint8_t  reserved[6];

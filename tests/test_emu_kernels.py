@@ -176,9 +176,32 @@ def test_device_synth_matches_host(emu):
     assert got == synth.illumina_fastq(1200, first=999990)
 
 
+@pytest.mark.parametrize("seed", range(400, 405))
+def test_field_filter(emu, oracle, seed):
+    """-f: titles rewritten in place by k_tag_filter (FastqParserExt), incl. the kept last field that takes the line
+    terminator along and the index-transformed base the tokenizer then sees (k_tag_poke)."""
+    import dataclasses
+    data, desc = fuzz_fastq(seed, [30, 40, 120][seed % 3])
+    for flags in (0b10, 0b1010, 0b11110, 0x7FFFFFFE):
+        for d, q, lossy, crc in [(0, 0, False, True), (1, 1, False, False), (2, 1, True, True)]:
+            cfg = dataclasses.replace(Config.from_levels(d, q, lossy, crc), tag_flags=flags)
+            h = emu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset, tag_flags=flags)
+            try:
+                want = oracle.compress_block(cfg, data)
+            except RuntimeError as e:
+                assert "rc=-2" in str(e)
+                with pytest.raises(emu.DsrcGpuError):
+                    h.compress_block(data)
+                h.close()
+                continue
+            got = h.compress_block(data)
+            h.close()
+            assert got == want, (seed, desc, bin(flags), d, q, lossy, crc)
+
+
 def test_bad_arguments(emu):
     with pytest.raises(emu.DsrcGpuError):
-        emu.Handle(tag_flags=6)
+        emu.Handle(tag_flags=1 << 31)          # field numbers above 30 are undefined in the reference (32-bit BIT())
     with pytest.raises(emu.DsrcGpuError):
         emu.Handle(color_space=True)
     with pytest.raises(emu.DsrcGpuError):

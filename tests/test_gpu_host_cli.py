@@ -89,3 +89,15 @@ def test_pydsrc_module_names(files):
         m.DNACompressionLevel = 4
     with pytest.raises(RuntimeError):
         m.Decompress(ours, str(d / "x.fastq"))
+
+
+@pytest.mark.parametrize("fields", ["-f1,2", "-f2,4,5", "-f1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16"])
+def test_field_filter_archive_identical(files, fields):
+    """`-f`: the title field filter through the whole CLI, against `dsrc c -f... -t1`."""
+    if not os.path.exists(CLI) or not os.path.exists(REF_BIN):
+        pytest.skip("CLI missing")
+    d, ill, _ = files
+    ours = str(d / "f.dsrc"); theirs = str(d / "fr.dsrc")
+    _run([CLI, "c", "-d2", "-q1", "-c", fields, "-b1", "-n3", "-t3", ill, ours])
+    _run([REF_BIN, "c", "-d2", "-q1", "-c", fields, "-b1", "-t1", ill, theirs])
+    assert md5(ours) == md5(theirs)

@@ -152,6 +152,28 @@ def test_exact_division_selftest(gpu):
     h.close()
 
 
+@pytest.mark.parametrize("seed", range(400, 440))
+def test_field_filter(gpu, oracle, seed):
+    """-f on the GPU path (k_tag_filter / k_tag_poke) against the oracle's restatement of FastqParserExt."""
+    import dataclasses
+    data, desc = fuzz_fastq(seed, [None, 300, 3000][seed % 3])
+    for flags in (0b10, 0b1010, 0b11110, 0x7FFFFFFE, 0b100100):
+        for d, q, lossy, crc in [(0, 0, False, True), (3, 2, False, False), (2, 1, True, True)]:
+            cfg = dataclasses.replace(Config.from_levels(d, q, lossy, crc), tag_flags=flags)
+            h = gpu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset, tag_flags=flags)
+            try:
+                want = oracle.compress_block(cfg, data)
+            except RuntimeError as e:
+                assert "rc=-2" in str(e)
+                with pytest.raises(gpu.DsrcGpuError):
+                    h.compress_block(data)
+                h.close()
+                continue
+            got = h.compress_block(data)
+            h.close()
+            assert got == want, (seed, desc, bin(flags), d, q, lossy, crc)
+
+
 def test_device_synth_matches_host(gpu):
     h = gpu.Handle()
     cap = 2 << 20
