@@ -325,7 +325,7 @@ def main():
         alg = (in_bytes + out_bytes) / n_sub_total               # chunk read once + block written once, per sub-batch launch
         achieved = alg / (rc_ms / 1e3) / 1e9 if rc_ms > 0 else 0.0
         line = {
-            "metric": "raw FASTQ MB/s compressed (bit-identical .dsrc)", "value": round(value, 1), "unit": "MB/s",
+            "metric": f"raw FASTQ MB/s compressed (bit-identical .dsrc) at -d{args.dna} -q{args.qua}", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16/u32 integer",
             "data": f"synthetic (counter-based generator, in HBM; {lanes[0].n_res} distinct ~{sub_blocks * 8.4 / 1e3:.1f} GB shards per scheduler instance, cycled)",
