@@ -91,6 +91,21 @@ def main():
             if len(blk) <= 700:
                 e["hex"] = blk.hex()
             g["blocks"].append(e)
+        # -f (title field filter, FastqParserExt): kept last field / dropped middle fields, LF and CRLF input
+        if name in ("tiny", "illumina300", "illumina300_crlf", "fuzz1", "fuzz4", "fuzz7", "fuzz10", "fuzz13"):
+            import dataclasses
+            for flags in (0b110, 0b101010, 0x7FFFFFFE):
+                for d, q, lossy, crc in ((0, 0, False, True), (2, 1, True, False)):
+                    cfg = dataclasses.replace(Config.from_levels(d, q, lossy, crc), tag_flags=flags)
+                    try:
+                        o.compress_block(cfg, data)
+                    except RuntimeError as e:
+                        if "rc=-2" in str(e):
+                            continue
+                        raise
+                    blk, raw, comp = r.compress_block(cfg, data)
+                    g["blocks"].append({"name": name, "spec": spec, "in_sha256": sha(data), "levels": [d, q, lossy, crc], "tag_flags": flags,
+                                        "raw": raw, "comp": comp, "sha256": sha(blk), "size": len(blk)})
         if name in ("tiny", "illumina300", "iontorrent200", "fuzz1", "fuzz2", "fuzz5"):
             for lossy in (False, True):
                 dst, qst, recs, cs, raw = r.block_stats(Config(lossy=lossy), data)
