@@ -341,7 +341,7 @@ def main():
                          # i.e. exactly the 12-byte records read once + the 4-byte codes written once (profiles/r01_pmc_b512_p1_d3q2.txt)
                          "traffic": int(PMC_RC_BYTES_PER_BLOCK * sub_blocks), "kernel": "k_rc (range-coder arithmetic, one lane per stream; followed by k_rc_emit)",
                          "kernel_ms": round(rc_ms, 2), "launch_bytes": int(alg), "batch_ms": round(batch_ms, 2),
-                         "note": "algorithmic bytes = chunk bytes in + block bytes out of one sub-batch launch (SURVEY 8d); kernel_ms = k_rc + k_rc_emit from HIP events on the range-coder stream, measured while other scheduler instances share the GPU (alone: 174 ms)"},
+                         "note": "algorithmic bytes = chunk bytes in + block bytes out of one sub-batch launch (SURVEY 8d); kernel_ms = k_rc + k_rc_emit from HIP events on the range-coder stream, measured while other scheduler instances share the GPU (alone: 141 ms)"},
         }
         if not args.no_cpu and world == 1:
             ln = lanes[0]

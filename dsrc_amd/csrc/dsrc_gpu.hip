@@ -634,7 +634,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		HIPCHK(hipEventRecord(h->ev[4], s));
 		HIPCHK(hipStreamWaitEvent(h->rc_stream, h->ev[4], 0));
 		HIPCHK(hipEventRecord(h->ev[2], h->rc_stream));
-		hipLaunchKernelGGL(k_rc, dim3((NJ + RC_LANES - 1) / RC_LANES), dim3(64), 0, h->rc_stream, d_chains, NJ, AP<RcRec>(h, 0), AP<RcFin>(h, o_fin), d_state); KCHK();
+		hipLaunchKernelGGL(k_rc, dim3((NJ + RC_LANES - 1) / RC_LANES), dim3(128), 0, h->rc_stream, d_chains, NJ, AP<RcRec>(h, 0), AP<RcFin>(h, o_fin), d_state); KCHK();
 		hipLaunchKernelGGL(k_rc_emit, dim3(NJ), dim3(RC_EMIT_WG), 0, h->rc_stream, d_chains, AP<RcRec>(h, 0), AP<RcFin>(h, o_fin), wpool, d_state); KCHK();
 		HIPCHK(hipEventRecord(h->ev[3], h->rc_stream));
 		HIPCHK(hipStreamWaitEvent(s, h->ev[3], 0));

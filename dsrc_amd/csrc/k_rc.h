@@ -643,76 +643,96 @@ __device__ __forceinline__ void rc_load_group(RcRegs& g, const LDS_AS U4* row, u
 template <int J0, int J1>
 __device__ __forceinline__ void rc_dma(LDS_AS U4* buf, const u8* base, u32 pitch, u32 chunk_off, u32 n_live)
 {
-	if (threadIdx.x < 3 * RC_CHUNK / 4)
+	if (lane_id() < 3 * RC_CHUNK / 4)
 	{
 		const u8* sp = base + chunk_off + (u64)J0 * pitch;
 #pragma unroll
 		for (int j = J0; j < J1; ++j)
 		{
-			if ((u32)j < n_live) lds_dma16(sp, threadIdx.x * 16u, buf + j * RC_ROW_U4);      // n_live: constant RC_LANES in full waves
+			if ((u32)j < n_live) lds_dma16(sp, lane_id() * 16u, buf + j * RC_ROW_U4);      // n_live: constant RC_LANES in full waves
 			sp += pitch;
 		}
 	}
 }
 
-// one 64-symbol chunk: the chain's records are in `cur` (landed), r0 holds its first group; requests the
-// chunk after it into `nxt` and leaves that chunk's first group in r0
-__device__ __forceinline__ void rc_chunk(RcState& s, u32* codes, RcRegs& r0, RcRegs& r1, const LDS_AS U4* cur, LDS_AS U4* nxt, u32 t0, u32 n,
-										 const u8* base, u32 pitch, u32 n_live, u8* xb, u32* err, u32 fx)
+// one 64-symbol chunk of the coder wave: the chain's records are in `cur` (landed), r0 holds its first group
+__device__ __forceinline__ void rc_chunk(RcState& s, u32* codes, RcRegs& r0, RcRegs& r1, const LDS_AS U4* row, u32 t0, u32 n,
+										 u8* xb, u32* err, u32 fx)
 {
-	const u32 lane = threadIdx.x;
-	const u32 off = (t0 + RC_CHUNK) * (u32)sizeof(RcRec);
-	const u32 rowi = lane < RC_LANES ? lane : RC_LANES - 1;               // idle lanes read a valid row and code nothing
-	const LDS_AS U4* row = cur + rowi * RC_ROW_U4;
 	u32* c = codes + t0;
 	rc_load_group(r1, row, 1);
-	rc_dma<0, RC_LANES / 3>(nxt, base, pitch, off, n_live);
 	if (t0 + 1 * RC_GROUP <= n) rc_group(s, c, r0, row, 0, xb, err, fx);
 	rc_load_group(r0, row, 2);
-	rc_dma<RC_LANES / 3, 2 * RC_LANES / 3>(nxt, base, pitch, off, n_live);
 	if (t0 + 2 * RC_GROUP <= n) rc_group(s, c + RC_GROUP, r1, row, 1, xb, err, fx);
 	rc_load_group(r1, row, 3);
-	rc_dma<2 * RC_LANES / 3, RC_LANES>(nxt, base, pitch, off, n_live);
 	if (t0 + 3 * RC_GROUP <= n) rc_group(s, c + 2 * RC_GROUP, r0, row, 2, xb, err, fx);
-	lds_dma_wait();                                                        // the requests above have landed before row 0 of `nxt` is read
-	rc_load_group(r0, nxt + rowi * RC_ROW_U4, 0);
 	if (t0 + 4 * RC_GROUP <= n) rc_group(s, c + 3 * RC_GROUP, r1, row, 3, xb, err, fx);
 }
 
-// FULL: every lane of the wave has a chain; the last wave of a launch may be partial and then must not request rows
-// it does not have (one launch, two instantiations of the body: a wave only ever fetches the code of its own)
+// A workgroup is two waves.  Wave 0 codes (one lane = one chain, RC_LANES chains); wave 1 only issues the LDS-DMA
+// requests, one chunk ahead, so that the coder's instruction stream is the arithmetic and nothing else (the requests
+// were 1/5 of its issue slots).  They meet at one barrier per 64-symbol chunk: the loader arrives when the chunk
+// after the current one has landed, the coder when it has finished the current one -- after the barrier the loader
+// may overwrite the buffer the coder has just left.
+// FULL: every lane below RC_LANES has a chain; the last workgroup of a launch may be partial and then must not request
+// rows it does not have (one launch, two instantiations of the body: a wave only ever fetches the code of its own).
 template <bool FULL>
-__device__ __forceinline__ void rc_wave(const RcChain* chains, u32 n_chains, RcRec* rec_pool, RcFin* fin, BlkState* st, LDS_AS U4* buf_a, LDS_AS U4* buf_b, u8* s_xb)
+__device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains, RcRec* rec_pool, RcFin* fin, BlkState* st, LDS_AS U4* buf_a, LDS_AS U4* buf_b, u8* s_xb)
 {
-	__builtin_amdgcn_s_setprio(3);                                             // the serial wave wins issue arbitration against co-resident data-parallel waves
+	__builtin_amdgcn_s_setprio(3);                                             // the serial waves win issue arbitration against co-resident data-parallel waves
 	const u32 first_chain = blockIdx.x * RC_LANES;
-	const u32 lane = threadIdx.x, id = first_chain + lane;
+	const u32 lane = lane_id(), id = first_chain + lane;
+	const bool loader = wave_id() == 1;
 	const bool have = lane < RC_LANES && (FULL || id < n_chains);
 	const RcChain c = chains[have ? id : n_chains - 1];                        // idle lanes shadow a real chain's values and code nothing
 	const u32 n_live = FULL ? (u32)RC_LANES : n_chains - first_chain;
 	const u32 n = have ? c.n : 0;
+	const u32 n_full = n & ~(u32)(RC_GROUP - 1);
+	const u32 wave_full = (u32)__builtin_amdgcn_readfirstlane((int)wave_max(n_full));      // same value in both waves
+
+	if (loader)
+	{
+		if (!wave_full) return;
+		// the arrays of a wave's chains are c.pitch records apart (wave-uniform; idle lanes shadow the last chain's values)
+		const u8* base = uniform_ptr(rec_pool + __shfl(c.trip, 0));
+		const u32 pitch = (u32)__builtin_amdgcn_readfirstlane((int)(c.pitch * (u32)sizeof(RcRec)));
+		rc_dma<0, RC_LANES>(buf_a, base, pitch, 0, n_live);
+		lds_dma_wait();
+		__syncthreads();                                                       // chunk 0 is there
+		for (u32 t0 = 0; t0 < wave_full; t0 += 2 * RC_CHUNK)
+		{
+			rc_dma<0, RC_LANES>(buf_b, base, pitch, (t0 + RC_CHUNK) * (u32)sizeof(RcRec), n_live);
+			lds_dma_wait();
+			__syncthreads();                                                   // coder is through buf_a, chunk t0+64 is in buf_b
+			rc_dma<0, RC_LANES>(buf_a, base, pitch, (t0 + 2 * RC_CHUNK) * (u32)sizeof(RcRec), n_live);
+			lds_dma_wait();
+			__syncthreads();                                                   // coder is through buf_b, chunk t0+128 is in buf_a
+		}
+		return;
+	}
+
 	RcRec* p = rec_pool + c.trip;
 	u32* codes = (u32*)p;                                                      // code t overwrites bytes 4t..4t+3 of the chain's own array
 	u8* xb = s_xb + lane * RC_XB;
 	u32* err = &st[c.blk].err;
 	RcState s;
 	s.low = 0; s.range = 0xFFFFFFFFu;
-
-	const u32 n_full = n & ~(u32)(RC_GROUP - 1);
-	const u32 wave_full = (u32)__builtin_amdgcn_readfirstlane((int)wave_max(n_full));
 	if (wave_full)
 	{
-		// the arrays of a wave's chains are c.pitch records apart (wave-uniform; idle lanes shadow the last chain's values)
-		const u8* base = uniform_ptr(rec_pool + __shfl(c.trip, 0));
-		const u32 pitch = (u32)__builtin_amdgcn_readfirstlane((int)(c.pitch * (u32)sizeof(RcRec)));
+		const u32 rowi = lane < RC_LANES ? lane : RC_LANES - 1;               // idle lanes read a valid row and code nothing
+		const LDS_AS U4* row_a = buf_a + rowi * RC_ROW_U4;
+		const LDS_AS U4* row_b = buf_b + rowi * RC_ROW_U4;
 		RcRegs r0, r1;
-		rc_dma<0, RC_LANES>(buf_a, base, pitch, 0, n_live);
-		lds_dma_wait();
-		rc_load_group(r0, buf_a + (lane < RC_LANES ? lane : RC_LANES - 1) * RC_ROW_U4, 0);
+		__syncthreads();
+		rc_load_group(r0, row_a, 0);
 		for (u32 t0 = 0; t0 < wave_full; t0 += 2 * RC_CHUNK)
 		{
-			rc_chunk(s, codes, r0, r1, buf_a, buf_b, t0, n, base, pitch, n_live, xb, err, c.force_exact);
-			rc_chunk(s, codes, r0, r1, buf_b, buf_a, t0 + RC_CHUNK, n, base, pitch, n_live, xb, err, c.force_exact);
+			rc_chunk(s, codes, r0, r1, row_a, t0, n, xb, err, c.force_exact);
+			__syncthreads();
+			rc_load_group(r0, row_b, 0);
+			rc_chunk(s, codes, r0, r1, row_b, t0 + RC_CHUNK, n, xb, err, c.force_exact);
+			__syncthreads();
+			rc_load_group(r0, row_a, 0);
 		}
 	}
 	if (!have) return;
@@ -726,13 +746,13 @@ __device__ __forceinline__ void rc_wave(const RcChain* chains, u32 n_chains, RcR
 	F->n = nb + 8;
 }
 
-__global__ void __launch_bounds__(64) k_rc(const RcChain* chains, u32 n_chains, RcRec* rec_pool, RcFin* fin, BlkState* st)
+__global__ void __launch_bounds__(128) k_rc(const RcChain* chains, u32 n_chains, RcRec* rec_pool, RcFin* fin, BlkState* st)
 {
 	__shared__ U4 s_a[RC_LANES * RC_ROW_U4];
 	__shared__ U4 s_b[RC_LANES * RC_ROW_U4];
 	__shared__ u8 s_xb[64 * RC_XB];
-	if (blockIdx.x * RC_LANES + RC_LANES <= n_chains) rc_wave<true>(chains, n_chains, rec_pool, fin, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb);
-	else rc_wave<false>(chains, n_chains, rec_pool, fin, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb);
+	if (blockIdx.x * RC_LANES + RC_LANES <= n_chains) rc_workgroup<true>(chains, n_chains, rec_pool, fin, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb);
+	else rc_workgroup<false>(chains, n_chains, rec_pool, fin, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb);
 }
 
 // ---- byte emitter: codes -> stream bytes (data-parallel) ------------------------------------------
