@@ -245,7 +245,7 @@ def main():
     def worker(idx):
         try:
             if idx:
-                time.sleep(t_sub * idx / P)
+                time.sleep(t_sub * idx / P * float(os.environ.get("DSRC_BENCH_STAGGER", "1")))
             for s in range(first, total_steps):
                 if dist is not None:
                     gates.lane_may_start(s, first)
