@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off soak: many more fuzz seeds than the test-suite runs, GPU path vs oracle, for a bounded time.
 Usage: tools/fuzz_soak.py [first_seed] [seconds] [batch]"""
+import dataclasses
 import os
 import sys
 import time
@@ -58,9 +59,10 @@ def main():
     while time.time() - t0 < limit:
         nrec = [None, 3000, 7000][seed % 3]
         data, desc = fuzz_fastq(seed, nrec)
-        for d, q, lossy, crc in cfgs:
-            cfg = Config.from_levels(d, q, lossy, crc)
-            h = _lib.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc)
+        for ci, (d, q, lossy, crc) in enumerate(cfgs):
+            flags = [0, 0, 0b110, 0x7FFFFFFE, 0b101000, 0, 0b10, 0][(seed + ci) % 8]      # -f masks on some
+            cfg = dataclasses.replace(Config.from_levels(d, q, lossy, crc), tag_flags=flags)
+            h = _lib.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, tag_flags=flags)
             try:
                 want = o.compress_block(cfg, data)
             except RuntimeError as e:
