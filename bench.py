@@ -328,7 +328,7 @@ def main():
             "metric": f"raw FASTQ MB/s compressed (bit-identical .dsrc) at -d{args.dna} -q{args.qua}", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16/u32 integer",
-            "data": f"synthetic (counter-based generator, in HBM; {lanes[0].n_res} distinct ~{sub_blocks * 8.4 / 1e3:.1f} GB shards per scheduler instance, cycled)",
+            "data": f"synthetic (counter-based generator, in HBM; {lanes[0].n_res} distinct ~{sub_blocks * 8.4 / 1e3:.1f} GB shards per scheduler instance = {P * lanes[0].n_res * sub_blocks * 8.4 / 1e3:.1f} GB of distinct records per GPU, cycled)",
             "config": {"workload": f"Synthetic Illumina 150 bp FASTQ, 100M-read data set shape (BASELINE configs[2]), -d{args.dna} -q{args.qua} -b8; "
                                    f"step = {args.blocks} consecutive 8 MiB chunks per GPU, device-resident, {P} scheduler instances per GPU",
                        "blocks_per_step": args.blocks, "pipeline": P,
