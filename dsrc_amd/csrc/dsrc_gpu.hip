@@ -414,6 +414,11 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 				j.rescale_shift = 7 - log2u(rescale); j.translate = 1; j.out_byte0 = 33; j.scheme = D.q_scheme;
 			}
 			if (j.order > 7) return fail(h, DSRCGPU_E_ARG, "quality order %u not supported", j.order);
+			if (S.min_len == S.max_len && S.max_len >= 1 && S.max_len <= 65535)
+			{
+				const u64 m = ((1ull << 48) + S.max_len - 1) / S.max_len;
+				j.qlen = S.max_len; j.qm_lo = (u32)m; j.qm_hi = (u32)(m >> 32);
+			}
 			j.alpha_bits = log2u(j.n_alpha); j.key_bits = j.alpha_bits * (j.order + 1);
 			j.out_words = D.qua_out; j.out_cap = D.qua_cap * 4 - j.out_byte0 - 16;
 			qjobs.push_back(j);

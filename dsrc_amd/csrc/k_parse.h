@@ -323,6 +323,7 @@ __global__ void __launch_bounds__(WG) k_prep_write(const u8* in, const BlkDesc* 
 	const u8* p = in + d.in_off;
 	const u32 n_recs = st[b].n_recs;
 	const u32 lane = lane_id();
+	const bool write_qp = st[b].min_len != st[b].max_len;      // reads of one length: the position context is a closed form of t (qua_pctx)
 	const u32 waves_total = gridDim.x * (blockDim.x >> 6);
 	for (u32 r = blockIdx.x * (blockDim.x >> 6) + wave_id(); r < n_recs; r += waves_total)
 	{
@@ -340,7 +341,7 @@ __global__ void __launch_bounds__(WG) k_prep_write(const u8* in, const BlkDesc* 
 			if (in_r) q = transform_base(p[so + j], p[qo + j], prm.quality_offset, prm.lossy, &sidx, &keep);
 			const bool k2 = in_r && keep;
 			const u64 km = __ballot(k2);
-			if (in_r) { qs[j] = (u8)q; qps[j] = (u8)((j * 128u) / len); }
+			if (in_r) { qs[j] = (u8)q; if (write_qp) qps[j] = (u8)((j * 128u) / len); }
 			if (k2) ds[run + (u32)__popcll(km & lanemask_lt())] = (u8)sidx;
 			run += (u32)__popcll(km);
 		}

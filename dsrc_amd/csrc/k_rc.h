@@ -45,10 +45,28 @@ struct CtxJob     // one (block, stream)
 	u32 is_dna;
 	u32 scheme;         // scheme byte of the stream prologue
 	u32 n_alpha;        // alphabet size (replay template selector)
+	u32 qlen;           // quality: read length if every read of the block has the same one (then qp_stream does not exist), else 0
+	u32 qm_lo, qm_hi;   // ceil(2^48 / qlen) for exact_div
 	u32 pad0;
 };
 
 typedef u64 __attribute__((aligned(1))) u64_unaligned;
+
+// floor(n / d) for n < 2^32, d <= 2^16 with m = ceil(2^48 / d) (same identity as rc_div)
+__device__ __forceinline__ u32 exact_div(u32 n, u32 m_lo, u32 m_hi)
+{
+	const u64 p = (u64)n * m_hi + __umulhi(n, m_lo);
+	return (u32)(p >> 16);
+}
+
+// position context of quality symbol t: floor(j * 128 / len) >> shift, j = position inside the read.  With reads of one
+// length j = t mod len is a closed form of t and no qp_stream is needed; otherwise k_prep_write stored floor(j*128/len).
+__device__ __forceinline__ u32 qua_pctx(const CtxJob& j, const u8* qp, u32 t)
+{
+	if (j.qlen == 0) return (u32)qp[t] >> j.rescale_shift;
+	const u32 pos = t - exact_div(t, j.qm_lo, j.qm_hi) * j.qlen;
+	return exact_div(pos * 128u, j.qm_lo, j.qm_hi) >> j.rescale_shift;
+}
 
 // ---- DNA context: hash of the previous `order` symbols, carried across records --------------
 // (TDnaRCOrderModeler::UpdateHash, src/DnaModelerRCO.h:121-131).  Element of symbol t:
@@ -126,7 +144,7 @@ __device__ __forceinline__ u64 ctx_elem_qua(const CtxJob& j, const u8* s, const 
 			const u32 x = (slot < half || order == 1) ? v[slot] : ((v[slot] + v[slot + 1]) >> 1);
 			h = (h << ab) | x;
 		}
-	const u32 pctx = qp[t] >> j.rescale_shift;
+	const u32 pctx = qua_pctx(j, qp, t);
 	const u32 ctx = (h << ab) | pctx;
 	const u32 sym = rank[cur] & ((1u << ab) - 1u);
 	return ((u64)ctx << ELEM_CTX_SHIFT) | ((u64)sym << ELEM_SYM_SHIFT) | t;
@@ -145,7 +163,7 @@ __device__ __forceinline__ u32 ctx_digit0(const CtxJob& j, const u8* s, const u8
 	if (2 * j.alpha_bits >= j.dbits)
 	{	// position context + slot 0, which is always the raw previous symbol
 		const u32 v0 = t >= 1 ? rank[s[t - 1]] : 0u;
-		return ((v0 << j.alpha_bits) | (qp[t] >> j.rescale_shift)) & dmask;
+		return ((v0 << j.alpha_bits) | qua_pctx(j, qp, t)) & dmask;
 	}
 	return (u32)(ctx_elem_qua(j, s, qp, rank, t) >> ELEM_CTX_SHIFT) & dmask;
 }
