@@ -204,7 +204,26 @@ __global__ void __launch_bounds__(SORT_WG) k_sort(const CtxJob* jobs, u64* pool,
 	__syncthreads();
 	{	// histogram of digit 0
 		bool bad = false;
-		for (u32 i = threadIdx.x; i < n; i += blockDim.x)
+		u32 i_from = 0;
+		if (j.is_dna && j.alpha_bits == 2 && j.dbits <= 10 && n >= 16)
+		{	// 2-bit bases: the digits of four consecutive symbols t..t+3 come out of ONE 8-byte window s[t-5 .. t+2]
+			// (packed newest-last, symbol t+i is the 10-bit field at bit 6-2i); the histogram does not care about order
+			const u32 dmask = (bins - 1) & (u32)((1ull << (2 * j.order)) - 1ull);
+			const u32 n4 = (n - 8) / 4;                                   // groups starting at t = 8, 12, ...
+			for (u32 g = threadIdx.x; g < n4; g += blockDim.x)
+			{
+				const u32 t = 8 + 4 * g;
+				const u64 w = *(const u64_unaligned*)(sym_src + t - 5);
+				if ((w & 0xFCFCFCFCFCFCFCFCull) || sym_src[t + 3] >= 4) bad = true;
+				const u32 R = pack2x8(__builtin_bswap64(w));                 // byte b of w at bits 2*(7-b)
+#pragma unroll
+				for (u32 k = 0; k < 4; ++k) atomicAdd(&s_base[(R >> (6 - 2 * k)) & dmask], 1u);
+			}
+			// symbols 0..7 and the tail go the general way
+			for (u32 i = threadIdx.x; i < 8; i += blockDim.x) atomicAdd(&s_base[ctx_digit0(j, sym_src, qp, s_rank, i, bins - 1, &bad)], 1u);
+			i_from = 8 + 4 * n4;
+		}
+		for (u32 i = i_from + threadIdx.x; i < n; i += blockDim.x)
 		{
 			atomicAdd(&s_base[ctx_digit0(j, sym_src, qp, s_rank, i, bins - 1, &bad)], 1u);
 		}
