@@ -51,6 +51,7 @@ struct CtxJob     // one (block, stream)
 };
 
 typedef u64 __attribute__((aligned(1))) u64_unaligned;
+typedef u32 __attribute__((aligned(1))) u32_unaligned;
 
 // floor(n / d) for n < 2^32, d <= 2^16 with m = ceil(2^48 / d) (same identity as rc_div)
 __device__ __forceinline__ u32 exact_div(u32 n, u32 m_lo, u32 m_hi)
@@ -222,6 +223,28 @@ __global__ void __launch_bounds__(SORT_WG) k_sort(const CtxJob* jobs, u64* pool,
 			// symbols 0..7 and the tail go the general way
 			for (u32 i = threadIdx.x; i < 8; i += blockDim.x) atomicAdd(&s_base[ctx_digit0(j, sym_src, qp, s_rank, i, bins - 1, &bad)], 1u);
 			i_from = 8 + 4 * n4;
+		}
+		if (!j.is_dna && j.qlen && 2 * j.alpha_bits >= j.dbits && n >= 16)
+		{	// quality with reads of one length: digit = (rank of s[t-1] << ab | position context) -- four consecutive
+			// symbols share one 4-byte window s[t-1 .. t+2] and one division for the position inside the read
+			const u32 dmask = bins - 1;
+			const u32 n4 = (n - 1) / 4;                                   // groups starting at t = 1, 5, ...
+			for (u32 g = threadIdx.x; g < n4; g += blockDim.x)
+			{
+				const u32 t = 1 + 4 * g;
+				const u32 w = *(const u32_unaligned*)(sym_src + t - 1);
+				u32 pos = t - exact_div(t, j.qm_lo, j.qm_hi) * j.qlen;
+#pragma unroll
+				for (u32 k = 0; k < 4; ++k)
+				{
+					const u32 v0 = s_rank[(w >> (8 * k)) & 0xFFu];
+					const u32 pc = exact_div(pos * 128u, j.qm_lo, j.qm_hi) >> j.rescale_shift;
+					atomicAdd(&s_base[((v0 << j.alpha_bits) | pc) & dmask], 1u);
+					pos = pos + 1 == j.qlen ? 0u : pos + 1;
+				}
+			}
+			if (threadIdx.x == 0) atomicAdd(&s_base[ctx_digit0(j, sym_src, qp, s_rank, 0, bins - 1, &bad)], 1u);
+			i_from = 1 + 4 * n4;
 		}
 		for (u32 i = i_from + threadIdx.x; i < n; i += blockDim.x)
 		{
