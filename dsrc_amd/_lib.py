@@ -19,7 +19,7 @@ EXPORTS = [
     "dsrcgpu_compress_batch_device", "dsrcgpu_submit", "dsrcgpu_flush", "dsrcgpu_collect", "dsrcgpu_release",
     "dsrcgpu_last_timing", "dsrcgpu_synth_illumina", "dsrcgpu_dev_alloc", "dsrcgpu_dev_free", "dsrcgpu_dev_upload",
     "dsrcgpu_dev_download", "dsrcgpu_chain_create", "dsrcgpu_chain_destroy", "dsrcgpu_set_chain", "dsrcgpu_host_alloc",
-    "dsrcgpu_host_free", "dsrcgpu_selftest",
+    "dsrcgpu_host_free", "dsrcgpu_selftest", "dsrcgpu_set_record_layout",
 ]
 
 
@@ -62,6 +62,7 @@ def load():
     L.dsrcgpu_chain_destroy.restype = None
     L.dsrcgpu_chain_destroy.argtypes = [C.c_void_p]
     L.dsrcgpu_set_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.dsrcgpu_set_record_layout.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     _lib = L
     return L
 
@@ -118,6 +119,12 @@ class Handle:
     def set_chain(self, chain, seq: int):
         """The next batch call on this handle is batch number `seq` of `chain` (None detaches)."""
         self._chk(self.L.dsrcgpu_set_chain(self.h, chain.c if chain is not None else None, C.c_uint64(seq)))
+
+    def set_record_layout(self, chunk_sizes):
+        """The next batch call compresses chunks assembled from records (reference: BlockCompressorExt);
+        chunk_sizes[i] is block i's chunkSize word."""
+        arr = (C.c_uint32 * len(chunk_sizes))(*[v & 0xFFFFFFFF for v in chunk_sizes])
+        self._chk(self.L.dsrcgpu_set_record_layout(self.h, len(chunk_sizes), arr))
 
     def compress_block(self, data: bytes):
         cap = len(data) + (1 << 16)

@@ -72,6 +72,7 @@ struct dsrcgpu_handle
 	Arena arena;
 	u64 arena_fixed = 0;
 	u32 fields_cap = 0;              // capacity of the reference's TagStats::fields vector, carried block to block
+	std::vector<u32> rec_chunk_sizes; // dsrcgpu_set_record_layout: applies to the next batch, then cleared
 	dsrcgpu_chain* chain = nullptr;  // if set: fields_cap comes from / goes to the chain, in batch order
 	uint64_t chain_seq = 0; bool chain_taken = false; u32 chain_cap_in = 0;
 	u32* d_crc_tab = nullptr;
@@ -153,6 +154,9 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	DsrcParams prm;
 	prm.dna_order = dna_order; prm.quality_order = qo; prm.lossy = lossy; prm.crc = crc; prm.tag_flags = (u32)h->set.tag_preserve_flags;
 	prm.quality_offset = h->ds.quality_offset; prm.n_blocks = B; prm.max_tiles = 1;
+	prm.record_layout = h->rec_chunk_sizes.empty() ? 0u : 1u;
+	if (prm.record_layout && (h->rec_chunk_sizes.size() != B || prm.tag_flags || crc))
+		return fail(h, DSRCGPU_E_ARG, "record layout: one chunkSize per chunk of the batch, no field filter, no CRC (src/DsrcArchive.cpp:33-47)");
 
 	std::vector<BlkDesc> desc(B);
 	std::vector<BlkState> st(B);
@@ -162,6 +166,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	{
 		if (io.sizes[b] == 0 || io.sizes[b] >= (1ull << 31)) return fail(h, DSRCGPU_E_ARG, "chunk %u: size %llu out of range", b, (unsigned long long)io.sizes[b]);
 		desc[b].in_off = io.offs[b]; desc[b].in_size = (u32)io.sizes[b];
+		if (prm.record_layout) desc[b].chunk_size_value = h->rec_chunk_sizes[b];
 		desc[b].n_tiles = (u32)((io.sizes[b] + DSRC_TILE_BYTES - 1) / DSRC_TILE_BYTES);
 		prm.max_tiles = std::max(prm.max_tiles, desc[b].n_tiles);
 		in_total += io.sizes[b];
@@ -217,7 +222,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		hipLaunchKernelGGL(k_prep_write, dim3(gx, B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, d_q, d_qp, d_d, prm); KCHK();
 	}
 	if (crc) { hipLaunchKernelGGL(k_crc, dim3(B, 3), dim3(WG), 0, s, d_in, d_desc, d_state, rp, h->d_crc_tab, prm); KCHK(); }
-	if (prm.tag_flags) { hipLaunchKernelGGL(k_tag_poke, dim3((max_rec_cap + WG - 1) / WG, B), dim3(WG), 0, s, const_cast<u8*>(d_in), d_desc, d_state, rp, prm); KCHK(); }
+	if (prm.tag_flags || prm.record_layout) { hipLaunchKernelGGL(k_tag_poke, dim3((max_rec_cap + WG - 1) / WG, B), dim3(WG), 0, s, const_cast<u8*>(d_in), d_desc, d_state, rp, prm); KCHK(); }
 	hipLaunchKernelGGL(k_tag_template, dim3((B + 63) / 64), dim3(64), 0, s, d_in, d_desc, d_state, rp, B); KCHK();
 	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
@@ -703,6 +708,7 @@ template <typename F> int with_arena_retry(dsrcgpu_handle* h, size_t initial, F&
 {
 	const int rc = with_arena_retry_(h, initial, body);
 	if (rc != DSRCGPU_OK) chain_abort(h);
+	h->rec_chunk_sizes.clear();           // dsrcgpu_set_record_layout is one-shot
 	return rc;
 }
 
@@ -845,6 +851,14 @@ int dsrcgpu_compress_batch(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* 
 		BatchIO io{d_in, offs.data(), sizes, n, nullptr, 0, blocks, blocks_cap, block_offs, block_sizes, raw_sizes, comp_sizes};
 		return run_batch(h, io);
 	});
+}
+
+int dsrcgpu_set_record_layout(dsrcgpu_handle* h, uint32_t n, const uint32_t* chunk_sizes)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	if (n && !chunk_sizes) return fail(h, DSRCGPU_E_ARG, "null argument");
+	h->rec_chunk_sizes.assign(chunk_sizes, chunk_sizes + n);
+	return DSRCGPU_OK;
 }
 
 int dsrcgpu_compress_block(dsrcgpu_handle* h, const uint8_t* fastq, uint64_t size, uint8_t* block, uint64_t block_cap, uint64_t* block_size,

@@ -45,6 +45,7 @@ struct DsrcParams   // uniform over a batch
 	u32 n_blocks;
 	u32 max_tiles;          // tiles per block upper bound (grid.x of the tile kernels)
 	u32 tag_flags;          // -f mask (bit k: keep title field k, 1-based); 0 = titles as they are
+	u32 record_layout;      // chunks assembled by the record-level API (BlockCompressorExt): see dsrcgpu_set_record_layout
 };
 
 // numeric-field coding schemes, Field::NumericSchemeEnum (src/TagModeler.h:73)
@@ -82,6 +83,8 @@ struct BlkDesc   // host -> device
 	u32 rec_base;           // into the per-record pools
 	u32 rec_cap;
 	u32 fields_keep_from;   // first field index whose record-0 double count survives
+	u32 chunk_size_value;   // record layout: the chunkSize word of the block's meta stream (running total, src/BlockCompressorExt.cpp:126)
+	u32 pad0;
 	u64 q_base, d_base;     // quality / DNA symbol streams (bytes)
 	// per-stream staging of the compressed block (u32 words, MSB-first "logical big-endian")
 	u64 tag_out, qua_out, dna_out;        // u32 index

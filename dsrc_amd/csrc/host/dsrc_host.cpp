@@ -593,6 +593,170 @@ void DsrcModule::Compress(const std::string& in, const std::string& out)
 	if (!op.Process(p)) throw DsrcException(op.GetError());
 }
 
+// ---- FastqFile --------------------------------------------------------------------------------------------------
+FastqFile::~FastqFile() { if (file) fclose(file); }
+
+void FastqFile::Open(const std::string& filename_)
+{
+	if (file) throw DsrcException("Invalid state");
+	file = fopen(filename_.c_str(), "rb");
+	if (!file) throw DsrcException(("Cannot open file to read:" + filename_).c_str());
+	writing = false;
+}
+
+void FastqFile::Create(const std::string& filename_)
+{
+	if (file) throw DsrcException("Invalid state");
+	file = fopen(filename_.c_str(), "wb");
+	if (!file) throw DsrcException(("Cannot open file to write:" + filename_).c_str());
+	writing = true;
+}
+
+void FastqFile::Close()
+{
+	if (!file) throw DsrcException("Invalid state");
+	fclose(file); file = nullptr;
+}
+
+bool FastqFile::ReadString(std::string& str_)
+{
+	str_.clear();
+	int c;
+	while ((c = getc_unlocked(file)) != EOF && c != '\n') str_.push_back((char)c);
+	return !str_.empty();
+}
+
+bool FastqFile::ReadNextRecord(FastqRecord& rec_)
+{
+	if (!file || writing) throw DsrcException("Invalid state");
+	return ReadString(rec_.tag) && ReadString(rec_.sequence) && ReadString(rec_.plus) && ReadString(rec_.quality);
+}
+
+void FastqFile::WriteNextRecord(const FastqRecord& rec_)
+{
+	if (!file || !writing) throw DsrcException("Invalid state");
+	const std::string* part[4] = {&rec_.tag, &rec_.sequence, &rec_.plus, &rec_.quality};
+	for (const std::string* p : part) { fwrite(p->data(), 1, p->size(), file); putc_unlocked('\n', file); }
+}
+
+// ---- DsrcArchive (write side) -----------------------------------------------------------------------------------
+struct DsrcArchive::ArchiveImpl
+{
+	enum State { StateNone, StateCompression } state = StateNone;
+	dsrcgpu_handle* h = nullptr;
+	comp::ArchiveWriter* writer = nullptr;
+	comp::CompressionSettings settings;
+	fq::FastqDatasetType type;
+	uint64 bufferSize = 0;
+	// chunks waiting for the GPU: FASTQ text without the last newline + the chunkSize word of the block
+	std::vector<std::vector<uchar> > chunks;
+	std::vector<uint32_t> chunkSizes;
+	std::vector<uchar> cur;          // chunk being filled
+	uint64 curPayload = 0;           // title + sequence + quality bytes in `cur` (BlockCompressorExt::ChunkSize)
+	uint64 runningSize = 0;          // chunkHeader.chunkSize: never cleared between blocks (src/BlockCompressor.cpp:105-109)
+	uint64 pendingBytes = 0;
+	void Release()
+	{
+		if (h) { dsrcgpu_destroy(h); h = nullptr; }
+		delete writer; writer = nullptr;
+		chunks.clear(); chunkSizes.clear(); cur.clear(); curPayload = runningSize = pendingBytes = 0;
+		state = StateNone;
+	}
+};
+
+DsrcArchive::DsrcArchive() : impl(new ArchiveImpl()) { params.qualityOffset = 0; }
+DsrcArchive::~DsrcArchive() { impl->Release(); delete impl; }
+
+void DsrcArchive::StartCompress(const std::string& filename_)
+{
+	if (impl->state != ArchiveImpl::StateNone) throw DsrcException("Invalid state");
+	// ArchiveSettings::FromInputParams (src/DsrcArchive.cpp:33-47)
+	impl->settings = comp::CompressionSettings();
+	impl->settings.dnaOrder = params.dnaCompressionLevel * 3;
+	impl->settings.qualityOrder = params.qualityCompressionLevel * 3;
+	impl->settings.lossy = params.lossyCompression;
+	impl->type.qualityOffset = params.qualityOffset;
+	impl->type.plusRepetition = plusRepetition;
+	impl->type.colorSpace = colorSpace;
+	impl->bufferSize = (uint64)params.fastqBufferSizeMB << 20;
+	if (!impl->settings.lossy && impl->settings.qualityOrder != 0)
+		throw DsrcException("DsrcArchive: lossless quality levels 1-2 are undefined in the reference's archive API (qualityOrder = 3 * level, src/DsrcArchive.cpp:42); use level 0 or lossy mode");
+	if (impl->type.qualityOffset == 0)
+		throw DsrcException("DsrcArchive: set the quality offset (33 or 64); the archive API does not analyse the data");
+	comp::InputParameters args = params;
+	impl->h = comp::DsrcCompressorGPU::CreateInstance(args, impl->settings, impl->type);
+	try
+	{
+		impl->writer = new comp::ArchiveWriter();
+		impl->writer->Start(filename_);
+	}
+	catch (...) { impl->Release(); throw; }
+	impl->state = ArchiveImpl::StateCompression;
+}
+
+void DsrcArchive::WriteNextRecord(const FastqRecord& rec_)
+{
+	if (impl->state != ArchiveImpl::StateCompression) throw DsrcException("Invalid state");
+	const std::string* part[4] = {&rec_.tag, &rec_.sequence, &rec_.plus, &rec_.quality};
+	// what the reference leaves undefined is refused here
+	if (rec_.tag.empty() || rec_.tag[0] != '@' || rec_.plus.empty() || rec_.plus[0] != '+' || rec_.sequence.empty()
+		|| rec_.sequence.size() != rec_.quality.size() || rec_.sequence.size() > 65535 || rec_.tag.size() > 65535)
+		throw DsrcException("DsrcArchive::WriteNextRecord: malformed record (tag '@...', plus '+...', sequence and quality of equal non-zero length)");
+	for (const std::string* p : part)
+		if (p->find('\n') != std::string::npos || p->find('\r') != std::string::npos)
+			throw DsrcException("DsrcArchive::WriteNextRecord: line terminators inside a record string");
+	std::vector<uchar>& c = impl->cur;
+	for (const std::string* p : part) { c.insert(c.end(), p->begin(), p->end()); c.push_back('\n'); }
+	impl->curPayload += rec_.tag.size() + rec_.sequence.size() + rec_.quality.size();
+	impl->runningSize += rec_.tag.size() + rec_.sequence.size() + rec_.plus.size() + rec_.quality.size() + 4;    // BlockCompressorExt::RecordSize
+	if (impl->curPayload > impl->bufferSize) CloseChunk();
+}
+
+void DsrcArchive::CloseChunk()
+{
+	impl->cur.pop_back();                                    // Store()'s chunks carry no final newline
+	impl->pendingBytes += impl->cur.size();
+	impl->chunks.emplace_back(); impl->chunks.back().swap(impl->cur);
+	impl->chunkSizes.push_back((uint32_t)impl->runningSize);
+	impl->curPayload = 0;
+	if (impl->pendingBytes >= (1536ull << 20)) FlushBatch();
+}
+
+void DsrcArchive::FlushBatch()
+{
+	const uint32 n = (uint32)impl->chunks.size();
+	if (n == 0) return;
+	std::vector<const uint8_t*> ptrs(n); std::vector<uint64_t> sizes(n), offs(n), osz(n), raw(4 * n), comp(4 * n);
+	uint64 cap = 0;
+	for (uint32 i = 0; i < n; ++i) { ptrs[i] = impl->chunks[i].data(); sizes[i] = impl->chunks[i].size(); cap += sizes[i] + (1u << 16); }
+	std::vector<uchar> out(cap);
+	if (dsrcgpu_set_record_layout(impl->h, n, impl->chunkSizes.data()) != DSRCGPU_OK
+		|| dsrcgpu_compress_batch(impl->h, n, ptrs.data(), sizes.data(), out.data(), cap, offs.data(), osz.data(), raw.data(), comp.data()) != DSRCGPU_OK)
+	{
+		const std::string msg = dsrcgpu_last_error(impl->h);
+		impl->Release();
+		throw DsrcException(msg);
+	}
+	for (uint32 i = 0; i < n; ++i) impl->writer->WriteBlock(out.data() + offs[i], osz[i], (const uint64*)&raw[4 * i], (const uint64*)&comp[4 * i]);
+	impl->chunks.clear(); impl->chunkSizes.clear(); impl->pendingBytes = 0;
+}
+
+void DsrcArchive::FinishCompress()
+{
+	if (impl->state != ArchiveImpl::StateCompression) throw DsrcException("Invalid state");
+	if (impl->curPayload > 0) CloseChunk();
+	FlushBatch();
+	impl->writer->Finish(impl->type, impl->settings);
+	impl->Release();
+}
+
+void DsrcArchive::StartDecompress(const std::string&)
+{
+	throw DsrcException("DsrcArchive: reading records needs the block decompressor, which is not part of the MI355X path yet (SURVEY 8f-1); use the reference's DsrcArchive");
+}
+bool DsrcArchive::ReadNextRecord(FastqRecord&) { throw DsrcException("Invalid state"); }
+void DsrcArchive::FinishDecompress() { throw DsrcException("Invalid state"); }
+
 void DsrcModule::Decompress(const std::string&, const std::string&)
 {
 	throw DsrcException("Decompression is not part of the MI355X hot path (SURVEY 8f-1); use the reference's DsrcModule::Decompress");

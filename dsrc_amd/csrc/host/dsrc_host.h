@@ -110,9 +110,9 @@ class DsrcCompressorGPU : public IDsrcOperator
 {
 public:
 	bool Process(const InputParameters& args_);
+	static dsrcgpu_handle* CreateInstance(const InputParameters& args_, const CompressionSettings& settings_, const fq::FastqDatasetType& type_);
 private:
 	bool ProcessStream(const InputParameters& args_, FILE* in_);      // stdin / pipes: one scheduler instance
-	static dsrcgpu_handle* CreateInstance(const InputParameters& args_, const CompressionSettings& settings_, const fq::FastqDatasetType& type_);
 	void LogSizes(const ArchiveWriter& writer_);
 };
 
@@ -178,9 +178,73 @@ public:
 	bool IsCrc32Checking() const { return params.calculateCrc32; }
 	void SetTagFieldFilterMask(uint64 mask_) { params.tagPreserveFlags = mask_; }
 	uint64 GetTagFieldFilterMask() const { return params.tagPreserveFlags; }
+	void SetPlusRepetition(bool use_) { plusRepetition = use_; }
+	bool IsPlusRepetition() const { return plusRepetition; }
+	void SetColorSpace(bool use_) { colorSpace = use_; }
+	bool IsColorSpace() const { return colorSpace; }
 	void SetDevice(int device_) { params.device = device_; }
 protected:
 	comp::InputParameters params;
+	bool plusRepetition = false, colorSpace = false;
+};
+
+class FieldMask              // include/dsrc/Configurable.h:22-43
+{
+public:
+	FieldMask() : mask(0) {}
+	FieldMask AddField(uint32 i_) const { FieldMask m(*this); m.mask |= 1ull << i_; return m; }
+	uint64 GetMask() const { return mask; }
+private:
+	uint64 mask;
+};
+
+struct FastqRecord           // include/dsrc/FastqRecord.h:21-27
+{
+	std::string tag, sequence, plus, quality;
+};
+
+// include/dsrc/FastqFile.h:22-85, src/FastqFile.cpp: strings up to '\n'; an empty string ends the file
+class FastqFile
+{
+public:
+	FastqFile() {}
+	~FastqFile();
+	void Open(const std::string& filename_);
+	void Create(const std::string& filename_);
+	void Close();
+	bool ReadNextRecord(FastqRecord& rec_);
+	void WriteNextRecord(const FastqRecord& rec_);
+private:
+	FILE* file = nullptr;
+	bool writing = false;
+	bool ReadString(std::string& str_);
+	FastqFile(const FastqFile&); FastqFile& operator=(const FastqFile&);
+};
+
+// Record-level archive API, write side (include/dsrc/DsrcArchive.h:27-66, src/DsrcArchive.cpp:100-150,217-224,
+// src/BlockCompressorExt.cpp).  Records are gathered into chunks exactly as BlockCompressorExt does (a chunk is closed
+// once its title+sequence+quality bytes exceed FastqBufferSizeMB), chunks are compressed on the GPU in batches through
+// dsrcgpu_set_record_layout + dsrcgpu_compress_batch, and the archive is the one the reference's DsrcArchive writes.
+// As in the reference this API maps QualityCompressionLevel to qualityOrder = 3 * level whether or not the mode is
+// lossy, so lossless archives are only defined for level 0 (others are refused), and it ignores Crc32Checking and
+// TagFieldFilterMask.  Reading (StartDecompress / ReadNextRecord) needs the block decompressor and throws.
+class DsrcArchive : public Configurable
+{
+public:
+	DsrcArchive();
+	~DsrcArchive();
+	void StartCompress(const std::string& filename_);
+	void WriteNextRecord(const FastqRecord& rec_);
+	void FinishCompress();
+	void StartDecompress(const std::string& filename_);
+	bool ReadNextRecord(FastqRecord& rec_);
+	void FinishDecompress();
+private:
+	struct ArchiveImpl;
+	ArchiveImpl* impl;
+	void CloseChunk();
+	void FlushBatch();
+	DsrcArchive(const DsrcArchive&); DsrcArchive& operator=(const DsrcArchive&);
 };
 
 class DsrcModule : public Configurable   // include/dsrc/DsrcModule.h:22-40

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(WG) k_assemble(const BlkDesc* desc, const BlkS
 		store_be32(o + at, S->n_recs); at += 4;
 		store_be32(o + at, (u16)S->max_len); at += 4;
 		store_be32(o + at, S->flags); at += 4;
-		store_be32(o + at, (u32)((i32)(d.in_size - S->n_crlf) - S->title_cut)); at += 4;       // chunkSize = size - cut - skipped LFs (src/FastqParser.cpp:163,196)
+		store_be32(o + at, prm.record_layout ? d.chunk_size_value : (u32)((i32)(d.in_size - S->n_crlf) - S->title_cut)); at += 4;       // chunkSize = size - cut - skipped LFs (src/FastqParser.cpp:163,196)
 		if (S->flags & 2u) { store_be32(o + at, (u16)S->min_len); at += 4; }
 		if (prm.crc)
 		{

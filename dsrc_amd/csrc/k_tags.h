@@ -118,7 +118,8 @@ __global__ void __launch_bounds__(WG) k_tag_poke(u8* in, const BlkDesc* desc, co
 	if (r >= st[b].n_recs) return;
 	const u64 g = (u64)d.rec_base + r;
 	const u32 so = rp.seq_off[g], len = rp.len[g];
-	if (rp.title_off[g] + rp.title_len[g] != so || len == 0) return;        // the title does not reach the sequence line
+	const u32 tend = rp.title_off[g] + rp.title_len[g];
+	if ((!prm.record_layout && tend != so) || len == 0) return;             // the title does not reach the sequence line
 	u8* p = in + d.in_off;
 	u32 first = 255;
 	for (u32 j = 0; j < len && first == 255; ++j)
@@ -127,7 +128,9 @@ __global__ void __launch_bounds__(WG) k_tag_poke(u8* in, const BlkDesc* desc, co
 		transform_base(p[so + j], p[rp.qual_off[g] + j], prm.quality_offset, prm.lossy, &sidx, &keep);
 		if (keep) first = sidx;
 	}
-	p[so] = (u8)(first != 255 ? first : dna_index(p[so]));
+	// record layout (BlockCompressorExt::InsertNewRecord): tag and sequence lie back to back, so the same byte is what
+	// follows the title; in our text layout that place is the title's line terminator
+	p[prm.record_layout ? tend : so] = (u8)(first != 255 ? first : dna_index(p[so]));
 }
 
 // ---- record 0 -> field template -----------------------------------------------------------------

@@ -113,6 +113,17 @@ int dsrcgpu_chain_create(dsrcgpu_chain** out);
 void dsrcgpu_chain_destroy(dsrcgpu_chain* c);
 int dsrcgpu_set_chain(dsrcgpu_handle* h, dsrcgpu_chain* c, uint64_t seq);
 
+/* Record-level API (reference: wrap::BlockCompressorExt::WriteNextRecord/Flush, src/BlockCompressorExt.cpp:20-46,65-127,
+ * used by wrap::DsrcArchive, src/DsrcArchive.cpp:129-150,217-224).  The caller assembles each chunk as FASTQ text
+ * (tag\nsequence\nplus\nquality, no newline after the last record) and declares, for the NEXT batch call on h
+ * (n must equal that call's chunk count; one-shot), that the chunks come from records:
+ *   - block i stores chunk_sizes[i] as chunkSize (the reference keeps a running total over the whole archive there,
+ *     because BlockCompressor::Reset does not clear it);
+ *   - the reference lays tag, sequence and quality out back to back, so its tag tokenizer takes the first sequence
+ *     byte (already turned into a base index) as the separator after the last title field; reproduced.
+ * Not combinable with tag_preserve_flags or calculate_crc32 (the reference's archive API drops both). */
+int dsrcgpu_set_record_layout(dsrcgpu_handle* h, uint32_t n, const uint32_t* chunk_sizes);
+
 /* Page-locked host memory for chunk / block buffers: host<->device copies from it run at PCIe speed and
  * asynchronously to the other handles' kernels (the entry points accept any host pointer; pageable ones are slower). */
 int dsrcgpu_host_alloc(uint64_t bytes, void** out);

@@ -174,6 +174,7 @@ typedef struct { u32 sym, freq; } hfreq_t;
 /* set when the input drives the reference into undefined behaviour:
  * the caller then reports ORC_E_UNSUPPORTED instead of pretending to know the reference's bytes */
 static __thread int g_ref_ub;
+static __thread int g_chunk_size_set = 0; static __thread u64 g_chunk_size_value = 0;
 
 static int hf_less(const hfreq_t* a, const hfreq_t* b)   /* a pops before b */
 {
@@ -471,6 +472,7 @@ static void block_parse(block_t* b)
 		b->raw[1] += r.title_len; b->raw[2] += r.seq_len; b->raw[3] += r.qual_len;
 	}
 	b->chunk_size = b->size - cut - p.skipped;
+	if (g_chunk_size_set) b->chunk_size = g_chunk_size_value;     /* record-level API: see orc_compress_records_file */
 }
 
 /* PreprocessRecords: IRecordsProcessor::ProcessForward + Lossless/Lossy
@@ -1378,6 +1380,12 @@ static int block_run(const orc_config* cfg, const u8* in, u64 size, bw_t* w, u64
 	if (b.n_recs == 0) { free(b.mem); free(b.recs); return ORC_E_INPUT; }
 	block_preprocess(&b);
 	if (keep) { *keep = b; return ORC_OK; }
+	if (g_chunk_size_set)
+	{
+		/* BlockCompressorExt::InsertNewRecord stores tag, sequence and quality back to back, so the byte the tag
+		 * tokenizer takes for the last field's separator (title[titleLen]) is sequence[0] as ProcessForward left it. */
+		for (u64 i = 0; i < b.n_recs; ++i) b.mem[b.recs[i].title + b.recs[i].title_len] = b.mem[b.recs[i].seq];
+	}
 
 	/* AnalyzeMetaData (src/BlockCompressor.cpp:184-205) */
 	b.max_qlen = (u16)b.st.max_len; b.min_qlen = (u16)b.st.min_len;
@@ -1626,6 +1634,93 @@ int orc_compress_file(const char* in_path, const char* out_path, uint32_t dna_le
 	}
 	fclose(fo);
 	free(bsz); free(file); free(starts); free(sizes);
+	return rc;
+}
+
+/* ------------------------------------------------------------------------
+ * Record-level API: wrap::DsrcArchive::StartCompress / WriteNextRecord / FinishCompress over
+ * wrap::BlockCompressorExt (src/DsrcArchive.cpp:33-47,100-150,217-224, src/BlockCompressorExt.cpp:20-46,65-127),
+ * fed by wrap::FastqFile::ReadNextRecord (src/FastqFile.cpp:66-92: strings up to '\n', an empty string ends the file).
+ *  - a chunk is flushed once the title+sequence+quality bytes held exceed bufferMB << 20 (checked after every record);
+ *  - chunkHeader.chunkSize grows by (tag+1)+(seq+1)+(plus+1)+(qual+1) per record and is NOT cleared by Reset()
+ *    (src/BlockCompressor.cpp:105-109), so block k stores the running total over blocks 0..k (mod 2^32);
+ *  - settings: dnaOrder = 3*level, qualityOrder = 3*level also when lossless (src/DsrcArchive.cpp:41-42), no CRC,
+ *    no field filter, dataset type straight from the setters (no Analyze);
+ *  - Flush = PreprocessRecords + AnalyzeRecords + StoreRecords on one persistent BlockCompressor.
+ * ---------------------------------------------------------------------- */
+int orc_compress_records_block(const orc_config* cfg, uint32_t* fields_cap, uint32_t chunk_size, const uint8_t* in, uint64_t size,
+							   uint8_t* out, uint64_t cap, uint64_t* out_size, uint64_t raw[4], uint64_t comp[4])
+{
+	g_chunk_size_set = 1; g_chunk_size_value = chunk_size;
+	const int rc = orc_compress_block_state(cfg, fields_cap, in, size, out, cap, out_size, raw, comp);
+	g_chunk_size_set = 0;
+	return rc;
+}
+
+int orc_compress_records_file(const char* in_path, const char* out_path, uint32_t dna_level, uint32_t quality_level,
+							  int lossy, uint32_t qoff, uint32_t buf_mb, int plus_rep)
+{
+	FILE* fi = fopen(in_path, "rb");
+	if (!fi) return ORC_E_IO;
+	fseeko(fi, 0, SEEK_END); u64 fsz = (u64)ftello(fi); fseeko(fi, 0, SEEK_SET);
+	u8* file = (u8*)malloc(fsz + 16);
+	if (fread(file, 1, fsz, fi) != fsz) { fclose(fi); free(file); return ORC_E_IO; }
+	fclose(fi);
+	orc_config cfg; memset(&cfg, 0, sizeof(cfg));
+	cfg.dna_order = dna_level * 3; cfg.quality_order = quality_level * 3;
+	cfg.lossy = lossy; cfg.quality_offset = qoff; cfg.plus_repetition = plus_rep;
+	FILE* fo = fopen(out_path, "wb");
+	if (!fo) { free(file); return ORC_E_IO; }
+	u8 hdr[40]; memset(hdr, 0, 40); fwrite(hdr, 1, 40, fo);
+	u64 bcap = 64, nb = 0; u32* bsz = (u32*)malloc(bcap * 4);
+	u64 off = 40, total = 0, payload = 0, chunk_start = 0, pos = 0;
+	u32 fields_cap = 0;
+	int rc = 0, done = 0;
+	const u64 buf = (u64)buf_mb << 20;
+	while (!done && rc == 0)
+	{
+		/* one record = four strings; ReadNextRecord fails on the first empty one */
+		u64 len[4], p = pos; int ok = 1;
+		for (int k = 0; k < 4 && ok; ++k)
+		{
+			u64 e = p; while (e < fsz && file[e] != '\n') e++;
+			len[k] = e - p; p = e < fsz ? e + 1 : e;
+			if (len[k] == 0) ok = 0;
+		}
+		int flush = 0;
+		if (ok)
+		{
+			pos = p; payload += len[0] + len[1] + len[3]; total += len[0] + len[1] + len[2] + len[3] + 4;
+			flush = payload > buf;
+		}
+		else { done = 1; flush = payload > 0; }
+		if (flush)
+		{
+			/* the chunk as FASTQ text without its last newline = what Store() would be given */
+			u64 csz = pos - chunk_start; if (csz && file[chunk_start + csz - 1] == '\n') csz--;
+			u64 ocap = csz + (1 << 16), osz = 0, raw[4], comp[4];
+			u8* out = (u8*)malloc(ocap);
+			rc = orc_compress_records_block(&cfg, &fields_cap, (u32)total, file + chunk_start, csz, out, ocap, &osz, raw, comp);
+			if (rc == 0)
+			{
+				fwrite(out, 1, osz, fo);
+				if (nb == bcap) { bcap *= 2; bsz = (u32*)realloc(bsz, bcap * 4); }
+				bsz[nb++] = (u32)osz; off += osz;
+			}
+			free(out);
+			chunk_start = pos; payload = 0;
+		}
+	}
+	if (rc == 0)
+	{
+		u8* foot = (u8*)malloc((size_t)nb * 4 + 32);
+		u64 fs = orc_archive_footer(foot, bsz, nb, &cfg);
+		fwrite(foot, 1, fs, fo);
+		orc_archive_header(hdr, off, (u32)fs, nb);
+		fseeko(fo, 0, SEEK_SET); fwrite(hdr, 1, 40, fo);
+		free(foot);
+	}
+	fclose(fo); free(bsz); free(file);
 	return rc;
 }
 

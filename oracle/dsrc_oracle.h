@@ -69,6 +69,14 @@ uint64_t orc_archive_footer(uint8_t* out, const uint32_t* block_sizes, uint64_t 
 int orc_compress_file(const char* in_path, const char* out_path, uint32_t dna_level, uint32_t quality_level,
 					  int lossy, int crc, uint32_t qoff, uint32_t buf_mb);
 
+/* wrap::DsrcArchive write path (record-level API) over a FASTQ file read like wrap::FastqFile does:
+ * chunking by payload bytes, running chunkSize, settings mapping of src/DsrcArchive.cpp:33-47.
+ * _block: one Flush() of BlockCompressorExt for a chunk given as text (no final newline) with that chunkSize word. */
+int orc_compress_records_block(const orc_config* cfg, uint32_t* fields_cap, uint32_t chunk_size, const uint8_t* in, uint64_t size,
+							   uint8_t* out, uint64_t cap, uint64_t* out_size, uint64_t raw[4], uint64_t comp[4]);
+int orc_compress_records_file(const char* in_path, const char* out_path, uint32_t dna_level, uint32_t quality_level,
+							  int lossy, uint32_t qoff, uint32_t buf_mb, int plus_rep);
+
 /* primitives (same calling convention as the ref_* probes) */
 uint64_t orc_bitwriter_script(const uint32_t* ops, uint32_t nops, uint8_t* out, uint64_t cap);
 uint64_t orc_huffman(const uint32_t* freqs, uint32_t n, uint32_t* codes, uint32_t* lens, uint8_t* tree, uint64_t cap);

@@ -74,6 +74,22 @@ class Oracle:
             raise RuntimeError(f"orc_compress_block rc={rc}")
         return bytes(out[: osz.value]), list(raw), list(comp)
 
+    def compress_records_block(self, cfg: Config, data: bytes, chunk_size: int, fields_cap: int = 0):
+        """BlockCompressorExt::Flush for a chunk given as text; returns (block, new fields_cap)."""
+        c = _orc_cfg(cfg)
+        cap = len(data) + (1 << 16)
+        out = (C.c_uint8 * cap)()
+        osz = C.c_uint64(0); fc = C.c_uint32(fields_cap)
+        raw = (C.c_uint64 * 4)(); comp = (C.c_uint64 * 4)()
+        rc = self.lib.orc_compress_records_block(C.byref(c), C.byref(fc), C.c_uint32(chunk_size & 0xFFFFFFFF), data,
+                                                 C.c_uint64(len(data)), out, C.c_uint64(cap), C.byref(osz), raw, comp)
+        if rc != 0:
+            raise RuntimeError(f"orc_compress_records_block rc={rc}")
+        return bytes(out[: osz.value]), fc.value
+
+    def compress_records_file(self, src: str, dst: str, d: int, q: int, lossy=False, qoff=33, buf_mb=8, plus_rep=False):
+        return self.lib.orc_compress_records_file(src.encode(), dst.encode(), d, q, int(lossy), qoff, buf_mb, int(plus_rep))
+
     def block_stats(self, cfg: Config, data: bytes):
         c = _orc_cfg(cfg)
         d = (C.c_uint32 * 21)(); q = (C.c_uint32 * 262)()

@@ -199,6 +199,48 @@ def test_field_filter(emu, oracle, seed):
             assert got == want, (seed, desc, bin(flags), d, q, lossy, crc)
 
 
+@pytest.mark.parametrize("seed", range(500, 506))
+def test_record_layout(emu, oracle, seed):
+    """dsrcgpu_set_record_layout: chunks assembled from records (BlockCompressorExt) -- chunkSize word given by the
+    caller, last title separator = the index-transformed first base; block-to-block state carried as usual."""
+    data, desc = fuzz_fastq(seed, [30, 60, 150][seed % 3])
+    data = data.replace(b"\r\n", b"\n")                   # record strings hold no line terminators
+    other = synth.illumina_fastq(40, first=7)[:-1]
+    for d, q, lossy in [(0, 0, False), (2, 0, False), (1, 1, True), (3, 2, True)]:
+        # settings mapping of the archive API: qualityOrder = 3 * level also when lossless (src/DsrcArchive.cpp:41-42)
+        cfg = Config(dna_order=3 * d, quality_order=3 * q, lossy=lossy)
+        h = emu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, False, cfg.quality_offset)
+        try:
+            w0, cap = oracle.compress_records_block(cfg, data, 123456789)
+            w1, cap = oracle.compress_records_block(cfg, other, 0xFFFFFFF0 + 77, cap)
+            w2, _ = oracle.compress_records_block(cfg, data, 5, cap)
+        except RuntimeError as e:
+            assert "rc=-2" in str(e)
+            h.close()
+            continue
+        h.set_record_layout([123456789, 0xFFFFFFF0 + 77])
+        got = h.compress_batch([data, other])
+        assert got[0][0] == w0 and got[1][0] == w1, (seed, desc, d, q, lossy)
+        h.set_record_layout([5])
+        assert h.compress_batch([data])[0][0] == w2
+        assert h.compress_batch([data])[0][0] != w2            # one-shot: back to the text layout
+        h.close()
+
+
+def test_record_layout_arguments(emu):
+    h = emu.Handle(crc=True)
+    h.set_record_layout([1])
+    with pytest.raises(emu.DsrcGpuError):
+        h.compress_batch([TINY])
+    h.close()
+    h = emu.Handle()
+    h.set_record_layout([1, 2])
+    with pytest.raises(emu.DsrcGpuError):
+        h.compress_batch([TINY])                            # one chunkSize per chunk
+    assert h.compress_batch([TINY])[0][0]                   # cleared by the failed call
+    h.close()
+
+
 def test_bad_arguments(emu):
     with pytest.raises(emu.DsrcGpuError):
         emu.Handle(tag_flags=1 << 31)          # field numbers above 30 are undefined in the reference (32-bit BIT())

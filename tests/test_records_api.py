@@ -1,0 +1,129 @@
+"""Record-level archive API: wrap::DsrcArchive::StartCompress / WriteNextRecord / FinishCompress.
+
+CPU part: the oracle's restatement of that path (orc_compress_records_file) against archives written by the unmodified
+reference's DsrcArchive (tests/golden/records_golden.json, made by tests/golden/make_records_golden.py, and live against
+oracle/_ref/ref_records when it is there); the C++ host's DsrcArchive linked against the HIP emulator against the oracle.
+GPU part: dsrc-amd-records and pydsrc.DsrcArchive against the same golden digests."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+from dsrc_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = json.load(open(os.path.join(ROOT, "tests", "golden", "records_golden.json")))
+REF_RECORDS = os.path.join(ROOT, "oracle", "_ref", "ref_records")
+EMU_HOST = os.path.join(ROOT, "tests", "emu", "dsrc-amd-records-emu")
+GPU_HOST = os.path.join(ROOT, "dsrc_amd", "csrc", "dsrc-amd-records")
+
+FILES = {
+    "illumina9000": lambda: synth.illumina_fastq(9000),
+    "illumina3200": lambda: synth.illumina_fastq(3200, first=501),
+    "iontorrent6000": lambda: synth.iontorrent_fastq(6000),
+}
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def inputs(tmp_path_factory):
+    d = tmp_path_factory.mktemp("rec")
+    paths = {}
+    for name, gen in FILES.items():
+        data = gen()
+        for e in G["archives"]:
+            if e["name"] == name:
+                assert sha(data) == e["in_sha256"], "generator drifted from the golden input"
+        p = d / (name + ".fastq"); p.write_bytes(data)
+        paths[name] = str(p)
+    return d, paths
+
+
+def test_oracle_against_reference_archives(oracle, inputs):
+    d, paths = inputs
+    out = str(d / "orc.dsrc")
+    for e in G["archives"]:
+        dl, ql, lossy = e["levels"]
+        assert oracle.compress_records_file(paths[e["name"]], out, dl, ql, bool(lossy), e["quality_offset"], e["buf_mb"]) == 0
+        arc = open(out, "rb").read()
+        assert (len(arc), sha(arc)) == (e["size"], e["sha256"]), e
+
+
+def test_running_chunk_size_and_block_cut():
+    """What makes these archives differ from `dsrc c`: blocks are cut by payload bytes and the chunkSize word is a
+    running total (src/BlockCompressorExt.cpp:126, src/BlockCompressor.cpp:105-109)."""
+    e = next(x for x in G["archives"] if x["name"] == "illumina9000" and x["buf_mb"] == 1 and x["levels"] == [0, 0, 0])
+    assert len(e["block_sizes"]) == 4
+
+
+@pytest.mark.skipif(not os.path.exists(REF_RECORDS), reason="oracle/_ref/ref_records not built (needs /root/reference)")
+def test_oracle_against_live_reference(oracle, inputs, tmp_path):
+    d, paths = inputs
+    # plus repetition, offset 64 data and other buffer sizes than the golden set
+    data = synth.illumina_fastq(5000, first=90001)
+    lines = data.split(b"\n")
+    for i in range(2, len(lines), 4):
+        lines[i] = b"+" + lines[i - 2][1:]
+    rep = tmp_path / "rep.fastq"; rep.write_bytes(b"\n".join(lines))
+    cases = [(str(rep), 0, 0, 0, 1, 33, 1), (str(rep), 2, 2, 1, 1, 33, 1), (paths["illumina9000"], 3, 0, 0, 3, 33, 0),
+             (paths["iontorrent6000"], 0, 0, 0, 1, 33, 0), (paths["iontorrent6000"], 1, 1, 1, 2, 33, 0)]
+    for src, dl, ql, lossy, buf, off, prep in cases:
+        a = str(tmp_path / "ref.dsrc"); b = str(tmp_path / "orc.dsrc")
+        subprocess.check_call([REF_RECORDS, src, a, str(dl), str(ql), str(lossy), str(buf), str(off), str(prep)], stderr=subprocess.DEVNULL)
+        assert oracle.compress_records_file(src, b, dl, ql, bool(lossy), off, buf, bool(prep)) == 0
+        assert open(a, "rb").read() == open(b, "rb").read(), (src, dl, ql, lossy, buf, prep)
+
+
+def test_host_archive_on_emulator(inputs):
+    """dsrc_host.cpp's DsrcArchive (chunk assembly, running chunkSize, batches, archive writer) with the kernels on
+    the CPU emulator: the reference's archive, two blocks."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emu")], stdout=subprocess.DEVNULL)
+    d, paths = inputs
+    e = next(x for x in G["archives"] if x["name"] == "illumina3200" and x["levels"] == [0, 0, 0])
+    assert len(e["block_sizes"]) == 2
+    out = str(d / "emu.dsrc")
+    subprocess.check_call([EMU_HOST, paths["illumina3200"], out, "0", "0", "0", "1", "33"], stderr=subprocess.DEVNULL)
+    arc = open(out, "rb").read()
+    assert (len(arc), sha(arc)) == (e["size"], e["sha256"])
+    # refusals: lossless quality level 1 is undefined in the reference's archive API; offset must be given
+    assert subprocess.run([EMU_HOST, paths["illumina3200"], out, "0", "1", "0", "1", "33"], capture_output=True).returncode == 1
+    assert subprocess.run([EMU_HOST, paths["illumina3200"], out, "0", "0", "0", "1", "0"], capture_output=True).returncode == 1
+
+
+@pytest.mark.gpu
+def test_gpu_host_archives(inputs):
+    assert os.path.exists(GPU_HOST), "dsrc-amd-records not built"
+    d, paths = inputs
+    out = str(d / "gpu.dsrc")
+    for e in G["archives"]:
+        dl, ql, lossy = e["levels"]
+        subprocess.check_call([GPU_HOST, paths[e["name"]], out, str(dl), str(ql), str(lossy), str(e["buf_mb"]), str(e["quality_offset"])],
+                              stderr=subprocess.DEVNULL)
+        arc = open(out, "rb").read()
+        assert (len(arc), sha(arc)) == (e["size"], e["sha256"]), e
+
+
+@pytest.mark.gpu
+def test_gpu_pydsrc_archive(inputs):
+    """The reference's Python names (py/Interface.cpp:59-94): FastqFile -> DsrcArchive, as in examples/py."""
+    from dsrc_amd import pydsrc
+    d, paths = inputs
+    e = next(x for x in G["archives"] if x["name"] == "illumina9000" and x["buf_mb"] == 1 and x["levels"] == [3, 2, 1])
+    out = str(d / "py.dsrc")
+    f = pydsrc.FastqFile(); f.Open(paths["illumina9000"])
+    a = pydsrc.DsrcArchive()
+    a.DNACompressionLevel = 3; a.QualityCompressionLevel = 2; a.LossyCompression = True
+    a.FastqBufferSizeMB = 1; a.QualityOffset = 33
+    a.StartCompress(out)
+    rec = pydsrc.FastqRecord(); n = 0
+    while f.ReadNextRecord(rec):
+        a.WriteNextRecord(rec); n += 1
+    a.FinishCompress(); f.Close()
+    assert n == 9000
+    arc = open(out, "rb").read()
+    assert (len(arc), sha(arc)) == (e["size"], e["sha256"])
