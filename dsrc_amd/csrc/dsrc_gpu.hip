@@ -155,6 +155,9 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	prm.dna_order = dna_order; prm.quality_order = qo; prm.lossy = lossy; prm.crc = crc; prm.tag_flags = (u32)h->set.tag_preserve_flags;
 	prm.quality_offset = h->ds.quality_offset; prm.n_blocks = B; prm.max_tiles = 1;
 	prm.record_layout = h->rec_chunk_sizes.empty() ? 0u : 1u;
+	prm.color_space = h->ds.color_space ? 1u : 0u;
+	if (prm.color_space && (prm.record_layout || prm.tag_flags))
+		return fail(h, DSRCGPU_E_ARG, "colour space cannot be combined with the field filter or the record layout on the GPU path");
 	if (prm.record_layout && (h->rec_chunk_sizes.size() != B || prm.tag_flags || crc))
 		return fail(h, DSRCGPU_E_ARG, "record layout: one chunkSize per chunk of the batch, no field filter, no CRC (src/DsrcArchive.cpp:33-47)");
 
@@ -215,13 +218,21 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	hipLaunchKernelGGL(k_index_lines, dim3(prm.max_tiles, B), dim3(WG), 0, s, d_in, d_desc, d_tiles, d_lines, prm); KCHK();
 	hipLaunchKernelGGL(k_records, dim3((max_rec_cap + WG - 1) / WG, B), dim3(WG), 0, s, d_in, d_desc, d_state, d_lines, rp); KCHK();
 	if (prm.tag_flags) { hipLaunchKernelGGL(k_tag_filter, dim3((max_rec_cap + WG - 1) / WG, B), dim3(WG), 0, s, const_cast<u8*>(d_in), d_desc, d_state, rp, prm); KCHK(); }
+	const u32 rec_gx = std::max(1u, std::min(64u, (max_rec_cap + 4 * WAVES - 1) / (4 * WAVES)));
+	if (prm.color_space)
+	{	// checksums are taken over the text as it came; then colours -> bases in place
+		hipLaunchKernelGGL(k_rec_count, dim3((B + 63) / 64), dim3(64), 0, s, d_desc, d_state, B); KCHK();
+		if (crc) { hipLaunchKernelGGL(k_crc, dim3(B, 3), dim3(WG), 0, s, d_in, d_desc, d_state, rp, h->d_crc_tab, prm); KCHK(); }
+		hipLaunchKernelGGL(k_cs_decode, dim3(rec_gx, B), dim3(WG), 0, s, const_cast<u8*>(d_in), d_desc, d_state, rp); KCHK();
+	}
 	hipLaunchKernelGGL(k_prep_stats, dim3(B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, prm); KCHK();
+	if (prm.color_space) { hipLaunchKernelGGL(k_cs_reduce, dim3((max_rec_cap + WG - 1) / WG, B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, prm); KCHK(); }
 	hipLaunchKernelGGL(k_rec_offsets, dim3(B), dim3(WG), 0, s, d_desc, d_state, rp); KCHK();
 	{
 		const u32 gx = std::max(1u, std::min(64u, (max_rec_cap + 4 * WAVES - 1) / (4 * WAVES)));
 		hipLaunchKernelGGL(k_prep_write, dim3(gx, B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, d_q, d_qp, d_d, prm); KCHK();
 	}
-	if (crc) { hipLaunchKernelGGL(k_crc, dim3(B, 3), dim3(WG), 0, s, d_in, d_desc, d_state, rp, h->d_crc_tab, prm); KCHK(); }
+	if (crc && !prm.color_space) { hipLaunchKernelGGL(k_crc, dim3(B, 3), dim3(WG), 0, s, d_in, d_desc, d_state, rp, h->d_crc_tab, prm); KCHK(); }
 	if (prm.tag_flags || prm.record_layout) { hipLaunchKernelGGL(k_tag_poke, dim3((max_rec_cap + WG - 1) / WG, B), dim3(WG), 0, s, const_cast<u8*>(d_in), d_desc, d_state, rp, prm); KCHK(); }
 	hipLaunchKernelGGL(k_tag_template, dim3((B + 63) / 64), dim3(64), 0, s, d_in, d_desc, d_state, rp, B); KCHK();
 	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
@@ -421,8 +432,8 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			if (j.order > 7) return fail(h, DSRCGPU_E_ARG, "quality order %u not supported", j.order);
 			if (S.min_len == S.max_len && S.max_len >= 1 && S.max_len <= 65535)
 			{
-				const u64 m = ((1ull << 48) + S.max_len - 1) / S.max_len;
-				j.qlen = S.max_len; j.qm_lo = (u32)m; j.qm_hi = (u32)(m >> 32);
+				const u64 m = ((1ull << 48) + (S.max_len - S.cs_reduced) - 1) / (S.max_len - S.cs_reduced);
+				j.qlen = S.max_len - S.cs_reduced; j.qm_lo = (u32)m; j.qm_hi = (u32)(m >> 32);
 			}
 			j.alpha_bits = log2u(j.n_alpha); j.key_bits = j.alpha_bits * (j.order + 1);
 			j.out_words = D.qua_out; j.out_cap = D.qua_cap * 4 - j.out_byte0 - 16;
@@ -732,7 +743,6 @@ int check_settings(dsrcgpu_handle* h, const dsrcgpu_settings* s, const dsrcgpu_d
 {
 	if (!s || !d) return fail(h, DSRCGPU_E_ARG, "null settings/dataset");
 	if (s->tag_preserve_flags & ~0x7FFFFFFEull) return fail(h, DSRCGPU_E_ARG, "tag field filter (-f): field numbers 1..30 only (the reference shifts a 32-bit int)");
-	if (d->color_space) return fail(h, DSRCGPU_E_ARG, "colour-space data sets are not supported on the GPU path");
 	if (d->quality_offset < 33 || d->quality_offset > 64) return fail(h, DSRCGPU_E_ARG, "quality offset %u outside [33,64]", d->quality_offset);
 	if (s->dna_order > 9) return fail(h, DSRCGPU_E_ARG, "dna_order %u > 9", s->dna_order);
 	if (!s->lossy && s->quality_order > 2) return fail(h, DSRCGPU_E_ARG, "lossless quality_order %u > 2", s->quality_order);

@@ -46,6 +46,7 @@ struct DsrcParams   // uniform over a batch
 	u32 max_tiles;          // tiles per block upper bound (grid.x of the tile kernels)
 	u32 tag_flags;          // -f mask (bit k: keep title field k, 1-based); 0 = titles as they are
 	u32 record_layout;      // chunks assembled by the record-level API (BlockCompressorExt): see dsrcgpu_set_record_layout
+	u32 color_space;        // SOLiD: primer base + colours (src/RecordsProcessor.cpp:25-58)
 };
 
 // numeric-field coding schemes, Field::NumericSchemeEnum (src/TagModeler.h:73)
@@ -120,6 +121,12 @@ struct BlkState  // device -> host (and device scratch)
 	u32 meta_bytes, tag_bytes, qua_bytes, dna_bytes;
 	u32 tag_hdr_bytes;
 	u32 q_runs;             // RLE quality: number of runs
+	u32 rle_qn;             // RLE quality: the modeler's own alphabet = values that start a run (QualityRLEModeler::qSymbols); differs
+	u8  rle_qsym[256];      //   from q_sym only when records were shortened after the statistics (colour space)
+	// colour space (ColorSpaceStats src/Stats.h:23-42; ChunkHeader::csSeqBegin/csQuaBegin src/BlockCompressor.h:43-44)
+	u32 cs_varbegin;        // != 0: the records do not all start with record 0's primer character
+	u32 cs_reduced;         // 1: constant primer, records were shortened by k_cs_reduce (FLAG_DELTA_CONSTANT)
+	u32 cs_seq_begin, cs_qua_begin;
 	u32 scratch[8];
 	TagField fld[DSRC_MAX_FIELDS];
 };

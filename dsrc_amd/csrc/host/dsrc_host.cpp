@@ -679,6 +679,7 @@ void DsrcArchive::StartCompress(const std::string& filename_)
 	impl->type.plusRepetition = plusRepetition;
 	impl->type.colorSpace = colorSpace;
 	impl->bufferSize = (uint64)params.fastqBufferSizeMB << 20;
+	if (colorSpace) throw DsrcException("DsrcArchive: colour-space records are not supported by the record-level API on the GPU path (use DsrcModule::Compress)");
 	if (!impl->settings.lossy && impl->settings.qualityOrder != 0)
 		throw DsrcException("DsrcArchive: lossless quality levels 1-2 are undefined in the reference's archive API (qualityOrder = 3 * level, src/DsrcArchive.cpp:42); use level 0 or lossy mode");
 	if (impl->type.qualityOffset == 0)

@@ -13,8 +13,9 @@ __global__ void __launch_bounds__(64) k_meta_plan(BlkState* st, DsrcParams prm)
 	BlkState* S = &st[b];
 	u32 flags = S->flags & 4u;
 	if ((u16)S->max_len != (u16)S->min_len) flags |= 2u;          // FLAG_VARIABLE_LENGTH
+	if (S->cs_reduced) flags |= 1u;           // FLAG_DELTA_CONSTANT (src/BlockCompressor.cpp:190-199)
 	S->flags = flags;
-	u32 m = 16 + ((flags & 2u) ? 4u : 0u);
+	u32 m = 16 + ((flags & 2u) ? 4u : 0u) + ((flags & 1u) ? 2u : 0u);
 	if (prm.crc) m += (prm.tag_flags ? 0u : 4u) + 4 + (prm.lossy ? 0u : 4u);      // CALC_TAG only without -f (src/BlockCompressor.cpp:84-93)
 	S->meta_bytes = m;
 }
@@ -33,10 +34,12 @@ __global__ void __launch_bounds__(WG) k_assemble(const BlkDesc* desc, const BlkS
 	{
 		u32 at = 0;
 		store_be32(o + at, S->n_recs); at += 4;
-		store_be32(o + at, (u16)S->max_len); at += 4;
+		const u32 red = S->flags & 1u;                                 // colour space, constant primer: lengths without it
+		store_be32(o + at, (u16)(S->max_len - red)); at += 4;
 		store_be32(o + at, S->flags); at += 4;
 		store_be32(o + at, prm.record_layout ? d.chunk_size_value : (u32)((i32)(d.in_size - S->n_crlf) - S->title_cut)); at += 4;       // chunkSize = size - cut - skipped LFs (src/FastqParser.cpp:163,196)
-		if (S->flags & 2u) { store_be32(o + at, (u16)S->min_len); at += 4; }
+		if (S->flags & 2u) { store_be32(o + at, (u16)(S->min_len - red)); at += 4; }
+		if (red) { o[at++] = (u8)S->cs_seq_begin; o[at++] = (u8)S->cs_qua_begin; }      // src/BlockCompressor.cpp:415-422
 		if (prm.crc)
 		{
 			if (!prm.tag_flags) { store_be32(o + at, S->crc_tag); at += 4; }

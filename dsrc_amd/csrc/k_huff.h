@@ -440,19 +440,24 @@ __global__ void __launch_bounds__(WG) k_qrle_hist(const BlkDesc* desc, BlkState*
 	u32* scr = scr_pool + pl.scr;
 	const u32* run_start = scr_pool + pl.run_start;
 	const u8* q = q_stream + d.q_base;
-	const u32 R = S->q_runs, qn = S->q_count;
-	for (u32 i = threadIdx.x; i < 256; i += blockDim.x) { s_lf[i] = 0; s_qrank[i] = S->q_sym[i]; }
+	__shared__ u32 s_qf[256];
+	__shared__ u32 s_qn;
+	const u32 R = S->q_runs;
+	for (u32 i = threadIdx.x; i < 256; i += blockDim.x) { s_lf[i] = 0; s_qf[i] = 0; }
 	__syncthreads();
-	for (u32 k = threadIdx.x; k < R; k += blockDim.x) atomicAdd(&s_lf[run_start[k + 1] - run_start[k] - 1], 1u);
+	for (u32 k = threadIdx.x; k < R; k += blockDim.x) { atomicAdd(&s_lf[run_start[k + 1] - run_start[k] - 1], 1u); atomicAdd(&s_qf[q[run_start[k]]], 1u); }
 	__syncthreads();
 	if (threadIdx.x == 0)
 	{
-		u32 ln = 0;
+		u32 ln = 0, qc = 0;
 		for (u32 i = 0; i < 256; ++i) s_lrank[i] = s_lf[i] ? (u8)ln++ : (u8)255;
-		s_ln = ln;
-		S->scratch[0] = ln;
+		for (u32 i = 0; i < 256; ++i) s_qrank[i] = s_qf[i] ? (u8)qc++ : (u8)255;      // EncodeRecords' own symbol set (src/QualityRLEModeler.cpp:142-205)
+		s_ln = ln; s_qn = qc;
+		S->scratch[0] = ln; S->rle_qn = qc;
 	}
 	__syncthreads();
+	for (u32 i = threadIdx.x; i < 256; i += blockDim.x) S->rle_qsym[i] = s_qrank[i];
+	const u32 qn = s_qn;
 	u32* lr = scr + pl.lf_off;                  // 256 words: run-length rank table for later kernels
 	for (u32 i = threadIdx.x; i < 256; i += blockDim.x) lr[i] = s_lrank[i];
 	if (qn <= 1) return;
@@ -474,9 +479,9 @@ __global__ void __launch_bounds__(64) k_qrle_trees(BlkState* st, u32* scr_pool, 
 {
 	const u32 b = blockIdx.y;
 	BlkState* S = &st[b];
-	if (plans[b].scheme != 2 || S->q_count <= 1) return;
+	if (plans[b].scheme != 2 || S->rle_qn <= 1) return;
 	const QuaPlan pl = plans[b];
-	const u32 qn = S->q_count, ln = S->scratch[0];
+	const u32 qn = S->rle_qn, ln = S->scratch[0];
 	const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k >= 2 * qn) return;
 	u32* scr = scr_pool + pl.scr;
@@ -510,8 +515,8 @@ __global__ void __launch_bounds__(WG) k_qrle_emit(const BlkDesc* desc, BlkState*
 	const u32* run_start = scr_pool + pl.run_start;
 	const u32* lrank = scr + pl.lf_off;
 	const u8* q = q_stream + d.q_base;
-	const u32 R = S->q_runs, qn = S->q_count, ln = S->scratch[0];
-	for (u32 i = threadIdx.x; i < 256; i += blockDim.x) s_qrank[i] = S->q_sym[i];
+	const u32 R = S->q_runs, qn = S->rle_qn, ln = S->scratch[0];
+	for (u32 i = threadIdx.x; i < 256; i += blockDim.x) s_qrank[i] = S->rle_qsym[i];
 	if (threadIdx.x == 0)
 	{
 		put_byte(out, 0, 2);
@@ -519,7 +524,7 @@ __global__ void __launch_bounds__(WG) k_qrle_emit(const BlkDesc* desc, BlkState*
 		for (u32 k = 0; k < 32; ++k)
 		{
 			u32 v = 0, w = 0;
-			for (u32 i = 0; i < 8; ++i) { v = (v << 1) | (S->q_sym[8 * k + i] != 255 ? 1u : 0u); w = (w << 1) | (lrank[8 * k + i] != 255 ? 1u : 0u); }
+			for (u32 i = 0; i < 8; ++i) { v = (v << 1) | (S->rle_qsym[8 * k + i] != 255 ? 1u : 0u); w = (w << 1) | (lrank[8 * k + i] != 255 ? 1u : 0u); }
 			put_byte(out, 5 + k, v); put_byte(out, 37 + k, w);
 		}
 		u32 at = 69;

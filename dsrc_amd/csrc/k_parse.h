@@ -207,6 +207,61 @@ __device__ __forceinline__ u32 transform_base(u32 base, u32 qual, u32 qoff, u32 
 	return q;
 }
 
+// ---- colour space: colours -> bases in place, one wave per record ---------------------------------
+// IRecordsProcessor::ProcessRecordFromColorSpace (src/RecordsProcessor.cpp:25-58): character k >= 1 is looked up in the
+// transition matrix of the last decoded base that was one of ACGT (matrix A before any).  With A,C,G,T = 0,1,2,3 the
+// matrices are `state xor colour`, '.' and '/' give N and leave the state alone, so the state at k is the primer's
+// code xor the prefix-xor of the colours: two ballots (one per colour bit) and a popcount parity per 64 characters.
+// Also ColorSpaceStats::constBeginSym (src/RecordsProcessor.h:92-105) on the raw primer characters.
+__device__ __forceinline__ u32 block_rec_count(const BlkState& S, const BlkDesc& d)
+{
+	u32 n_cand = (S.n_term + 1 + 3) / 4;
+	if (n_cand > d.rec_cap) n_cand = d.rec_cap;
+	return S.first_bad < n_cand ? S.first_bad : n_cand;
+}
+
+// n_recs ahead of k_prep_stats, for the kernels the colour-space path runs before it
+__global__ void __launch_bounds__(64) k_rec_count(const BlkDesc* desc, BlkState* st, u32 n_blocks)
+{
+	const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b < n_blocks) st[b].n_recs = block_rec_count(st[b], desc[b]);
+}
+
+__device__ __forceinline__ u32 cs_state(u32 c) { return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u; }
+
+__global__ void __launch_bounds__(WG) k_cs_decode(u8* in, const BlkDesc* desc, BlkState* st, RecPools rp)
+{
+	const u32 b = blockIdx.y;
+	const BlkDesc d = desc[b];
+	u8* p = in + d.in_off;
+	const u32 n_recs = st[b].n_recs;
+	const u32 lane = lane_id();
+	const u32 waves_total = gridDim.x * (blockDim.x >> 6);
+	for (u32 r = blockIdx.x * (blockDim.x >> 6) + wave_id(); r < n_recs; r += waves_total)
+	{
+		const u64 g = (u64)d.rec_base + r;
+		const u32 len = rp.len[g], so = rp.seq_off[g];
+		if (len == 0) continue;
+		if (lane == 0 && p[so] != p[rp.seq_off[d.rec_base]]) atomicOr(&st[b].cs_varbegin, 1u);
+		u32 state = cs_state(p[so]);
+		bool bad = false;
+		for (u32 j0 = 0; j0 < len; j0 += 64)
+		{
+			const u32 j = j0 + lane;
+			const bool in_r = j < len && j >= 1;
+			const u32 c = in_r ? (u32)p[so + j] - '.' : 0u;          // '.' '/' '0' '1' '2' '3' -> 0..5
+			if (c > 5) bad = true;                                    // the reference reads outside its 24-entry table
+			const u32 col = (in_r && c >= 2 && c <= 5) ? c - 2 : 0u;
+			const u64 m0 = __ballot((col & 1u) != 0), m1 = __ballot((col & 2u) != 0);
+			const u64 le = lanemask_lt() | (1ull << lane);
+			const u32 mine = state ^ ((u32)__popcll(m0 & le) & 1u) ^ (((u32)__popcll(m1 & le) & 1u) << 1);
+			if (in_r) p[so + j] = c < 2 ? (u8)'N' : (u8)"ACGT"[mine];
+			state ^= ((u32)__popcll(m0) & 1u) ^ (((u32)__popcll(m1) & 1u) << 1);
+		}
+		if (bad) atomicOr(&st[b].err, (u32)DSRC_ERR_BAD_BASE);
+	}
+}
+
 // ---- pass 5: statistics, one workgroup per block, one wave per record ------------------------
 __global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* desc, BlkState* st, RecPools rp, DsrcParams prm)
 {
@@ -216,9 +271,7 @@ __global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* 
 	const u32 b = blockIdx.x;
 	const BlkDesc d = desc[b];
 	const u8* p = in + d.in_off;
-	u32 n_cand = (st[b].n_term + 1 + 3) / 4;
-	if (n_cand > d.rec_cap) n_cand = d.rec_cap;
-	const u32 n_recs = st[b].first_bad < n_cand ? st[b].first_bad : n_cand;
+	const u32 n_recs = block_rec_count(st[b], d);
 
 	for (u32 i = threadIdx.x; i < 256; i += blockDim.x) s_qf[i] = 0;
 	if (threadIdx.x < 20) s_df[threadIdx.x] = 0;
@@ -291,6 +344,41 @@ __global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* 
 	}
 }
 
+// ---- colour space with a constant primer: every record loses its first kept base and its first quality
+// AFTER the statistics were taken (AnalyzeMetaData + the "2nd pass" of AnalyzeTags, src/BlockCompressor.cpp:184-199,
+// 380-393).  From here on the record pools describe the shortened records; k_prep_write rebuilds the full view.
+__global__ void __launch_bounds__(WG) k_cs_reduce(const u8* in, const BlkDesc* desc, BlkState* st, RecPools rp, DsrcParams prm)
+{
+	const u32 b = blockIdx.y;
+	BlkState* S = &st[b];
+	if (S->cs_varbegin) return;
+	const BlkDesc d = desc[b];
+	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= S->n_recs) return;
+	const u64 g = (u64)d.rec_base + r;
+	const u32 len = rp.len[g];
+	if (r == 0)
+	{
+		// csSeqBegin = records[0].sequence[0] after ProcessForward (index of the first kept base, or of base 0 if none
+		// is kept); csQuaBegin = records[0].quality[0] after it
+		const u8* p = in + d.in_off;
+		u32 first = 255, q0 = 0;
+		for (u32 j = 0; j < len && first == 255; ++j)
+		{
+			u32 sidx; bool keep;
+			const u32 q = transform_base(p[rp.seq_off[g] + j], p[rp.qual_off[g] + j], prm.quality_offset, prm.lossy, &sidx, &keep);
+			if (j == 0) q0 = q;
+			if (keep) first = sidx;
+		}
+		S->cs_seq_begin = first != 255 ? first : (len ? dna_index(p[rp.seq_off[g]]) : 0u);
+		S->cs_qua_begin = q0;
+		S->cs_reduced = 1;
+	}
+	if (rp.kept[g] < 1 || len < 2) { atomicOr(&S->err, (u32)DSRC_ERR_BAD_BASE); return; }      // lengths wrap in the reference
+	rp.len[g] = (u16)(len - 1); rp.qual_off[g] += 1; rp.kept[g] -= 1;
+	if (rp.trunc[g] > 0) rp.trunc[g] -= 1;
+}
+
 // ---- pass 6: per-record stream offsets (exclusive scans of len / kept) ----------------------
 __global__ void __launch_bounds__(WG) k_rec_offsets(const BlkDesc* desc, BlkState* st, RecPools rp)
 {
@@ -324,11 +412,12 @@ __global__ void __launch_bounds__(WG) k_prep_write(const u8* in, const BlkDesc* 
 	const u32 n_recs = st[b].n_recs;
 	const u32 lane = lane_id();
 	const bool write_qp = st[b].min_len != st[b].max_len;      // reads of one length: the position context is a closed form of t (qua_pctx)
+	const u32 red = st[b].cs_reduced;      // k_cs_reduce: first quality and first kept base are not coded
 	const u32 waves_total = gridDim.x * (blockDim.x >> 6);
 	for (u32 r = blockIdx.x * (blockDim.x >> 6) + wave_id(); r < n_recs; r += waves_total)
 	{
 		const u64 g = (u64)d.rec_base + r;
-		const u32 len = rp.len[g], so = rp.seq_off[g], qo = rp.qual_off[g];
+		const u32 rlen = rp.len[g], len = rlen + red, so = rp.seq_off[g], qo = rp.qual_off[g] - red;
 		u8* qs = q_stream + d.q_base + rp.q_off[g];
 		u8* qps = qp_stream + d.q_base + rp.q_off[g];
 		u8* ds = d_stream + d.d_base + rp.d_off[g];
@@ -341,8 +430,9 @@ __global__ void __launch_bounds__(WG) k_prep_write(const u8* in, const BlkDesc* 
 			if (in_r) q = transform_base(p[so + j], p[qo + j], prm.quality_offset, prm.lossy, &sidx, &keep);
 			const bool k2 = in_r && keep;
 			const u64 km = __ballot(k2);
-			if (in_r) { qs[j] = (u8)q; if (write_qp) qps[j] = (u8)((j * 128u) / len); }
-			if (k2) ds[run + (u32)__popcll(km & lanemask_lt())] = (u8)sidx;
+			if (in_r && j >= red) { qs[j - red] = (u8)q; if (write_qp) qps[j - red] = (u8)(((j - red) * 128u) / rlen); }
+			const u32 at = run + (u32)__popcll(km & lanemask_lt());
+			if (k2 && at >= red) ds[at - red] = (u8)sidx;
 			run += (u32)__popcll(km);
 		}
 	}

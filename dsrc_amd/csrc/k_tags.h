@@ -695,7 +695,7 @@ __global__ void __launch_bounds__(WG) k_tag_emit(const u8* in, const BlkDesc* de
 	}
 	__syncthreads();
 	const u32 len_bits = bit_length32((u64)(u16)((u16)S->max_len - (u16)S->min_len));
-	const u32 minq = (u16)S->min_len;
+	const u32 minq = (u16)(S->min_len - S->cs_reduced);     // colour space: rp.len is the shortened length (k_cs_reduce)
 	const u32* val = val_pool + pl.val;
 	const u16* rl = rl_pool + pl.rl;
 	u32* rbits = scr + pl.rbits_off;
@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(WG) k_tag_raw(const u8* in, const BlkDesc* des
 	}
 	__syncthreads();
 	const u32 len_bits = bit_length32((u64)(u16)((u16)S->max_len - (u16)S->min_len));
-	const u32 minq = (u16)S->min_len;
+	const u32 minq = (u16)(S->min_len - S->cs_reduced);     // colour space: rp.len is the shortened length (k_cs_reduce)
 	u32* rbits = scr + pl.rbits_off;
 	for (u32 r = threadIdx.x; r < n; r += blockDim.x)
 	{

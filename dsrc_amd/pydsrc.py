@@ -194,7 +194,7 @@ class DsrcArchive:
         if not 1 <= int(self.FastqBufferSizeMB) <= 1024:
             raise RuntimeError("Invalid fastq buffer size specified [1-1024]")
         if self.ColorSpace:
-            raise RuntimeError("colour-space data sets are not supported on the GPU path")
+            raise RuntimeError("colour-space records are not supported by the record-level API on the GPU path (use DsrcModule.Compress)")
         if not os.path.exists(_RECORDS_CLI):
             raise RuntimeError(f"{_RECORDS_CLI} not built: python -c 'import __graft_entry__ as g; g.build()'")
         cmd = [_RECORDS_CLI, "/dev/stdin", filename, str(int(self.DNACompressionLevel)), str(int(self.QualityCompressionLevel)),

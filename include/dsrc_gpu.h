@@ -43,7 +43,7 @@ typedef struct dsrcgpu_dataset
 {
 	uint32_t quality_offset;       /* 33..64, already resolved (not 0/auto) */
 	uint8_t  plus_repetition;
-	uint8_t  color_space;          /* must be 0: SOLiD colour space is not on the GPU path */
+	uint8_t  color_space;          /* SOLiD colour space (primer base + colours); not together with tag_preserve_flags / record layout */
 	uint8_t  reserved[2];
 } dsrcgpu_dataset;
 

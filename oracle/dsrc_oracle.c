@@ -446,6 +446,7 @@ typedef struct
 	stats_t st;
 	u32 crc_tag, crc_seq, crc_qual, crc_flags;
 	u16 min_qlen, max_qlen; u32 flags;
+	int cs_const; u8 cs_seq_begin, cs_qua_begin;      /* ColorSpaceStats (src/Stats.h:23-42) / ChunkHeader::csSeqBegin, csQuaBegin */
 	void* tags;
 	u32 fields_cap;
 } block_t;
@@ -506,6 +507,25 @@ static void block_preprocess(block_t* b)
 		if (b->crc_flags & 2) c_seq = crc_update(c_seq, seq, r->seq_len);
 		if (b->crc_flags & 4) c_qual = crc_update(c_qual, qua, r->qual_len);
 
+		if (b->cfg->color_space)
+		{
+			/* IRecordsProcessor::ProcessRecordFromColorSpace + ProcessFromColorSpace (src/RecordsProcessor.cpp:25-58,
+			 * src/RecordsProcessor.h:92-105): colours '.','/','0'..'3' -> bases through the transition matrix of the
+			 * last base that was one of ACGT (matrix A before any); then the begin-symbol statistics on the raw chars */
+			static const char deltas[] = "NNACGT" "NNCATG" "NNGTAC" "NNTGCA";
+			const char* m = deltas;
+			u8 sym = seq[0];
+			for (u32 i = 1; i < r->seq_len; ++i)
+			{
+				switch (sym) { case 'A': m = deltas; break; case 'C': m = deltas + 6; break; case 'G': m = deltas + 12; break; case 'T': m = deltas + 18; break; default: break; }
+				const u32 c = (u32)seq[i] - '.';
+				if (c > 5) { g_ref_ub = 1; break; }             /* reads outside the 24-entry table */
+				sym = (u8)m[c];
+				seq[i] = sym;
+			}
+			if (k == 0) { b->cs_const = 1; b->cs_seq_begin = seq[0]; b->cs_qua_begin = qua[0]; }
+			b->cs_const &= (b->cs_seq_begin == seq[0]);
+		}
 		u32 kept = 0, th = 0; u8 prev = 255;
 		const u32 n = r->seq_len;
 		for (u32 i = 0; i < n; ++i)
@@ -1364,7 +1384,6 @@ static void tags_emit(block_t* b, bw_t* w)
  * ---------------------------------------------------------------------- */
 static int block_run(const orc_config* cfg, const u8* in, u64 size, bw_t* w, u64 raw[4], u64 comp[4], block_t* keep, u32* fields_cap)
 {
-	if (cfg->color_space) return ORC_E_UNSUPPORTED;
 	block_t b;
 	memset(&b, 0, sizeof(b));
 	b.cfg = cfg;
@@ -1390,12 +1409,34 @@ static int block_run(const orc_config* cfg, const u8* in, u64 size, bw_t* w, u64
 	/* AnalyzeMetaData (src/BlockCompressor.cpp:184-205) */
 	b.max_qlen = (u16)b.st.max_len; b.min_qlen = (u16)b.st.min_len;
 	if (b.max_qlen != b.min_qlen) b.flags |= 2;
+	const int cs_reduce = cfg->color_space && b.cs_const;
+	if (cs_reduce)
+	{
+		/* src/BlockCompressor.cpp:190-199: the begin symbols are read AFTER ProcessForward, i.e. base index and
+		 * quality - offset (or its hoisted code) of record 0 */
+		b.flags |= 1;
+		b.cs_seq_begin = b.mem[b.recs[0].seq]; b.cs_qua_begin = b.mem[b.recs[0].qual];
+		b.max_qlen = (u16)(b.max_qlen - 1); b.min_qlen = (u16)(b.min_qlen - 1);
+	}
 	tags_analyze(&b);
+	if (cs_reduce)
+	{
+		/* AnalyzeTags, "2nd pass" (src/BlockCompressor.cpp:380-393): every record loses its first (kept) base and its
+		 * first quality; the statistics above were taken with them */
+		for (u64 k = 0; k < b.n_recs; ++k)
+		{
+			rec_t* r = &b.recs[k];
+			if (r->seq_len < 1 || r->qual_len < 2) g_ref_ub = 1;    /* ASSERTs of the reference; lengths wrap in a release build */
+			r->seq++; r->qual++; r->qual_len--; r->seq_len--;
+			if (r->trunc_len > 0) r->trunc_len--;
+		}
+	}
 	if (fields_cap) *fields_cap = b.fields_cap;
 
 	u64 pos = w->pos;
 	bw_word(w, (u32)b.n_recs); bw_word(w, b.max_qlen); bw_word(w, b.flags); bw_word(w, (u32)b.chunk_size);
 	if (b.flags & 2) bw_word(w, b.min_qlen);
+	if (cfg->color_space && (b.flags & 1)) { bw_byte(w, b.cs_seq_begin); bw_byte(w, b.cs_qua_begin); }   /* src/BlockCompressor.cpp:415-422 */
 	if (cfg->calc_crc32)
 	{
 		if (b.crc_flags & 1) bw_word(w, b.crc_tag);

@@ -66,3 +66,41 @@ def fuzz_fastq(seed: int, nrec: int | None = None):
         out += [t, nl, bytes(seq), nl, b'+', nl, bytes(v + 33 for v in q), nl]
     data = b''.join(out)
     return data[:-len(nl)], (style, varlen, L0, qmode, nmode, crlf)
+
+
+def fuzz_solid(seed: int, nrec: int | None = None):
+    """SOLiD colour-space chunks (primer base + colours 0-3 and '.', as many qualities as sequence characters).
+    Returns (chunk_bytes_without_final_newline, description)."""
+    rng = random.Random(0x501D ^ seed)
+    if nrec is None:
+        nrec = rng.choice([2, 5, 40, 400, 1500])
+    const_begin = rng.random() < 0.7
+    varlen = rng.random() < 0.3
+    L0 = rng.choice([2, 3, 26, 36, 51, 76])
+    dots = rng.choice([0.0, 0.0, 0.01, 0.1])
+    qmode = rng.choice(['wide', 'binned', 'tails', 'runs', 'few'])
+    q0 = rng.choice([0, 0, 2, 30, None])                # quality of the primer position (None: like the others)
+    out = []
+    for i in range(nrec):
+        L = rng.randrange(max(2, L0 // 2), L0 + 1) if varlen else L0
+        first = b'T' if const_begin else bytes([rng.choice(b'TTTGAC')])
+        seq = bytearray(first) + bytearray(rng.choice(b'0123') for _ in range(L - 1))
+        if qmode == 'wide': q = [rng.randrange(2, 41) for _ in range(L)]
+        elif qmode == 'binned': q = [rng.choice([2, 11, 25, 37]) for _ in range(L)]
+        elif qmode == 'few': q = [rng.choice([30, 31]) for _ in range(L)]
+        elif qmode == 'runs':
+            q = []
+            while len(q) < L: q += [rng.choice([2, 15, 30, 40])] * rng.randrange(1, 400)
+            q = q[:L]
+        else:
+            k = rng.randrange(0, L + 1) if rng.random() < 0.7 else L
+            q = [rng.randrange(20, 41) for _ in range(k)] + [2] * (L - k)
+        for j in range(1, L):
+            if rng.random() < dots:
+                seq[j] = ord('.')
+                q[j] = rng.choice([0, 1, 2, 5, 8, 20])
+        if q0 is not None:
+            q[0] = q0
+        t = b"@SRR%d.%d solid_%d_%d_%d" % (2000 + seed, i + 1, 1 + i // 300, (i * 7) % 2048, (i * 13) % 2048)
+        out += [t, b'\n', bytes(seq), b'\n+\n', bytes(v + 33 for v in q), b'\n']
+    return b''.join(out)[:-1], (const_begin, varlen, L0, dots, qmode, q0)

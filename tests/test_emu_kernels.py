@@ -8,7 +8,7 @@ import pytest
 
 from dsrc_amd import synth
 from tests._oracle import Config
-from tests.cases import LEVELS, TINY, fuzz_fastq
+from tests.cases import LEVELS, TINY, fuzz_fastq, fuzz_solid
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU = os.path.join(ROOT, "tests", "emu", "libdsrc_emu.so")
@@ -241,13 +241,58 @@ def test_record_layout_arguments(emu):
     h.close()
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_color_space(emu, oracle, seed):
+    """SOLiD: colours decoded in place by k_cs_decode (prefix xor), constant-primer blocks shortened by k_cs_reduce after
+    the statistics, meta with FLAG_DELTA_CONSTANT + csSeqBegin/csQuaBegin."""
+    import dataclasses
+    data, desc = fuzz_solid(seed, [5, 40, 130, 70][seed % 4])
+    for d, q, lossy, crc in LEVELS:
+        cfg = dataclasses.replace(Config.from_levels(d, q, lossy, crc), color_space=True)
+        h = emu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset, color_space=True)
+        try:
+            want = oracle.compress_block(cfg, data)
+        except RuntimeError as e:
+            assert "rc=-2" in str(e)
+            h.close()
+            continue
+        got = h.compress_batch([data, TINY_CS])
+        h.close()
+        assert got[0] == want, (seed, desc, d, q, lossy, crc)
+
+
+def test_color_space_golden_small(emu):
+    """The small -q0 blocks of the reference's SOLiD golden set (all three quality schemes; the RLE modeler takes its
+    alphabet from the runs of the shortened records, not from the statistics)."""
+    import dataclasses, hashlib, json
+    G = json.load(open(os.path.join(ROOT, "tests", "golden", "solid_golden.json")))
+    n = 0
+    for e in G["blocks"]:
+        d, q, lossy, crc = e["levels"]
+        if q != 0 or e["size"] > 5000:
+            continue
+        data = fuzz_solid(e["seed"], e["nrec"])[0]
+        cfg = dataclasses.replace(Config.from_levels(d, q, lossy, crc), color_space=True)
+        h = emu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset, color_space=True)
+        blk = h.compress_block(data)[0]
+        h.close()
+        assert hashlib.sha256(blk).hexdigest() == e["sha256"], e
+        n += 1
+    assert n >= 20
+
+
+TINY_CS = b"@s.1 a_1\nT0120.312\n+\n!IIII#III\n@s.2 a_2\nT3321..01\n+\n!HHHH!!HH"
+
+
 def test_bad_arguments(emu):
     with pytest.raises(emu.DsrcGpuError):
         emu.Handle(tag_flags=1 << 31)          # field numbers above 30 are undefined in the reference (32-bit BIT())
     with pytest.raises(emu.DsrcGpuError):
-        emu.Handle(color_space=True)
-    with pytest.raises(emu.DsrcGpuError):
         emu.Handle(quality_offset=20)
+    h = emu.Handle(color_space=True, tag_flags=0b110)          # colour space + field filter: refused at the first batch
+    with pytest.raises(emu.DsrcGpuError):
+        h.compress_block(fuzz_solid(1, 5)[0])
+    h.close()
     h = emu.Handle()
     with pytest.raises(emu.DsrcGpuError):
         h.compress_block(b"not a fastq chunk")

@@ -44,7 +44,7 @@ def test_analyze(oracle, ref):
 def test_field_filter_blocks(oracle, ref, seed):
     """`-f` (FastqParserExt, reference src/FastqParser.cpp:167-251): the oracle restates it -- including the kept last
     field swallowing the line terminator and the tokenizer then seeing the first, already index-transformed base --
-    although the GPU path refuses the option."""
+    (SURVEY 8a-2)."""
     import dataclasses
     data, desc = fuzz_fastq(seed)
     for flags in (0b10, 0b1010, 0b11110, 0x7FFFFFFE):
@@ -56,3 +56,21 @@ def test_field_filter_blocks(oracle, ref, seed):
                 assert "rc=-2" in str(e)
                 continue
             assert a == ref.compress_block(cfg, data), (seed, desc, bin(flags), d, q, lossy, crc)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_color_space_blocks(oracle, ref, seed):
+    """SOLiD colour space (src/RecordsProcessor.cpp:25-58, src/BlockCompressor.cpp:184-199,380-393,415-422): colours to
+    bases before the index transform; with a constant primer the records lose their first base / quality AFTER the
+    statistics were taken, and the meta stream carries csSeqBegin / csQuaBegin."""
+    import dataclasses
+    from tests.cases import fuzz_solid
+    data, desc = fuzz_solid(seed)
+    for d, q, lossy, crc in LEVELS:
+        cfg = dataclasses.replace(Config.from_levels(d, q, lossy, crc), color_space=True)
+        try:
+            a = oracle.compress_block(cfg, data)
+        except RuntimeError as e:
+            assert "rc=-2" in str(e)
+            continue
+        assert a == ref.compress_block(cfg, data), (seed, desc, d, q, lossy, crc)
