@@ -29,7 +29,7 @@ typedef struct orc_config
 	int32_t  calc_crc32;
 	uint32_t quality_offset;     /* FastqDatasetType (src/Common.h:56-80) */
 	int32_t  plus_repetition;
-	int32_t  color_space;        /* must be 0 (SOLiD is out of scope) */
+	int32_t  color_space;        /* SOLiD: primer base + colours (src/RecordsProcessor.cpp:25-58)   */
 } orc_config;
 
 enum { ORC_OK = 0, ORC_E_CAP = -1, ORC_E_UNSUPPORTED = -2, ORC_E_INPUT = -3, ORC_E_IO = -4 };

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off soak: many more fuzz seeds than the test-suite runs, GPU path vs oracle, for a bounded time.
-Usage: tools/fuzz_soak.py [first_seed] [seconds] [batch]"""
+Usage: tools/fuzz_soak.py [first_seed] [seconds] [batch|solid|records]"""
 import dataclasses
 import os
 import sys
@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dsrc_amd import _lib  # noqa: E402
 from tests._oracle import Config, Oracle  # noqa: E402
-from tests.cases import fuzz_fastq  # noqa: E402
+from tests.cases import fuzz_fastq, fuzz_solid  # noqa: E402
 
 
 def batch_mode(seed, limit):
@@ -48,9 +48,71 @@ def batch_mode(seed, limit):
     print(f"fuzz soak (batches): {nb} batches, {n} blocks identical, {time.time() - t0:.0f} s")
 
 
+def solid_mode(seed, limit):
+    """SOLiD colour space: single blocks and, every fourth seed, a batch of several chunks."""
+    o = Oracle()
+    t0 = time.time(); n = 0; refused = 0
+    cfgs = [(0, 0, False, False), (3, 2, False, True), (2, 1, True, False), (1, 1, False, False), (2, 2, False, False), (3, 2, True, False), (0, 2, False, False), (3, 0, False, True)]
+    while time.time() - t0 < limit:
+        chunks = [fuzz_solid(seed * 10 + k, [None, 3000, 9000][(seed + k) % 3]) for k in range(4 if seed % 4 == 0 else 1)]
+        for d, q, lossy, crc in cfgs:
+            cfg = dataclasses.replace(Config.from_levels(d, q, lossy, crc), color_space=True)
+            ok = []
+            for data, desc in chunks:
+                try:
+                    ok.append((data, desc, o.compress_block(cfg, data)))
+                except RuntimeError as e:
+                    assert "rc=-2" in str(e), e
+                    refused += 1
+            if not ok:
+                continue
+            h = _lib.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, color_space=True)
+            got = h.compress_batch([x[0] for x in ok]); h.close()
+            for (data, desc, want), g in zip(ok, got):
+                assert g == want, f"solid seed {seed} {desc} -d{d} -q{q} lossy={lossy} crc={crc}: GPU block differs from the oracle"
+                n += 1
+        seed += 1
+    print(f"fuzz soak (colour space): {n} blocks identical, {refused} reference-UB inputs skipped, seeds up to {seed - 1}, {time.time() - t0:.0f} s")
+
+
+def records_mode(seed, limit):
+    """Record layout (dsrcgpu_set_record_layout): batches of LF-only chunks with running chunkSize words."""
+    o = Oracle()
+    t0 = time.time(); n = 0
+    cfgs = [(0, 0, False), (3, 0, False), (2, 1, True), (3, 2, True), (1, 0, False)]
+    while time.time() - t0 < limit:
+        d, q, lossy = cfgs[seed % len(cfgs)]
+        cfg = Config(dna_order=3 * d, quality_order=3 * q, lossy=lossy)
+        chunks = []; s2 = seed * 100
+        while len(chunks) < 6:
+            data = fuzz_fastq(s2, [None, 2500, 7000][s2 % 3])[0].replace(b"\r\n", b"\n"); s2 += 1
+            try:
+                o.compress_records_block(cfg, data, 1)
+            except RuntimeError:
+                continue
+            chunks.append(data)
+        sizes = []; tot = 0xFFFFF000 if seed % 2 else 0
+        for c in chunks:
+            tot += len(c) + 1; sizes.append(tot & 0xFFFFFFFF)
+        h = _lib.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, False)
+        h.set_record_layout(sizes)
+        got = h.compress_batch(chunks); h.close()
+        cap = 0
+        for c, sz, g in zip(chunks, sizes, got):
+            want, cap = o.compress_records_block(cfg, c, sz, cap)
+            assert g[0] == want, f"records seed {seed} -d{d} -q{q} lossy={lossy}: GPU block differs from the oracle"
+            n += 1
+        seed += 1
+    print(f"fuzz soak (record layout): {n} blocks identical, seeds up to {seed - 1}, {time.time() - t0:.0f} s")
+
+
 def main():
     if len(sys.argv) > 3 and sys.argv[3] == "batch":
         return batch_mode(int(sys.argv[1]), float(sys.argv[2]))
+    if len(sys.argv) > 3 and sys.argv[3] == "solid":
+        return solid_mode(int(sys.argv[1]), float(sys.argv[2]))
+    if len(sys.argv) > 3 and sys.argv[3] == "records":
+        return records_mode(int(sys.argv[1]), float(sys.argv[2]))
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     limit = float(sys.argv[2]) if len(sys.argv) > 2 else 180.0
     o = Oracle()
