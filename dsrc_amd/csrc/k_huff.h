@@ -288,13 +288,14 @@ __global__ void __launch_bounds__(64) k_qpos_trees(BlkState* st, u32* scr_pool, 
 // bit offsets, then stores whole words -- only the first and last word of a strip can be shared with a neighbour and go
 // out as atomicOr (before: two global atomics and two global table reads per symbol; 75 -> 32 ms per 512 blocks).
 #define QPOS_TAB 8192u
+#define QPOS_K 3u
 
 __global__ void __launch_bounds__(WG) k_qpos_emit(const BlkDesc* desc, BlkState* st, RecPools rp, const u8* q_stream, u32* word_pool, u32* scr_pool, const QuaPlan* plans)
 {
 	__shared__ u8 s_rank[256];
 	__shared__ u32 s_hdr;
 	__shared__ u64 s_tab[QPOS_TAB];
-	__shared__ u32 s_stage[WG / 64][68];
+	__shared__ u32 s_stage[WG / 64][64 * QPOS_K + 4];
 	const u32 b = blockIdx.x;
 	BlkState* S = &st[b];
 	if (plans[b].scheme > 1) return;
@@ -391,27 +392,39 @@ __global__ void __launch_bounds__(WG) k_qpos_emit(const BlkDesc* desc, BlkState*
 			}
 			at += 1 + (ql != tl ? (variable ? bit_length32(ql) : max_bits) : 0);
 		}
-		for (u32 j0 = 0; j0 < n; j0 += 64)
+		for (u32 j0 = 0; j0 < n; j0 += 64 * QPOS_K)
 		{
-			const u32 j = j0 + lane;
-			u32 code = 0, len = 0;
-			if (j < n) { const u64 e = entry(j, q[j]); code = (u32)e; len = (u32)(e >> 32); }
-			const u32 inc = wave_incl_scan(len);
+			// QPOS_K consecutive symbols per lane: one scan, one strip per 192 symbols (a 150-base read is one strip)
+			u32 code[QPOS_K], len[QPOS_K], lsum = 0;
+#pragma unroll
+			for (u32 k = 0; k < QPOS_K; ++k)
+			{
+				const u32 j = j0 + lane * QPOS_K + k;
+				code[k] = 0; len[k] = 0;
+				if (j < n) { const u64 e = entry(j, q[j]); code[k] = (u32)e; len[k] = (u32)(e >> 32); }
+				lsum += len[k];
+			}
+			const u32 inc = wave_incl_scan(lsum);
 			const u32 T = __shfl(inc, 63);
 			if (T)
 			{
 				const u32 sh0 = (u32)at & 31u;
 				const u64 w0 = at >> 5;
-				const u32 nw = (sh0 + T + 31u) >> 5;             // <= 65 words for codes of <= 32 bits
-				stg[lane] = 0; if (lane < 4) stg[64 + lane] = 0;
+				const u32 nw = (sh0 + T + 31u) >> 5;             // <= 64 * QPOS_K + 1 words for codes of <= 32 bits
+				for (u32 i = lane; i < nw + 1; i += 64) stg[i] = 0;
 				wave_fence();
-				if (len)
+				u32 rel = sh0 + inc - lsum;
+#pragma unroll
+				for (u32 k = 0; k < QPOS_K; ++k)
 				{
-					if (len < 32) code &= (1u << len) - 1u;
-					const u32 rel = sh0 + inc - len;
-					const u64 v = (u64)code << (64u - len - (rel & 31u));
-					atomicOr(&stg[rel >> 5], (u32)(v >> 32));
-					if ((u32)v) atomicOr(&stg[(rel >> 5) + 1], (u32)v);
+					if (len[k])
+					{
+						const u32 c = len[k] < 32 ? code[k] & ((1u << len[k]) - 1u) : code[k];
+						const u64 v = (u64)c << (64u - len[k] - (rel & 31u));
+						atomicOr(&stg[rel >> 5], (u32)(v >> 32));
+						if ((u32)v) atomicOr(&stg[(rel >> 5) + 1], (u32)v);
+						rel += len[k];
+					}
 				}
 				wave_fence();
 				for (u32 i = lane; i < nw; i += 64)
