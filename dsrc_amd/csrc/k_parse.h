@@ -280,17 +280,33 @@ __global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* 
 
 	const u32 lane = lane_id();
 	u32 a_rle = 0, a_th = 0, a_raw = 0, a_min = 0xFFFFFFFFu, a_max = 0, a_tag = 0, a_bad = 0;
-	for (u32 r = wave_id(); r < n_recs; r += (blockDim.x >> 6))
+	// the next record's pool entries and first 64 characters are requested while the current one is processed
+	const u32 wstep = blockDim.x >> 6;
+	u32 n_len = 0, n_so = 0, n_qo = 0, n_b = 0, n_q = 0;
+	if (wave_id() < n_recs)
+	{
+		const u64 g0 = (u64)d.rec_base + wave_id();
+		n_len = rp.len[g0]; n_so = rp.seq_off[g0]; n_qo = rp.qual_off[g0];
+		if (lane < n_len) { n_b = p[n_so + lane]; n_q = p[n_qo + lane]; }
+	}
+	for (u32 r = wave_id(); r < n_recs; r += wstep)
 	{
 		const u64 g = (u64)d.rec_base + r;
-		const u32 len = rp.len[g], so = rp.seq_off[g], qo = rp.qual_off[g];
+		const u32 len = n_len, so = n_so, qo = n_qo;
+		const u32 c_b = n_b, c_q = n_q;
+		if (r + wstep < n_recs)
+		{
+			n_len = rp.len[g + wstep]; n_so = rp.seq_off[g + wstep]; n_qo = rp.qual_off[g + wstep];
+			if (lane < n_len) { n_b = p[n_so + lane]; n_q = p[n_qo + lane]; }
+		}
 		u32 kept = 0, th = 0, rle = 0, carry = 255, lastq = 255;
 		for (u32 j0 = 0; j0 < len; j0 += 64)
 		{
 			const u32 j = j0 + lane;
 			const bool in_r = j < len;
 			u32 sidx = 0, q = 0; bool keep = false;
-			if (in_r) q = transform_base(p[so + j], p[qo + j], prm.quality_offset, prm.lossy, &sidx, &keep);
+			if (in_r) q = j0 ? transform_base(p[so + j], p[qo + j], prm.quality_offset, prm.lossy, &sidx, &keep)
+							 : transform_base(c_b, c_q, prm.quality_offset, prm.lossy, &sidx, &keep);
 			const bool k2 = in_r && keep;
 			if (in_r) atomicAdd(&s_qf[q], 1u);
 			if (in_r && sidx >= 20) a_bad = 1;
