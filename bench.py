@@ -316,6 +316,7 @@ def main():
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         wall = float(tmax[0]); in_bytes = float(tsum[1]); out_bytes = float(tsum[2])
 
+    out_line = None
     if rank == 0:
         value = in_bytes / wall / 1e6
         tm = [x for ln in lanes for x in ln.timing]
@@ -349,11 +350,18 @@ def main():
             need = min(120, sub_blocks)
             sample = ln.h.dev_download(d_in, starts[need - 1] + sizes[need - 1] + 1)
             line["cpu_baseline"] = cpu_baseline(sample, args.dna, args.qua)
-        print(json.dumps(line))
+        out_line = json.dumps(line)
     for ln in lanes:
         ln.h.close()
     if dist is not None:
         dist.destroy_process_group()
+    if out_line is not None:
+        # RCCL's version banner sits in C stdio's buffer until exit: push it out first so that the JSON line is the last
+        # line of stdout
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(out_line, flush=True)
 
 
 if __name__ == "__main__":
