@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) k_synth_sizes(u64 first, u64 count, u64* 
 	if (threadIdx.x == 0) chunk_tot[blockIdx.x] = s_sum;
 }
 
-__global__ void __launch_bounds__(256) k_synth_write(u64 first, u64 count, const u64* chunk_base, u8* out, u64 seed)
+__global__ void __launch_bounds__(256) k_synth_write(u64 first, u64 count, const u64* chunk_base, u8* out, u64 seed, u32 binned)
 {
 	__shared__ u32 s_off[SYNTH_CHUNK];
 	// local exclusive scan of the record sizes of this chunk (serial per 256-thread stripe is enough here)
@@ -97,6 +97,7 @@ __global__ void __launch_bounds__(256) k_synth_write(u64 first, u64 count, const
 			const i32 z4 = num >= 0 ? num / 209 : -((-num + 208) / 209);       // floor division
 			i32 qv = 38 - (i32)((6 * pos) / 100) + z4;
 			qv = qv < 2 ? 2 : (qv > 40 ? 40 : qv);
+			if (binned) qv = qv < 3 ? 2 : qv < 18 ? 12 : qv < 30 ? 23 : 37;      // DSRC_SYNTH_BINNED=1: four-level (NovaSeq-like) qualities, for experiments only
 			p[pos] = is_n ? (u8)'N' : (u8)"ACGT"[h1 & 3];
 			q[pos] = (u8)(33 + (is_n ? 2 : qv));
 		}
@@ -124,7 +125,7 @@ static inline int synth_illumina_device(hipStream_t s, u64 first, u64 count, u8*
 	else
 	{
 		hipMemcpyAsync(d_tot, tot, (size_t)n_chunks * 8, hipMemcpyHostToDevice, s);
-		hipLaunchKernelGGL(k_synth_write, dim3(n_chunks), dim3(256), 0, s, first, count, d_tot, d_out, (u64)0xD5C0FFEEull);
+		hipLaunchKernelGGL(k_synth_write, dim3(n_chunks), dim3(256), 0, s, first, count, d_tot, d_out, (u64)0xD5C0FFEEull, (u32)(getenv("DSRC_SYNTH_BINNED") != nullptr));
 		hipStreamSynchronize(s);
 	}
 	free(tot); hipFree(d_tot);
