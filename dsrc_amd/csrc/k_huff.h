@@ -442,6 +442,7 @@ __global__ void __launch_bounds__(WG) k_qpos_emit(const BlkDesc* desc, BlkState*
 
 // ---- quality, RLE (scheme 2) ------------------------------------------------------------------------
 // runs cross record boundaries; a run holds at most 255 symbols (length byte 0..254).
+#define QRUN_ITEMS 4u
 __global__ void __launch_bounds__(WG) k_qrle_runs(const BlkDesc* desc, BlkState* st, const u8* q_stream, u32* scr_pool, const QuaPlan* plans)
 {
 	__shared__ u32 s_wmax[WAVES];
@@ -455,28 +456,48 @@ __global__ void __launch_bounds__(WG) k_qrle_runs(const BlkDesc* desc, BlkState*
 	const u8* q = q_stream + d.q_base;
 	const u32 n = S->q_total;
 	u32 carry_head = 0, carry_runs = 0;
-	for (u32 base = 0; base < n; base += blockDim.x)
+	// QRUN_ITEMS consecutive symbols per thread (one 4-byte load; the quality streams are 64-byte aligned and padded)
+	for (u32 base = 0; base < n; base += blockDim.x * QRUN_ITEMS)
 	{
-		const u32 t = base + threadIdx.x;
-		const bool valid = t < n;
-		const bool head = valid && (t == 0 || q[t] != q[t - 1]);
-		// inclusive max-scan of head positions (+1 so that 0 means "none in this tile")
-		u32 v = head ? t + 1 : 0;
+		const u32 t0 = base + threadIdx.x * QRUN_ITEMS;
+		const u32 w = t0 < n ? *(const u32*)(q + t0) : 0u;
+		u32 prevb = (t0 > 0 && t0 < n) ? q[t0 - 1] : 256u;
+		u32 hv = 0, hmask = 0;                      // last head position (+1) among my symbols; which of them are heads
+#pragma unroll
+		for (u32 i = 0; i < QRUN_ITEMS; ++i)
+		{
+			const u32 t = t0 + i, bq = (w >> (8 * i)) & 255u;
+			if (t < n && (t == 0 || bq != prevb)) { hv = t + 1; hmask |= 1u << i; }
+			prevb = bq;
+		}
+		// inclusive max-scan of head positions (+1 so that 0 means "none")
+		u32 v = hv;
 		for (u32 dd = 1; dd < 64; dd <<= 1) { const u32 o = __shfl_up(v, dd); if (lane_id() >= dd && o > v) v = o; }
 		if (lane_id() == 63) s_wmax[wave_id()] = v;
 		__syncthreads();
 		u32 pre = carry_head, all = carry_head;
-		for (u32 w = 0; w < (blockDim.x >> 6); ++w) { const u32 x = s_wmax[w]; if (w < wave_id() && x > pre) pre = x; if (x > all) all = x; }
-		if (pre > v) v = pre;                     // v-1 = start of the maximal run containing t
-		const bool chunk = valid && ((t - (v - 1)) % 255u == 0);
+		for (u32 wv = 0; wv < (blockDim.x >> 6); ++wv) { const u32 x = s_wmax[wv]; if (wv < wave_id() && x > pre) pre = x; if (x > all) all = x; }
+		u32 cur = __shfl_up(v, 1);                  // last head before my first symbol
+		if (lane_id() == 0) cur = 0;
+		if (pre > cur) cur = pre;
+		u32 cnt = 0, where[QRUN_ITEMS];
+#pragma unroll
+		for (u32 i = 0; i < QRUN_ITEMS; ++i)
+		{
+			const u32 t = t0 + i;
+			if ((hmask >> i) & 1u) cur = t + 1;       // cur-1 = start of the maximal run containing t
+			where[i] = 0;
+			if (t < n && ((t - (cur - 1)) % 255u == 0)) { where[cnt] = t; ++cnt; }
+		}
 		u32 tot;
-		const u32 ex = block_excl_scan(chunk ? 1u : 0u, &tot);
-		if (chunk) run_start[carry_runs + ex] = t;
+		const u32 ex = block_excl_scan(cnt, &tot);
+		for (u32 i = 0; i < cnt; ++i) run_start[carry_runs + ex + i] = where[i];
 		carry_runs += tot; carry_head = all;
 	}
 	if (threadIdx.x == 0) { S->q_runs = carry_runs; run_start[carry_runs] = n; }
 }
 
+#define QRLE_LDS_HIST 8192u
 // histograms: lf[256] (run-length symbols), then qF[prev][q] and lF[q][l] over dense ranks
 __global__ void __launch_bounds__(WG) k_qrle_hist(const BlkDesc* desc, BlkState* st, const u8* q_stream, u32* scr_pool, const QuaPlan* plans)
 {
@@ -516,13 +537,25 @@ __global__ void __launch_bounds__(WG) k_qrle_hist(const BlkDesc* desc, BlkState*
 	const u32 ln = s_ln;
 	u32* qF = scr;                              // [qn][qn]
 	u32* lF = scr + (u64)qn * qn;               // [qn][ln]
+	// the counters are few (4 x 4 + 4 x ln for four-level qualities) and every thread of the workgroup hits them:
+	// count in LDS and add the totals to the (zeroed) global tables once; global atomics only when they do not fit
+	__shared__ u32 s_h[QRLE_LDS_HIST];
+	const u32 words = qn * qn + qn * ln;
+	const bool in_lds = words <= QRLE_LDS_HIST;
+	if (in_lds) { for (u32 i = threadIdx.x; i < words; i += blockDim.x) s_h[i] = 0; __syncthreads(); }
 	for (u32 k = threadIdx.x; k < R; k += blockDim.x)
 	{
-		const u32 qs = s_qrank[q[run_start[k]]];
-		const u32 prev = k ? s_qrank[q[run_start[k - 1]]] : 0;
-		const u32 l = s_lrank[run_start[k + 1] - run_start[k] - 1];
-		atomicAdd(&qF[(u64)prev * qn + qs], 1u);
-		atomicAdd(&lF[(u64)qs * ln + l], 1u);
+		const u32 rs = run_start[k];
+		const u32 qs = s_qrank[q[rs]];
+		const u32 prev = k ? s_qrank[q[rs - 1]] : 0;          // the run before k ends right before k's first symbol
+		const u32 l = s_lrank[run_start[k + 1] - rs - 1];
+		if (in_lds) { atomicAdd(&s_h[prev * qn + qs], 1u); atomicAdd(&s_h[qn * qn + qs * ln + l], 1u); }
+		else { atomicAdd(&qF[(u64)prev * qn + qs], 1u); atomicAdd(&lF[(u64)qs * ln + l], 1u); }
+	}
+	if (in_lds)
+	{
+		__syncthreads();
+		for (u32 i = threadIdx.x; i < words; i += blockDim.x) if (s_h[i]) scr[i] = s_h[i];
 	}
 }
 
@@ -553,10 +586,13 @@ __global__ void __launch_bounds__(64) k_qrle_trees(BlkState* st, u32* scr_pool, 
 	*(u32*)tr = tb;
 }
 
+#define QRLE_LDS_TAB 4096u
+#define QRLE_ITEMS 4u
 __global__ void __launch_bounds__(WG) k_qrle_emit(const BlkDesc* desc, BlkState* st, const u8* q_stream, u32* word_pool, u32* scr_pool, const QuaPlan* plans)
 {
 	__shared__ u8 s_qrank[256];
 	__shared__ u32 s_hdr;
+	__shared__ u64 s_ct[QRLE_LDS_TAB];
 	const u32 b = blockIdx.x;
 	BlkState* S = &st[b];
 	if (plans[b].scheme != 2) return;
@@ -602,21 +638,56 @@ __global__ void __launch_bounds__(WG) k_qrle_emit(const BlkDesc* desc, BlkState*
 	if (qn > 1)
 	{
 		const u32* ccode = scr + pl.code_off; const u32* clen = scr + pl.len_off;
-		for (u32 base = 0; base < R; base += blockDim.x)
+		// code tables in LDS when they fit (q | prev: [qn][qn], then len | q: [qn][256]), as (len << 32 | code)
+		const u32 tabw = qn * qn + qn * 256u;
+		const bool in_lds = tabw <= QRLE_LDS_TAB;
+		if (in_lds) { for (u32 i = threadIdx.x; i < tabw; i += blockDim.x) s_ct[i] = ((u64)clen[i] << 32) | ccode[i]; }
+		__syncthreads();
+		// QRLE_ITEMS consecutive runs per thread: one workgroup scan per 4096 runs, and the thread's codes leave through a
+		// 64-bit accumulator (one or two word updates instead of two per run)
+		for (u32 base = 0; base < R; base += blockDim.x * QRLE_ITEMS)
 		{
-			const u32 k = base + threadIdx.x;
-			u32 c1 = 0, l1 = 0, c2 = 0, l2 = 0;
-			if (k < R)
+			const u32 k0 = base + threadIdx.x * QRLE_ITEMS;
+			u32 cc[2 * QRLE_ITEMS], ll[2 * QRLE_ITEMS], sum = 0;
+#pragma unroll
+			for (u32 i = 0; i < QRLE_ITEMS; ++i)
 			{
-				const u32 qs = s_qrank[q[run_start[k]]];
-				const u32 prev = k ? s_qrank[q[run_start[k - 1]]] : 0;
-				const u32 l = lrank[run_start[k + 1] - run_start[k] - 1];
-				const u64 i1 = (u64)prev * qn + qs, i2 = (u64)qn * qn + (u64)qs * 256 + l;
-				c1 = ccode[i1]; l1 = clen[i1]; c2 = ccode[i2]; l2 = clen[i2];
+				const u32 k = k0 + i;
+				cc[2 * i] = cc[2 * i + 1] = ll[2 * i] = ll[2 * i + 1] = 0;
+				if (k < R)
+				{
+					const u32 rs = run_start[k];
+					const u32 qs = s_qrank[q[rs]];
+					const u32 prev = k ? s_qrank[q[rs - 1]] : 0;
+					const u32 l = lrank[run_start[k + 1] - rs - 1];
+					const u32 i1 = prev * qn + qs, i2 = qn * qn + qs * 256u + l;
+					const u64 e1 = in_lds ? s_ct[i1] : (((u64)clen[i1] << 32) | ccode[i1]);
+					const u64 e2 = in_lds ? s_ct[i2] : (((u64)clen[i2] << 32) | ccode[i2]);
+					cc[2 * i] = (u32)e1; ll[2 * i] = (u32)(e1 >> 32); cc[2 * i + 1] = (u32)e2; ll[2 * i + 1] = (u32)(e2 >> 32);
+				}
+				sum += ll[2 * i] + ll[2 * i + 1];
 			}
 			u32 tot;
-			const u32 off = block_excl_scan(l1 + l2, &tot);
-			if (k < R) { put_bits(out, bitpos + off, c1, l1); put_bits(out, bitpos + off + l1, c2, l2); }
+			const u32 off = block_excl_scan(sum, &tot);
+			u64 at = bitpos + off, buf = 0; u32 nb = 0;
+			auto flush = [&]()
+			{
+				if (!nb) return;
+				const u32 h = nb < 32 ? nb : 32;
+				put_bits(out, at, (u32)(buf >> (64 - h)), h);
+				if (nb > 32) put_bits(out, at + 32, (u32)(buf >> (64 - nb)), nb - 32);
+				at += nb; nb = 0; buf = 0;
+			};
+#pragma unroll
+			for (u32 i = 0; i < 2 * QRLE_ITEMS; ++i)
+			{
+				const u32 len = ll[i];
+				if (!len) continue;
+				if (nb + len > 64) flush();
+				const u32 c = len < 32 ? cc[i] & ((1u << len) - 1u) : cc[i];
+				buf |= (u64)c << (64 - nb - len); nb += len;
+			}
+			flush();
 			bitpos += tot;
 		}
 	}

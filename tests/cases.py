@@ -104,3 +104,25 @@ def fuzz_solid(seed: int, nrec: int | None = None):
         t = b"@SRR%d.%d solid_%d_%d_%d" % (2000 + seed, i + 1, 1 + i // 300, (i * 7) % 2048, (i * 13) % 2048)
         out += [t, b'\n', bytes(seq), b'\n+\n', bytes(v + 33 for v in q), b'\n']
     return b''.join(out)[:-1], (const_begin, varlen, L0, dots, qmode, q0)
+
+
+def rle_chunks():
+    """Quality strings made of long runs: the RLE scheme (QualityRLEModeler) with 4, 20 and 45 distinct values -- the small
+    alphabets keep code tables and histograms in LDS, the large ones take the global-memory fallbacks -- and runs longer
+    than 255 (split) that cross record boundaries."""
+    import random
+    out = []
+    for nsym, nrec, L in ((4, 6000, 150), (20, 3000, 200), (45, 1500, 250)):
+        rng = random.Random(nsym)
+        vals = rng.sample(range(2, 60), nsym)
+        recs = []; cur = vals[0]; left = 0
+        for i in range(nrec):
+            q = bytearray()
+            for _ in range(L):
+                if left == 0:
+                    cur = rng.choice(vals); left = rng.choice([1, 2, 3, 7, 30, 90, 400, 700])
+                q.append(33 + cur); left -= 1
+            seq = bytes(rng.choice(b"ACGT") for _ in range(L))
+            recs.append(b"@r.%d x\n" % i + seq + b"\n+\n" + bytes(q))
+        out.append(b"\n".join(recs))
+    return out

@@ -261,6 +261,17 @@ def test_color_space(emu, oracle, seed):
         assert got[0] == want, (seed, desc, d, q, lossy, crc)
 
 
+def test_rle_quality_alphabets(emu, oracle):
+    """RLE quality scheme with 4 / 20 / 45 distinct values: LDS code tables and histograms, and their global fallbacks."""
+    from tests.cases import rle_chunks
+    cfg = Config.from_levels(0, 0)
+    for c in rle_chunks():
+        c = c[:len(c) // 8]; c = c[:c.rfind(b"\n@")]
+        want = oracle.compress_block(cfg, c)
+        assert want[0][want[2][0] + want[2][1]] == 2
+        assert run(emu, cfg, c) == want
+
+
 def test_color_space_golden_small(emu):
     """The small -q0 blocks of the reference's SOLiD golden set (all three quality schemes; the RLE modeler takes its
     alphabet from the runs of the shortened records, not from the statistics)."""

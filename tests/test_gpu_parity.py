@@ -105,6 +105,17 @@ def test_hot_contexts_rescale(gpu, oracle):
         _check(gpu, oracle, Config.from_levels(d, q, lossy), [data])
 
 
+def test_rle_quality_alphabets(gpu, oracle):
+    """RLE quality scheme at -q0 with small and large alphabets (LDS tables / global fallbacks in k_qrle_hist, k_qrle_emit)."""
+    from tests.cases import rle_chunks
+    chunks = rle_chunks()
+    for c in chunks:
+        blk, _, comp = oracle.compress_block(Config.from_levels(0, 0), c)
+        assert blk[comp[0] + comp[1]] == 2          # scheme byte of the quality stream: RLE
+    for d, q, lossy in [(0, 0, False), (2, 0, False)]:
+        _check(gpu, oracle, Config.from_levels(d, q, lossy), chunks)
+
+
 def test_range_coder_reference_loop_path(gpu, oracle, monkeypatch):
     """The carry-clamp fallback of k_rc (reference loop + byte re-dealing) must give the same stream as the fast
     path; DSRC_GPU_FORCE_EXACT_RC sends every 16-symbol group through it."""
