@@ -639,12 +639,12 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 				const u32 parts = std::max(1u, std::min(max_parts, mxn / 1024u));
 				switch (jobs[lo].n_alpha)
 				{
-				case 4:   hipLaunchKernelGGL(k_replay<4>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
-				case 8:   hipLaunchKernelGGL(k_replay<8>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
-				case 16:  hipLaunchKernelGGL(k_replay<16>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
-				case 32:  hipLaunchKernelGGL(k_replay<32>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
-				case 64:  hipLaunchKernelGGL(k_replay<64>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
-				default:  hipLaunchKernelGGL(k_replay<128>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+				case 4:   hipLaunchKernelGGL(k_replay_seams<4>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool)); hipLaunchKernelGGL(k_replay<4>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+				case 8:   hipLaunchKernelGGL(k_replay_seams<8>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool)); hipLaunchKernelGGL(k_replay<8>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+				case 16:  hipLaunchKernelGGL(k_replay_seams<16>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool)); hipLaunchKernelGGL(k_replay<16>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+				case 32:  hipLaunchKernelGGL(k_replay_seams<32>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool)); hipLaunchKernelGGL(k_replay<32>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+				case 64:  hipLaunchKernelGGL(k_replay_seams<64>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool)); hipLaunchKernelGGL(k_replay<64>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+				default:  hipLaunchKernelGGL(k_replay_seams<128>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool)); hipLaunchKernelGGL(k_replay<128>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
 				}
 				KCHK();
 				lo = hi;

@@ -385,8 +385,8 @@ __global__ void __launch_bounds__(256) k_selftest(u32* bad)
 // the chain's own 12 B x n array: with few chains in flight that array stays in the memory-side cache, so the
 // 12-byte pieces merge into full lines before they reach HBM -- the launch uses many waves per chain.)  Only the segment that
 // is still open at the end of a window carries state (lane v keeps base[v] / cnt[v]); a window is
-// cut short where that segment hits its rescale point.  A wave owns the segments whose heads fall
-// into its slice of the array, so any number of waves can work on one stream.
+// cut short where that segment hits its rescale point.  A wave replays exactly its slice of the array (see
+// k_replay_seams for segments that cross slices), so any number of waves can work on one stream.
 #define REPLAY_WG 256
 
 template <int N> struct ReplayRow
@@ -412,6 +412,96 @@ template <int N> __device__ __forceinline__ void replay_prefix(const ReplayRow<N
 	*total = ta + tb;
 }
 
+// Ranges: the sorted array of a stream is cut into gridDim.x * REPLAY_WG/64 ranges of `per` elements (a multiple of 64,
+// at least 256); wave w replays exactly range w.  A segment that crosses a range boundary needs the row state at the
+// boundary: k_replay_seams computes it with a cheap walk (counts only: no ranks, no records) by the wave whose range holds
+// the segment's head, and leaves it in the sort buffer that is no longer needed (REPLAY_SEAM_WORDS u32 per boundary, which
+// always fits: per >= 256 elements of 8 bytes per boundary).  So a context that holds most of a stream's symbols is
+// replayed by all the stream's waves, not by one.
+#define REPLAY_SEAM_WORDS 260u
+__device__ __forceinline__ u32 replay_per(u32 n, u32 n_ranges)
+{
+	const u32 per = ((n + n_ranges - 1) / n_ranges + 63u) & ~63u;
+	return per < 256u ? 256u : per;
+}
+
+template <int N>
+__global__ void __launch_bounds__(REPLAY_WG) k_replay_seams(const CtxJob* jobs, u64* pool)
+{
+	constexpr int BITS = N <= 4 ? 2 : N <= 8 ? 3 : N <= 16 ? 4 : N <= 32 ? 5 : N <= 64 ? 6 : 7;
+	const CtxJob j = jobs[blockIdx.y];
+	const u64* src = pool + (j.sorted_in_b ? j.elems_b : j.elems);
+	u32* seams = (u32*)(pool + (j.sorted_in_b ? j.elems : j.elems_b));
+	const u32 n = j.n;
+	const u32 lane = lane_id();
+	const u32 limit = (1u << 16) - 2u * N;
+	const u32 per = replay_per(n, gridDim.x * (REPLAY_WG / 64));
+	const u64 r_lo64 = (u64)(blockIdx.x * (REPLAY_WG / 64) + wave_id()) * per;
+	if (r_lo64 + per >= n) return;                          // no boundary after this range
+	const u32 r_lo = (u32)r_lo64, hi = r_lo + per;
+	if ((src[hi] >> ELEM_CTX_SHIFT) != (src[hi - 1] >> ELEM_CTX_SHIFT)) return;      // nothing crosses my upper boundary
+	// head of the segment that crosses it, if it lies in my range (otherwise the owner of that head walks through here)
+	u32 h = 0; bool found = false;
+	for (u32 we = hi; we > r_lo && !found; we -= 64)
+	{
+		const u32 i = we - 64 + lane;
+		const bool hd = i == 0 || (src[i] >> ELEM_CTX_SHIFT) != (src[i - 1] >> ELEM_CTX_SHIFT);
+		const u64 m = __ballot(hd);
+		if (m) { h = we - 64 + 63u - (u32)__clzll((long long)m); found = true; }
+	}
+	if (!found) return;
+	const u64 segctx = src[h] >> ELEM_CTX_SHIFT;
+	u32 base_a = lane < (u32)N ? 1u : 0u, base_b = N > 64 ? 1u : 0u, cnt_a = 0, cnt_b = 0;
+	u32 T0 = N, epoch_cnt = 0, epoch_left = (limit - N + 1) / 2;
+	u32 pos = h, next_b = hi;
+	u64 el_cur = pos + lane < n ? src[pos + lane] : ~0ull;
+	for (;;)
+	{
+		const u32 idx = pos + lane;
+		const u64 el = el_cur;
+		// windows are almost always full: ask for the next 64 elements before this window's length is known
+		const u64 el_spec = idx + 64 < n ? src[idx + 64] : ~0ull;
+		const bool same = idx < n && (el >> ELEM_CTX_SHIFT) == segctx;
+		const u64 m_not = __ballot(!same);
+		const u32 seg_rem = m_not ? (u32)__ffsll((long long)m_not) - 1 : 64u;
+		u32 tile_len = seg_rem;
+		if (epoch_left < tile_len) tile_len = epoch_left;
+		if (next_b - pos < tile_len) tile_len = next_b - pos;
+		const bool seg_ends = tile_len == seg_rem && seg_rem < 64;
+		const u64 tmask = tile_len >= 64 ? ~0ull : ((1ull << tile_len) - 1ull);
+		const u32 sym = (u32)(el >> ELEM_SYM_SHIFT) & 0xFFu;
+		// lane c counts the lanes of the window that carry symbol c (and c + 64)
+		u64 ma = tmask, mb = tmask;
+#pragma unroll
+		for (int k = BITS - 1; k >= 0; --k)
+		{
+			const u64 m = __ballot(lane < tile_len && ((sym >> k) & 1u));
+			if (k == 6) { ma &= ~m; mb &= m; }
+			else { const u64 sel = ((lane >> k) & 1u) ? m : ~m; ma &= sel; mb &= sel; }
+		}
+		if (lane < (u32)N) cnt_a += (u32)__popcll(ma);
+		if (N > 64) cnt_b += (u32)__popcll(mb);
+		epoch_cnt += tile_len; epoch_left -= tile_len; pos += tile_len;
+		if (epoch_left == 0)
+		{	// Rescale(), as in k_replay
+			u32 x = base_a + 2 * cnt_a; base_a = lane < (u32)N ? x - (x >> 1) : 0u;
+			if (N > 64) { x = base_b + 2 * cnt_b; base_b = x - (x >> 1); }
+			cnt_a = cnt_b = 0;
+			T0 = wave_sum(base_a + base_b);
+			epoch_cnt = 0; epoch_left = (limit - T0 + 1) / 2;
+		}
+		if (seg_ends || pos >= n) break;
+		el_cur = tile_len == 64 ? el_spec : (pos + lane < n ? src[pos + lane] : ~0ull);
+		if (pos == next_b)
+		{
+			u32* st = seams + (u64)(pos / per) * REPLAY_SEAM_WORDS;
+			if (lane == 0) { st[0] = T0; st[1] = epoch_cnt; st[2] = epoch_left; st[3] = 0x5EA35EA3u; }
+			st[4 + lane] = base_a; st[68 + lane] = base_b; st[132 + lane] = cnt_a; st[196 + lane] = cnt_b;
+			next_b += per;
+		}
+	}
+}
+
 template <int N>
 __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const u64* pool, RcRec* rec_pool)
 {
@@ -423,32 +513,27 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 	const u32 n = j.n;
 	const u32 lane = lane_id();
 	const u32 limit = (1u << 16) - 2u * N;                   // MaxAccumulatedValue (src/SymbolCoderRC.h:67)
-	const u32 n_ranges = gridDim.x * (REPLAY_WG / 64);
-	const u32 per = ((n + n_ranges - 1) / n_ranges + 63u) & ~63u;
+	const u32 per = replay_per(n, gridDim.x * (REPLAY_WG / 64));
 	const u64 r_lo = (u64)(blockIdx.x * (REPLAY_WG / 64) + wave_id()) * per;
 	if (r_lo >= n) return;
 	const u32 hi = (u32)(r_lo + per < n ? r_lo + per : n);
 	u32 pos = (u32)r_lo;
-	// first segment head at or after the nominal start belongs to this wave
-	if (pos > 0)
-	{
-		for (;;)
-		{
-			const u32 i = pos + lane;
-			const bool hd = i < n && (src[i] >> ELEM_CTX_SHIFT) != (src[i - 1] >> ELEM_CTX_SHIFT);
-			const u64 m = __ballot(hd);
-			if (m) { pos += (u32)__ffsll((long long)m) - 1; break; }
-			pos += 64;
-			if (pos >= hi) return;
-		}
-		if (pos >= hi) return;
-	}
+	// a range that starts inside a segment takes the row state k_replay_seams left for its lower boundary
+	const bool mid = pos > 0 && (src[pos] >> ELEM_CTX_SHIFT) == (src[pos - 1] >> ELEM_CTX_SHIFT);
 
 	ReplayRow<N> base, cnt, cumbase, cntpre;
 	base.a = base.b = 1; cnt.a = cnt.b = 0; cumbase.a = cumbase.b = 0; cntpre.a = cntpre.b = 0;
 	bool open = false;                      // a segment continues from the previous window
 	u32 T0 = N, epoch_cnt = 0, epoch_left = 0;
 	const u32 E0 = (limit - N + 1) / 2;     // symbols a fresh row codes before its first rescale
+	if (mid)
+	{
+		const u32* st = (const u32*)(pool + (j.sorted_in_b ? j.elems : j.elems_b)) + (u64)(pos / per) * REPLAY_SEAM_WORDS;
+		T0 = st[0]; epoch_cnt = st[1]; epoch_left = st[2];
+		base.a = st[4 + lane]; base.b = st[68 + lane]; cnt.a = st[132 + lane]; cnt.b = st[196 + lane];
+		u32 t; replay_prefix<N>(base, cumbase, &t); replay_prefix<N>(cnt, cntpre, &t);
+		open = true;
+	}
 
 	// software pipeline: the next window is requested as soon as this window's length is known
 	u64 el_cur = pos + lane < n ? src[pos + lane] : 0;
@@ -466,8 +551,7 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 		const u64 hm_all = __ballot(head);
 		u32 tile_len = (u32)__popcll(__ballot(valid));
 		bool last = false;
-		const u64 stop = hm_all & __ballot(idx >= hi);
-		if (stop) { const u32 c = (u32)__ffsll((long long)stop) - 1; if (c < tile_len) tile_len = c; last = true; }
+		if (pos + tile_len >= hi) { tile_len = hi - pos; last = true; }      // every wave stops at the end of its range
 		if (!(hm_all & 1ull) && !open) { /* cannot happen: windows start on a head unless a segment is open */ }
 		bool rescale_after = false;
 		const bool cont = open && !(hm_all & 1ull);          // lane 0 continues the open segment

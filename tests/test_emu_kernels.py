@@ -261,6 +261,22 @@ def test_color_space(emu, oracle, seed):
         assert got[0] == want, (seed, desc, d, q, lossy, crc)
 
 
+def test_hot_contexts_cross_ranges(emu, oracle):
+    """A context that holds most of a stream (> 32k symbols: several Rescale() calls) spans many replay ranges: the seam
+    states of k_replay_seams must let every range start in the middle of the segment."""
+    import random
+    rng = random.Random(11)
+    recs = []
+    for i in range(400):
+        seq = ''.join(rng.choice('AAAAAAAAAAAAAAAC') for _ in range(250))
+        q = ''.join('I' if rng.random() < 0.98 else 'H' for _ in range(250))
+        recs.append(f"@r.{i}\n{seq}\n+\n{q}")
+    data = '\n'.join(recs).encode()
+    for d, q, lossy in [(1, 2, False), (3, 1, False), (2, 2, True)]:
+        cfg = Config.from_levels(d, q, lossy)
+        assert run(emu, cfg, data) == oracle.compress_block(cfg, data), (d, q, lossy)
+
+
 def test_rle_quality_alphabets(emu, oracle):
     """RLE quality scheme with 4 / 20 / 45 distinct values: LDS code tables and histograms, and their global fallbacks."""
     from tests.cases import rle_chunks
