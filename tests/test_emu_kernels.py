@@ -267,12 +267,12 @@ def test_hot_contexts_cross_ranges(emu, oracle):
     import random
     rng = random.Random(11)
     recs = []
-    for i in range(400):
+    for i in range(250):
         seq = ''.join(rng.choice('AAAAAAAAAAAAAAAC') for _ in range(250))
         q = ''.join('I' if rng.random() < 0.98 else 'H' for _ in range(250))
         recs.append(f"@r.{i}\n{seq}\n+\n{q}")
     data = '\n'.join(recs).encode()
-    for d, q, lossy in [(1, 2, False), (3, 1, False), (2, 2, True)]:
+    for d, q, lossy in [(1, 2, False), (2, 2, True)]:
         cfg = Config.from_levels(d, q, lossy)
         assert run(emu, cfg, data) == oracle.compress_block(cfg, data), (d, q, lossy)
 
