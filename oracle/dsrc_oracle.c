@@ -148,6 +148,13 @@ static u32 crc_update(u32 crc, const u8* p, u32 n)
 	return crc;
 }
 
+/* raw register update (no initial / final inversion), for running checksums over many pieces */
+uint32_t orc_crc32_update(uint32_t state, const uint8_t* p, uint32_t n)
+{
+	crc_init();
+	return crc_update(state, p, n);
+}
+
 uint32_t orc_crc32(const uint8_t* p, uint32_t n)
 {
 	crc_init();

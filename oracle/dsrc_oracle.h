@@ -77,6 +77,16 @@ int orc_compress_records_block(const orc_config* cfg, uint32_t* fields_cap, uint
 int orc_compress_records_file(const char* in_path, const char* out_path, uint32_t dna_level, uint32_t quality_level,
 							  int lossy, uint32_t qoff, uint32_t buf_mb, int plus_rep);
 
+/* BlockCompressor::Read (src/BlockCompressor.cpp:262-297): one block -> the FASTQ text of the chunk, every line
+ * (also the last) ended by '\n'.  stored_crc / actual_crc (each tag, sequence, quality; may be NULL): the checksum
+ * words of the block's meta stream and the ones recomputed over the decoded records as VerifyChecksum does
+ * (src/BlockCompressor.cpp:576-594).  Implemented in dsrc_oracle_dec.c. */
+int orc_decompress_block(const orc_config* cfg, const uint8_t* in, uint64_t size, uint8_t* out, uint64_t cap,
+						 uint64_t* out_size, uint32_t stored_crc[3], uint32_t actual_crc[3]);
+/* VerifyChecksum: 1 = the enabled checksums match, 0 = mismatch, < 0 = ORC_E_* */
+int orc_verify_block(const orc_config* cfg, const uint8_t* in, uint64_t size, uint64_t text_cap);
+uint32_t orc_crc32_update(uint32_t state, const uint8_t* p, uint32_t n);
+
 /* primitives (same calling convention as the ref_* probes) */
 uint64_t orc_bitwriter_script(const uint32_t* ops, uint32_t nops, uint8_t* out, uint64_t cap);
 uint64_t orc_huffman(const uint32_t* freqs, uint32_t n, uint32_t* codes, uint32_t* lens, uint8_t* tree, uint64_t cap);

@@ -155,6 +155,21 @@ class Oracle:
     def crc32(self, data: bytes) -> int:
         return self.lib.orc_crc32(data, len(data))
 
+    def decompress_block(self, cfg: Config, block: bytes, cap: int, with_crc: bool = False):
+        """BlockCompressor::Read restated (oracle/dsrc_oracle_dec.c) -> chunk text incl. the final newline."""
+        c = _orc_cfg(cfg)
+        out = (C.c_uint8 * (cap + 64))()
+        osz = C.c_uint64(0); st = (C.c_uint32 * 3)(); ac = (C.c_uint32 * 3)()
+        rc = self.lib.orc_decompress_block(C.byref(c), block, C.c_uint64(len(block)), out, C.c_uint64(cap), C.byref(osz), st, ac)
+        if rc != 0:
+            raise RuntimeError(f"orc_decompress_block rc={rc}")
+        text = bytes(out[: osz.value])
+        return (text, list(st), list(ac)) if with_crc else text
+
+    def verify_block(self, cfg: Config, block: bytes, cap: int) -> int:
+        c = _orc_cfg(cfg)
+        return self.lib.orc_verify_block(C.byref(c), block, C.c_uint64(len(block)), C.c_uint64(cap))
+
 
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libdsrc_ref.so")
 REF_BIN = os.path.join(ORACLE_DIR, "_ref", "dsrc_ref")
