@@ -134,11 +134,12 @@ class Handle:
         self._chk(self.L.dsrcgpu_compress_block(self.h, data, C.c_uint64(len(data)), out, C.c_uint64(cap), C.byref(osz), raw, comp))
         return bytes(out[: osz.value]), list(raw), list(comp)
 
-    def compress_batch(self, chunks):
+    def compress_batch(self, chunks, cap=None):
         n = len(chunks)
         ptrs = (C.c_char_p * n)(*chunks)
         sizes = (C.c_uint64 * n)(*[len(c) for c in chunks])
-        cap = sum(len(c) for c in chunks) + n * (1 << 16)
+        if cap is None:
+            cap = sum(len(c) for c in chunks) + n * (1 << 16)
         out = (C.c_uint8 * cap)()
         offs = (C.c_uint64 * n)(); osz = (C.c_uint64 * n)()
         raw = (C.c_uint64 * (4 * n))(); comp = (C.c_uint64 * (4 * n))()

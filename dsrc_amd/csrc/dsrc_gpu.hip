@@ -75,6 +75,7 @@ struct dsrcgpu_handle
 	std::vector<u32> rec_chunk_sizes; // dsrcgpu_set_record_layout: applies to the next batch, then cleared
 	dsrcgpu_chain* chain = nullptr;  // if set: fields_cap comes from / goes to the chain, in batch order
 	uint64_t chain_seq = 0; bool chain_taken = false; u32 chain_cap_in = 0;
+	bool chain_batch_done = true;    // the batch announced by dsrcgpu_set_chain has run to completion
 	u32* d_crc_tab = nullptr;
 	std::string err;
 	std::vector<Pending> pending;
@@ -719,6 +720,7 @@ template <typename F> int with_arena_retry(dsrcgpu_handle* h, size_t initial, F&
 {
 	const int rc = with_arena_retry_(h, initial, body);
 	if (rc != DSRCGPU_OK) chain_abort(h);
+	else h->chain_batch_done = true;
 	h->rec_chunk_sizes.clear();           // dsrcgpu_set_record_layout is one-shot
 	return rc;
 }
@@ -952,7 +954,11 @@ void dsrcgpu_chain_destroy(dsrcgpu_chain* c) { delete c; }
 int dsrcgpu_set_chain(dsrcgpu_handle* h, dsrcgpu_chain* c, uint64_t seq)
 {
 	if (!h) return DSRCGPU_E_ARG;
-	h->chain = c; h->chain_seq = seq; h->chain_taken = false;
+	// Announcing the same batch again -- the caller retries it after DSRCGPU_E_CAPACITY with a larger output buffer --
+	// must not take a second turn: the first attempt has already read the state of batch seq - 1 and published its
+	// own (later batches may have advanced the chain since), so the retry re-uses what it read then.
+	if (c && h->chain == c && h->chain_seq == seq && h->chain_taken && !h->chain_batch_done) return DSRCGPU_OK;
+	h->chain = c; h->chain_seq = seq; h->chain_taken = false; h->chain_batch_done = false;
 	return DSRCGPU_OK;
 }
 

@@ -412,10 +412,10 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 					uint64 cap = inBytes * 2 / 5 + (uint64)n * (1u << 16);     // typical ratio 0.2-0.33; grown below if the data needs it
 					job->offs.resize(n); job->osz.resize(n); job->raw.resize(4 * n); job->comp.resize(4 * n);
 					int rc;
+					dsrcgpu_set_chain(h, chain, job->seq);     // once per batch: a retry below is the same turn of the chain
 					for (;;)
 					{
 						ob.Reserve(cap);
-						dsrcgpu_set_chain(h, chain, job->seq);
 						rc = dsrcgpu_compress_batch(h, n, ptrs.data(), job->sizes.data(), ob.p, ob.cap, job->offs.data(), job->osz.data(), job->raw.data(), job->comp.data());
 						if (rc != DSRCGPU_E_CAPACITY || cap >= inBytes + (uint64)n * (1u << 16)) break;
 						cap = inBytes + (uint64)n * (1u << 16);        // incompressible input: room for the worst case, once

@@ -74,6 +74,24 @@ class Oracle:
             raise RuntimeError(f"orc_compress_block rc={rc}")
         return bytes(out[: osz.value]), list(raw), list(comp)
 
+    def compress_blocks_state(self, cfg: Config, chunks, fields_cap: int = 0):
+        """Blocks of consecutive chunks from ONE BlockCompressor (`dsrc c -t1`): the capacity of TagStats::fields is
+        carried from chunk to chunk.  Returns [(block, raw, comp)] and leaves the final capacity in self.last_fields_cap."""
+        c = _orc_cfg(cfg)
+        cap_state = C.c_uint32(fields_cap)
+        res = []
+        for data in chunks:
+            cap = len(data) + (1 << 16)
+            out = (C.c_uint8 * cap)(); osz = C.c_uint64(0)
+            raw = (C.c_uint64 * 4)(); comp = (C.c_uint64 * 4)()
+            rc = self.lib.orc_compress_block_state(C.byref(c), C.byref(cap_state), data, C.c_uint64(len(data)), out,
+                                                   C.c_uint64(cap), C.byref(osz), raw, comp)
+            if rc != 0:
+                raise RuntimeError(f"orc_compress_block_state rc={rc}")
+            res.append((bytes(out[: osz.value]), list(raw), list(comp)))
+        self.last_fields_cap = cap_state.value
+        return res
+
     def compress_records_block(self, cfg: Config, data: bytes, chunk_size: int, fields_cap: int = 0):
         """BlockCompressorExt::Flush for a chunk given as text; returns (block, new fields_cap)."""
         c = _orc_cfg(cfg)

@@ -135,6 +135,31 @@ def test_chain_hands_state_between_handles(emu, oracle):
     assert alone != want[2]
 
 
+def test_chain_survives_a_capacity_retry(emu, oracle):
+    """A batch that comes back with DSRCGPU_E_CAPACITY has already taken its turn in the chain; announcing the same
+    batch again and retrying with a larger buffer must neither wait for that turn a second time (it deadlocked) nor
+    pick up state that later batches have published since."""
+    import threading
+    chunks = [synth.illumina_fastq(40, first=1 + 40 * k)[:-1] for k in range(3)]
+    cfg = Config.from_levels(0, 0)
+    hs = emu.Handle(cfg.dna_order, cfg.quality_order)
+    want = [r[0] for r in hs.compress_batch(chunks)]; hs.close()
+    chain = emu.Chain()
+    ha = emu.Handle(cfg.dna_order, cfg.quality_order); hb = emu.Handle(cfg.dna_order, cfg.quality_order)
+    ha.set_chain(chain, 0)
+    with pytest.raises(emu.DsrcGpuError) as ei:
+        ha.compress_batch(chunks[:2], cap=64)
+    assert ei.value.code == -4
+    hb.set_chain(chain, 1); got_b = [r[0] for r in hb.compress_batch(chunks[2:])]      # the chain has moved on meanwhile
+    res = []
+    def retry():
+        ha.set_chain(chain, 0); res.append([r[0] for r in ha.compress_batch(chunks[:2])])
+    t = threading.Thread(target=retry, daemon=True); t.start(); t.join(60)
+    assert not t.is_alive(), "the retry waits for a chain turn it has already taken"
+    assert res[0] + got_b == want
+    ha.close(); hb.close(); chain.close()
+
+
 def test_hot_contexts_rescale(emu, oracle):
     """One context with ~40k symbols: exercises the epoch/rescale path of k_replay and multi-wave ranges."""
     import random

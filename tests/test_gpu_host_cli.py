@@ -101,3 +101,23 @@ def test_field_filter_archive_identical(files, fields):
     _run([CLI, "c", "-d2", "-q1", "-c", fields, "-b1", "-n3", "-t3", ill, ours])
     _run([REF_BIN, "c", "-d2", "-q1", "-c", fields, "-b1", "-t1", ill, theirs])
     assert md5(ours) == md5(theirs)
+
+
+def test_config1_full_size_archive_md5(tmp_path):
+    """BASELINE configs 1/2 at their full size (1 M reads, 375 MB, 45 blocks of 8 MiB): the dsrc-amd CLI must write the
+    archive the unmodified reference wrote (`dsrc c -t1`; md5 committed in tests/golden/config_golden.json by
+    tests/golden/make_config_golden.py), at -d0 -q0 and at -d3 -q2 with and without -c."""
+    import json
+    if not os.path.exists(CLI):
+        pytest.skip("dsrc-amd not built")
+    G = json.load(open(os.path.join(ROOT, "tests", "golden", "config_golden.json")))
+    src = tmp_path / "ill1m.fastq"
+    h = hashlib.md5()
+    with open(src, "wb") as f:
+        for lo in range(1, 1000001, 50000):
+            b = synth.illumina_fastq(50000, first=lo); f.write(b); h.update(b)
+    assert (os.path.getsize(src), h.hexdigest()) == (G["input"]["size"], G["input"]["md5"])
+    for key in ("d0q0", "d3q2", "d3q2c"):
+        dst = tmp_path / (key + ".dsrc")
+        _run([CLI, "c", *G[key]["flags"], str(src), str(dst)])
+        assert (os.path.getsize(dst), md5(dst)) == (G[key]["size"], G[key]["md5"]), key

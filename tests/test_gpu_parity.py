@@ -25,12 +25,11 @@ def _check(gpu, oracle, cfg, chunks):
     h = gpu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
     got = h.compress_batch(chunks)
     h.close()
-    cap = 0
-    for i, c in enumerate(chunks):
-        want = oracle.compress_block(cfg, c) if i == 0 else None
-        if i == 0:
-            assert got[0][0] == want[0], "block bytes differ"
-            assert got[0][1] == want[1] and got[0][2] == want[2], "stream sizes differ"
+    want = oracle.compress_blocks_state(cfg, chunks)          # EVERY chunk, compressor state carried like `dsrc c -t1`
+    assert len(got) == len(want)
+    for i in range(len(chunks)):
+        assert got[i][0] == want[i][0], f"chunk {i}: block bytes differ"
+        assert got[i][1] == want[i][1] and got[i][2] == want[i][2], f"chunk {i}: stream sizes differ"
     return got
 
 
@@ -155,6 +154,50 @@ def test_concurrent_scheduler_instances(gpu, oracle):
     assert not errs, errs
     for t in range(3):
         assert [g[0] for g in got[t]] == [w[0] for w in want[t]]
+
+
+def test_queue_form(gpu, oracle):
+    """dsrcgpu_submit / flush / collect -- the form INTEGRATION.md section 1 binds in place of DsrcCompressor::Process
+    (reference src/DsrcWorker.cpp:39-70) -- on the real device: part ids come back with their blocks, blocks equal the
+    oracle's with the state carried in submission order, over several flushes of one handle."""
+    chunks = [synth.illumina_fastq(2500, first=1 + 2500 * k)[:-1] for k in range(6)] + [synth.iontorrent_fastq(600)[:-1]]
+    for d, q, lossy in ((0, 0, False), (0, 2, False), (2, 1, True)):
+        cfg = Config.from_levels(d, q, lossy)
+        want = oracle.compress_blocks_state(cfg, chunks)
+        h = gpu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
+        got = []
+        for lo, hi in ((0, 3), (3, 4), (4, 7)):
+            for i in range(lo, hi):
+                h.submit(1000 + i, chunks[i])
+            h.flush()
+            while True:
+                r = h.collect()
+                if r is None:
+                    break
+                got.append(r)
+        assert h.collect() is None
+        h.close()
+        assert [g[0] for g in got] == [1000 + i for i in range(len(chunks))]
+        for i, g in enumerate(got):
+            assert (g[1], g[2], g[3]) == want[i], f"part {i} at -d{d} -q{q}"
+
+
+def test_full_size_iontorrent_lossy(gpu, oracle):
+    """BASELINE config 5 at block size: variable-length reads with IUPAC codes, -d2 -q1 -l, twelve 8 MiB chunks cut like
+    the reference's reader cuts them (FLAG_VARIABLE_LENGTH, per-record length bits in the tag stream, the qp_stream
+    position contexts of k_sort).  Every block against the oracle, sampled blocks through the (reference-pinned) oracle decoder."""
+    data = synth.iontorrent_fastq(178000)
+    cuts = oracle.cut_chunks(data, 8 << 20)
+    assert len(cuts) >= 12
+    chunks = [data[s: s + n] for s, n in cuts[:12]]
+    cfg = Config.from_levels(2, 1, True)
+    got = _check(gpu, oracle, cfg, chunks)
+    for i in (0, 11):
+        blk = got[i][0]
+        assert blk[8:12] == b"\x00\x00\x00\x02"                      # FLAG_VARIABLE_LENGTH
+        text = oracle.decompress_block(cfg, blk, len(chunks[i]) + 64)      # pinned against the reference's Read
+        lines = text.split(b"\n"); src = chunks[i].split(b"\n")
+        assert lines[0::4][:-1] == src[0::4] and [len(x) for x in lines[1::4]] == [len(x) for x in src[1::4]]
 
 
 def test_exact_division_selftest(gpu):
