@@ -20,12 +20,14 @@ EXPORTS = [
     "dsrcgpu_last_timing", "dsrcgpu_synth_illumina", "dsrcgpu_dev_alloc", "dsrcgpu_dev_free", "dsrcgpu_dev_upload",
     "dsrcgpu_dev_download", "dsrcgpu_chain_create", "dsrcgpu_chain_destroy", "dsrcgpu_set_chain", "dsrcgpu_host_alloc",
     "dsrcgpu_host_free", "dsrcgpu_selftest", "dsrcgpu_set_record_layout",
+    "dsrcgpu_decompress_block", "dsrcgpu_decompress_batch", "dsrcgpu_decompress_batch_device",
 ]
 
 
 class Settings(C.Structure):
     _fields_ = [("dna_order", C.c_uint32), ("quality_order", C.c_uint32), ("tag_preserve_flags", C.c_uint64),
-                ("lossy", C.c_uint8), ("calculate_crc32", C.c_uint8), ("reserved", C.c_uint8 * 6)]
+                ("lossy", C.c_uint8), ("calculate_crc32", C.c_uint8), ("verify_after_compress", C.c_uint8),
+                ("reserved", C.c_uint8 * 5)]
 
 
 class Dataset(C.Structure):
@@ -87,10 +89,10 @@ class Handle:
     """One GPU block scheduler (replaces the reference's pool of BlockCompressor worker threads)."""
 
     def __init__(self, dna_order=0, quality_order=0, lossy=False, crc=False, quality_offset=33,
-                 plus_repetition=False, color_space=False, tag_flags=0, device=0, arena_bytes=0):
+                 plus_repetition=False, color_space=False, tag_flags=0, device=0, arena_bytes=0, verify=False):
         self.L = load()
         self.h = C.c_void_p()
-        s = Settings(dna_order, quality_order, tag_flags, int(lossy), int(crc))
+        s = Settings(dna_order, quality_order, tag_flags, int(lossy), int(crc), int(verify))
         d = Dataset(quality_offset, int(plus_repetition), int(color_space))
         rc = self.L.dsrcgpu_create(C.byref(s), C.byref(d), device, C.c_uint64(arena_bytes), C.byref(self.h))
         if rc != 0:
@@ -146,6 +148,30 @@ class Handle:
         self._chk(self.L.dsrcgpu_compress_batch(self.h, n, ptrs, sizes, out, C.c_uint64(cap), offs, osz, raw, comp))
         mv = memoryview(out)
         return [(bytes(mv[offs[i]: offs[i] + osz[i]]), list(raw[4 * i: 4 * i + 4]), list(comp[4 * i: 4 * i + 4])) for i in range(n)]
+
+    def decompress_batch(self, blocks, cap=None, text_caps=None, verify=False):
+        """BlockCompressor::Read for a batch of blocks -> list of chunk texts (each ends with a newline);
+        with verify=True also the per-block VerifyChecksum verdicts."""
+        n = len(blocks)
+        ptrs = (C.c_char_p * n)(*blocks)
+        sizes = (C.c_uint64 * n)(*[len(b) for b in blocks])
+        if cap is None:
+            cap = sum(text_caps) if text_caps else sum(int.from_bytes(b[12:16], "big") + 1 for b in blocks)
+        out = (C.c_uint8 * max(cap, 1))()
+        offs = (C.c_uint64 * n)(); osz = (C.c_uint64 * n)(); ok = (C.c_uint32 * n)()
+        caps = (C.c_uint64 * n)(*text_caps) if text_caps else None
+        self._chk(self.L.dsrcgpu_decompress_batch(self.h, n, ptrs, sizes, caps, out, C.c_uint64(cap), offs, osz, ok if verify else None))
+        mv = memoryview(out)
+        texts = [bytes(mv[offs[i]: offs[i] + osz[i]]) for i in range(n)]
+        return (texts, list(ok)) if verify else texts
+
+    def decompress_batch_device(self, d_in: int, offs, sizes, d_out: int, out_cap: int, verify=False):
+        n = len(offs)
+        a_offs = (C.c_uint64 * n)(*offs); a_sizes = (C.c_uint64 * n)(*sizes)
+        o_offs = (C.c_uint64 * n)(); o_sizes = (C.c_uint64 * n)(); ok = (C.c_uint32 * n)()
+        self._chk(self.L.dsrcgpu_decompress_batch_device(self.h, n, C.c_void_p(d_in), a_offs, a_sizes, None, C.c_void_p(d_out),
+                                                         C.c_uint64(out_cap), o_offs, o_sizes, ok if verify else None))
+        return (list(o_offs), list(o_sizes), list(ok)) if verify else (list(o_offs), list(o_sizes))
 
     def compress_batch_device(self, d_in: int, offs, sizes, d_out: int, out_cap: int):
         n = len(offs)

@@ -29,6 +29,7 @@
 #include "k_tags.h"
 #include "k_block.h"
 #include "k_synth.h"
+#include "k_dec.h"
 
 namespace
 {
@@ -78,6 +79,7 @@ struct dsrcgpu_handle
 	bool chain_batch_done = true;    // the batch announced by dsrcgpu_set_chain has run to completion
 	u32* d_crc_tab = nullptr;
 	std::string err;
+	u8* last_d_out = nullptr;        // device address of the blocks the last run_batch assembled (valid until the arena is reused)
 	std::vector<Pending> pending;
 	std::deque<Done> done;
 	float batch_ms = 0.f, rc_ms = 0.f;
@@ -127,6 +129,7 @@ size_t estimate_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
 	const size_t sort_slice = std::min(tot * 14, ((size_t)7168 << 20) + mx * 16);       // see slice_lo in run_batch
 	return tot * 13 + (rc ? sort_slice : 0) + (size_t)n * (1u << 20) + (16u << 20);      // measured: 12.7 x input + slice at -d3 -q2
 }
+size_t estimate_decode_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes);
 
 struct BatchIO
 {
@@ -692,6 +695,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		if (total > io.host_cap) return fail(h, DSRCGPU_E_CAPACITY, "output needs %llu bytes, caller gave %llu", (unsigned long long)total, (unsigned long long)io.host_cap);
 	}
 	else if (total > io.out_cap) return fail(h, DSRCGPU_E_CAPACITY, "output needs %llu bytes, caller gave %llu", (unsigned long long)total, (unsigned long long)io.out_cap);
+	h->last_d_out = d_out;
 	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(BlkDesc) * B, hipMemcpyHostToDevice, s));
 	hipLaunchKernelGGL(k_assemble, dim3(16, B), dim3(WG), 0, s, d_desc, d_state, wpool, d_out, prm); KCHK();
 	HIPCHK(hipEventRecord(h->ev[1], s));
@@ -739,6 +743,163 @@ template <typename F> int with_arena_retry_(dsrcgpu_handle* h, size_t initial, F
 		h->fields_cap = saved_cap;
 	}
 	return fail(h, DSRCGPU_E_NOMEM, "batch does not fit in HBM scratch after 8 attempts");
+}
+
+// ---- decompression ------------------------------------------------------------------------------------------------
+struct DecodeIO
+{
+	const u8* d_in; const u64* offs; const u64* sizes; u32 n;
+	const u64* text_caps;            // optional: text bytes to reserve per block (blocks written by the record-level API declare a running total)
+	u8* d_out; u64 out_cap;          // device output (nullptr => arena-allocated, copied to host_out)
+	u8* host_out; u64 host_cap;
+	u64* out_offs; u64* out_sizes;
+	u32* crc_ok;                     // optional, per block: 1 = the stored checksums match the decoded records
+};
+
+// u32 words of the largest model table the settings can ask for
+u64 dec_table_words(const dsrcgpu_settings& set)
+{
+	u64 q = 0, d = 0;
+	const u32 qo = set.quality_order, dn = set.dna_order;
+	if (qo > 0 && set.lossy) q = (1ull << (3 * (qo + 1))) * 4;
+	else if (qo == 1) q = 1ull << 20;                        // <128,1>: 128^2 rows x 128 counters
+	else if (qo == 2) q = 1ull << 24;                        // <32,3>: 32^4 rows x 32 counters = 64 MiB
+	if (dn > 0) d = std::max((1ull << (2 * dn)) * 2, (1ull << (3 * std::min(dn, 7u))) * 4);
+	return std::max<u64>(std::max(q, d), 16);
+}
+
+int run_decode(dsrcgpu_handle* h, DecodeIO io)
+{
+	const u32 B = io.n;
+	if (B == 0) return DSRCGPU_OK;
+	hipStream_t s = h->stream;
+	Arena& A = h->arena;
+	DecParams prm; memset(&prm, 0, sizeof(prm));
+	prm.dna_order = h->set.dna_order; prm.quality_order = h->set.quality_order; prm.lossy = h->set.lossy ? 1u : 0u;
+	prm.crc = h->set.calculate_crc32 ? 1u : 0u; prm.quality_offset = h->ds.quality_offset; prm.n_blocks = B;
+	prm.tag_flags = (u32)h->set.tag_preserve_flags; prm.plus_rep = h->ds.plus_repetition ? 1u : 0u; prm.color_space = h->ds.color_space ? 1u : 0u;
+
+	std::vector<DecDesc> desc(B); std::vector<DecState> st(B);
+	memset(desc.data(), 0, sizeof(DecDesc) * B);
+	for (u32 b = 0; b < B; ++b)
+	{
+		if (io.sizes[b] < 16 || io.sizes[b] >= (1ull << 31)) return fail(h, DSRCGPU_E_ARG, "block %u: size %llu out of range", b, (unsigned long long)io.sizes[b]);
+		desc[b].in_off = io.offs[b]; desc[b].in_size = (u32)io.sizes[b];
+	}
+	const size_t o_desc = A.alloc(sizeof(DecDesc) * B), o_state = A.alloc(sizeof(DecState) * B);
+	if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (decode, phase 1)");
+	DecDesc* d_desc = AP<DecDesc>(h, o_desc); DecState* d_state = AP<DecState>(h, o_state);
+	HIPCHK(hipEventRecord(h->ev[0], s));
+	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(DecDesc) * B, hipMemcpyHostToDevice, s));
+	hipLaunchKernelGGL(k_dec_meta, dim3((B + 63) / 64), dim3(64), 0, s, io.d_in, d_desc, d_state, prm); KCHK();
+	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(DecState) * B, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+
+	// ---- layout: text, record tables, symbol scratch, tree pools, model-table slots ---------------------------------
+	u64 text_total = 0, recs = 0, dbytes = 0, nodes = 0, fbytes = 0; u32 max_recs = 1;
+	for (u32 b = 0; b < B; ++b)
+	{
+		const DecState& S = st[b]; DecDesc& D = desc[b];
+		if (S.err) return fail(h, DSRCGPU_E_INPUT, "block %u cannot be decoded (error bits 0x%x: 1 truncated, 2 malformed, 8 undefined in the reference's decoder)", b, S.err);
+		const u64 cap = io.text_caps ? io.text_caps[b] : (u64)S.chunk_size + 1;
+		if (cap >= (1ull << 31)) return fail(h, DSRCGPU_E_ARG, "block %u declares a chunk of %llu bytes", b, (unsigned long long)cap);
+		D.out_off = text_total; D.out_cap = (u32)cap; text_total += cap;
+		D.rec_base = (u32)recs; D.rec_cap = S.n_recs; recs += (u64)S.n_recs + 1; max_recs = std::max(max_recs, S.n_recs);
+		D.d_base = dbytes; dbytes += al(cap / 2 + 64, 64);
+		D.node_cap = S.tag_nodes + 160 + 2 * DEC_STACK_SLACK; D.node_off = nodes; nodes += D.node_cap;
+		// trees of the quality stream: one per position (Plain/Truncated) or 2 x alphabet (RLE); the DNA tree reuses the pool
+		const u64 qn = std::min<u64>(std::max<u64>(((u64)S.max_qlen + 2) * 255, prm.quality_order == 0 ? 2ull * 256 * 256 : 64), (u64)D.in_size * 3) + 1024 + 2 * DEC_STACK_SLACK;
+		D.qnode_cap = (u32)qn; D.qnode_off = nodes; nodes += qn;
+		D.fld_off = fbytes; fbytes += al(sizeof(DecField) * std::max(1u, S.n_fields), 16);
+		if (recs >= (1ull << 32)) return fail(h, DSRCGPU_E_ARG, "batch too large for 32-bit record indices; submit fewer blocks per batch");
+	}
+	RecPools rp;
+	rp.title_off = AP<u32>(h, A.alloc(recs * 4)); rp.seq_off = AP<u32>(h, A.alloc(recs * 4)); rp.qual_off = AP<u32>(h, A.alloc(recs * 4));
+	rp.title_len = AP<u16>(h, A.alloc(recs * 2)); rp.len = AP<u16>(h, A.alloc(recs * 2));
+	rp.kept = AP<u16>(h, A.alloc(recs * 2)); rp.trunc = nullptr;
+	rp.q_off = nullptr; rp.d_off = AP<u32>(h, A.alloc(recs * 4));
+	const size_t o_d = A.alloc(dbytes + 64), o_nodes = A.alloc(nodes * 4 + 64), o_fld = A.alloc(fbytes + 64);
+	prm.table_words = (u32)dec_table_words(h->set);
+	u32 slots;
+	{
+		const char* env = getenv("DSRC_GPU_DEC_TABLE_MB");
+		const u64 budget = (env ? (u64)atol(env) : (u64)32768) << 20;
+		slots = (u32)std::max<u64>(1, std::min<u64>(B, budget / ((u64)prm.table_words * 4)));
+	}
+	const size_t o_tab = A.alloc((size_t)slots * prm.table_words * 4 + 64);
+	u8* d_out = io.d_out;
+	size_t o_out = 0;
+	if (!d_out) o_out = A.alloc(text_total + 64);
+	if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (decode): batch needs > %zu bytes of HBM scratch", A.top);
+	if (!d_out)
+	{
+		d_out = AP<u8>(h, o_out);
+		if (io.host_out && text_total > io.host_cap) return fail(h, DSRCGPU_E_CAPACITY, "output needs %llu bytes, caller gave %llu", (unsigned long long)text_total, (unsigned long long)io.host_cap);
+	}
+	else if (text_total > io.out_cap) return fail(h, DSRCGPU_E_CAPACITY, "output needs %llu bytes, caller gave %llu", (unsigned long long)text_total, (unsigned long long)io.out_cap);
+
+	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(DecDesc) * B, hipMemcpyHostToDevice, s));
+	hipLaunchKernelGGL(k_dec_tags, dim3(B), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), AP<u8>(h, o_fld), prm); KCHK();
+	hipLaunchKernelGGL(k_dec_streams, dim3(slots), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), AP<u8>(h, o_d), AP<u32>(h, o_tab), prm); KCHK();
+	{
+		const u32 gx = std::max(1u, std::min(64u, (max_recs + 4 * WAVES - 1) / (4 * WAVES)));
+		hipLaunchKernelGGL(k_dec_layout, dim3(gx, B), dim3(WG), 0, s, d_desc, d_state, rp, d_out, AP<u8>(h, o_d), prm); KCHK();
+	}
+	if (prm.crc && io.crc_ok) { hipLaunchKernelGGL(k_dec_crc, dim3(B, 3), dim3(WG), 0, s, d_desc, d_state, rp, d_out, h->d_crc_tab, prm); KCHK(); }
+	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(DecState) * B, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipEventRecord(h->ev[1], s));
+	if (io.host_out) HIPCHK(hipMemcpyAsync(io.host_out, d_out, text_total, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	for (u32 b = 0; b < B; ++b)
+	{
+		const DecState& S = st[b];
+		if (S.err == DEC_ERR_TEXT) return fail(h, DSRCGPU_E_CAPACITY, "block %u: the decoded text does not fit the %u bytes reserved for it", b, desc[b].out_cap);
+		if (S.err) return fail(h, DSRCGPU_E_INPUT, "block %u cannot be decoded (error bits 0x%x: 1 truncated, 2 malformed, 4 text overflow, 8 undefined in the reference's decoder, 16 scratch)", b, S.err);
+		if (S.end_pos != desc[b].in_size) return fail(h, DSRCGPU_E_INPUT, "block %u: %u of %u bytes consumed (wrong settings for this archive?)", b, S.end_pos, desc[b].in_size);
+		io.out_offs[b] = desc[b].out_off; io.out_sizes[b] = S.text_bytes;
+		if (io.crc_ok)
+		{
+			bool ok = true;
+			if (prm.crc)
+			{
+				if (!prm.tag_flags) ok &= S.crc_stored[0] == S.crc_actual[0];
+				ok &= S.crc_stored[1] == S.crc_actual[1];
+				if (!prm.lossy) ok &= S.crc_stored[2] == S.crc_actual[2];
+			}
+			io.crc_ok[b] = ok ? 1u : 0u;
+		}
+	}
+	hipEventElapsedTime(&h->batch_ms, h->ev[0], h->ev[1]);
+	h->rc_ms = 0.f; h->rc_launches = 0;
+	return DSRCGPU_OK;
+}
+
+size_t estimate_decode_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
+{
+	size_t tot = 0;
+	for (u32 i = 0; i < n; ++i) tot += (size_t)sizes[i] + 4096;
+	const u64 budget = (u64)32768 << 20;
+	const u64 tw = dec_table_words(h->set) * 4;
+	return tot * 12 + (size_t)std::min<u64>(budget, tw * n) + (size_t)n * (2u << 20) + (16u << 20);
+}
+
+// The reference's compressing worker decodes every block it has just written and compares the checksums
+// (DsrcCompressor::Process, src/DsrcWorker.cpp:53-62).  Here: the blocks still sit in HBM; they are decoded there and only
+// the verdicts come back.
+int verify_blocks(dsrcgpu_handle* h, u32 n, const u64* offs, const u64* sizes)
+{
+	std::vector<u64> to(n), ts(n); std::vector<u32> ok(n, 0);
+	DecodeIO io{h->last_d_out, offs, sizes, n, nullptr, nullptr, 0, nullptr, 0, to.data(), ts.data(), ok.data()};
+	const int rc = run_decode(h, io);
+	if (rc != DSRCGPU_OK)
+	{
+		if (rc == DSRCGPU_E_NOMEM) return rc;                 // the batch is re-run with a larger arena
+		const std::string why = h->err;
+		return fail(h, DSRCGPU_E_CRC, "CRC32 checksums mismatch. (%s)", why.c_str());
+	}
+	for (u32 i = 0; i < n; ++i)
+		if (!ok[i]) return fail(h, DSRCGPU_E_CRC, "CRC32 checksums mismatch.");
+	return DSRCGPU_OK;
 }
 
 int check_settings(dsrcgpu_handle* h, const dsrcgpu_settings* s, const dsrcgpu_dataset* d)
@@ -840,7 +1001,9 @@ int dsrcgpu_compress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_f
 	HIPCHK(hipSetDevice(h->device));
 	return with_arena_retry(h, estimate_arena(h, n, sizes), [&]() {
 		BatchIO io{(const u8*)d_fastq, offs, sizes, n, (u8*)d_blocks, blocks_cap, nullptr, 0, block_offs, block_sizes, raw_sizes, comp_sizes};
-		return run_batch(h, io);
+		const int rc = run_batch(h, io);
+		if (rc != DSRCGPU_OK || !h->set.verify_after_compress || !h->set.calculate_crc32) return rc;
+		return verify_blocks(h, n, block_offs, block_sizes);
 	});
 }
 
@@ -861,8 +1024,51 @@ int dsrcgpu_compress_batch(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* 
 		u8* d_in = h->arena.base + o_in;
 		for (u32 i = 0; i < n; ++i) HIPCHK(hipMemcpyAsync(d_in + offs[i], fastq[i], sizes[i], hipMemcpyHostToDevice, h->stream));
 		BatchIO io{d_in, offs.data(), sizes, n, nullptr, 0, blocks, blocks_cap, block_offs, block_sizes, raw_sizes, comp_sizes};
-		return run_batch(h, io);
+		const int rc = run_batch(h, io);
+		if (rc != DSRCGPU_OK || !h->set.verify_after_compress || !h->set.calculate_crc32) return rc;
+		return verify_blocks(h, n, block_offs, block_sizes);
 	});
+}
+
+int dsrcgpu_decompress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_blocks, const uint64_t* offs, const uint64_t* sizes,
+									const uint64_t* text_caps, void* d_text, uint64_t text_cap, uint64_t* text_offs, uint64_t* text_sizes, uint32_t* crc_ok)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	if (!d_blocks || !offs || !sizes || !d_text || !text_offs || !text_sizes) return fail(h, DSRCGPU_E_ARG, "null argument");
+	HIPCHK(hipSetDevice(h->device));
+	return with_arena_retry_(h, estimate_decode_arena(h, n, sizes), [&]() {
+		DecodeIO io{(const u8*)d_blocks, offs, sizes, n, text_caps, (u8*)d_text, text_cap, nullptr, 0, text_offs, text_sizes, crc_ok};
+		return run_decode(h, io);
+	});
+}
+
+int dsrcgpu_decompress_batch(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* blocks, const uint64_t* sizes, const uint64_t* text_caps,
+							 uint8_t* text, uint64_t text_cap, uint64_t* text_offs, uint64_t* text_sizes, uint32_t* crc_ok)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	if (!blocks || !sizes || !text || !text_offs || !text_sizes) return fail(h, DSRCGPU_E_ARG, "null argument");
+	if (n == 0) return DSRCGPU_OK;
+	HIPCHK(hipSetDevice(h->device));
+	std::vector<u64> offs(n);
+	size_t in_bytes = 0;
+	for (u32 i = 0; i < n; ++i) { offs[i] = in_bytes; in_bytes += al((size_t)sizes[i] + 16, 64); }
+	return with_arena_retry_(h, estimate_decode_arena(h, n, sizes) + in_bytes, [&]() {
+		const size_t o_in = h->arena.alloc(in_bytes + 256);
+		if (h->arena.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (input)");
+		u8* d_in = h->arena.base + o_in;
+		for (u32 i = 0; i < n; ++i) HIPCHK(hipMemcpyAsync(d_in + offs[i], blocks[i], sizes[i], hipMemcpyHostToDevice, h->stream));
+		DecodeIO io{d_in, offs.data(), sizes, n, text_caps, nullptr, 0, text, text_cap, text_offs, text_sizes, crc_ok};
+		return run_decode(h, io);
+	});
+}
+
+int dsrcgpu_decompress_block(dsrcgpu_handle* h, const uint8_t* block, uint64_t size, uint8_t* text, uint64_t text_cap, uint64_t* text_size, uint32_t* crc_ok)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	if (!text_size) return fail(h, DSRCGPU_E_ARG, "null argument");
+	u64 off = 0;
+	const uint8_t* ins[1] = {block};
+	return dsrcgpu_decompress_batch(h, 1, ins, &size, nullptr, text, text_cap, &off, text_size, crc_ok);
 }
 
 int dsrcgpu_set_record_layout(dsrcgpu_handle* h, uint32_t n, const uint32_t* chunk_sizes)

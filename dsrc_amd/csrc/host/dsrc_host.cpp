@@ -69,6 +69,7 @@ bool FastqChunker::ReadNextChunk(std::vector<uchar>& chunk)
 	if (r == toRead)
 	{
 		const uint64 end = NextRecordPos(chunk.data(), bufSize - 8192, bufSize, usesCrlf);
+		if (end > bufSize) throw DsrcException("no record boundary in the last 8 KiB of the FASTQ buffer (a record longer than 8 KiB is undefined in the reference's reader, src/FastqStream.cpp:74-98); use a larger -b");
 		carry.assign(chunk.begin() + end, chunk.end());
 		chunk.resize(end - 1 - (usesCrlf ? 1 : 0));
 		return true;
@@ -139,13 +140,25 @@ void ArchiveWriter::Start(const std::string& path)
 {
 	f = fopen(path.c_str(), "wb");
 	if (!f) throw DsrcException("Cannot open file to write:" + path);
+	name = path;
 	uchar zero[40]; memset(zero, 0, sizeof(zero));
-	fwrite(zero, 1, 40, f);                          // header is written last (src/DsrcFile.cpp:52-54)
+	Put(zero, 40);                                   // header is written last (src/DsrcFile.cpp:52-54)
+}
+
+void ArchiveWriter::Put(const void* p, uint64 n)
+{
+	if (n && fwrite(p, 1, n, f) != n) throw DsrcException("Error writing the archive (disk full?): " + name);
+}
+
+void ArchiveWriter::Abandon()
+{
+	if (f) { fclose(f); f = nullptr; }
+	if (!name.empty()) { unlink(name.c_str()); name.clear(); }
 }
 
 void ArchiveWriter::WriteBlock(const uchar* data, uint64 size, const uint64 raw[4], const uint64 comp[4])
 {
-	fwrite(data, 1, size, f);
+	Put(data, size);
 	blockSizes.push_back((uint32)size);
 	for (int i = 0; i < 4; ++i) { rawInfo.sizes[i] += raw[i]; compInfo.sizes[i] += comp[i]; }
 }
@@ -162,17 +175,19 @@ void ArchiveWriter::Finish(const fq::FastqDatasetType& type, const CompressionSe
 	foot.push_back((uchar)((s.lossy ? 1 : 0) | (s.calculateCrc32 ? 2 : 0)));
 	foot.push_back((uchar)s.dnaOrder); foot.push_back((uchar)s.qualityOrder);
 	PutBE(foot, s.tagPreserveFlags, 8);
-	fwrite(foot.data(), 1, foot.size(), f);
+	Put(foot.data(), foot.size());
 	std::vector<uchar> head;
 	head.push_back(0xAA); head.push_back(2); head.push_back(0); head.push_back(2);
 	PutBE(head, foot.size(), 4); PutBE(head, footerOffset, 8); PutBE(head, 0, 8); PutBE(head, blockSizes.size(), 8);
 	for (int i = 0; i < 8; ++i) head.push_back(0xAA);
-	fseeko(f, 0, SEEK_SET);
-	fwrite(head.data(), 1, head.size(), f);
-	fclose(f); f = nullptr;
+	if (fseeko(f, 0, SEEK_SET) != 0) throw DsrcException("Error writing the archive: " + name);
+	Put(head.data(), head.size());
+	FILE* g = f; f = nullptr;
+	if (fclose(g) != 0) throw DsrcException("Error writing the archive (disk full?): " + name);
+	name.clear();
 }
 
-ArchiveWriter::~ArchiveWriter() { if (f) fclose(f); }
+ArchiveWriter::~ArchiveWriter() { if (f) Abandon(); }           // an archive that was not finished is not left behind
 
 // ---- operator -----------------------------------------------------------------------------------------------
 // File -> archive as a pipeline: the calling thread cuts chunk boundaries (two 8 KiB reads per chunk),
@@ -215,6 +230,7 @@ struct Pipeline
 	std::map<uint64, Job*> ready; uint64 nextStart = 0;  // read into page-locked memory, waiting for a scheduler instance (taken in order)
 	std::vector<Pinned*> freeIn;                         // input buffers not in use
 	std::map<uint64, Job*> done;
+	bool writerDone = false;                             // the writer thread no longer touches any output buffer
 	std::string error;
 	bool Failed() { std::lock_guard<std::mutex> g(m); return !error.empty(); }
 	void Fail(const std::string& e) { std::lock_guard<std::mutex> g(m); if (error.empty()) error = e; cv.notify_all(); }
@@ -234,7 +250,10 @@ struct FileCutter
 		if (rem >= bufSize)
 		{
 			if (pread(fd, win.data(), 8192, (off_t)(pos + bufSize - 8192)) != 8192) throw DsrcException("read error");
-			const uint64 end = FastqChunker::NextRecordPos(win.data() - (bufSize - 8192), bufSize - 8192, bufSize, crlf);
+			// the window is the last 8 KiB of the buffer: positions are relative to it
+			const uint64 wend = FastqChunker::NextRecordPos(win.data(), 0, 8192, crlf);
+			if (wend > 8192) throw DsrcException("no record boundary in the last 8 KiB of the FASTQ buffer (a record longer than 8 KiB is undefined in the reference's reader, src/FastqStream.cpp:74-98); use a larger -b");
+			const uint64 end = bufSize - 8192 + wend;
 			size = end - 1 - (crlf ? 1 : 0);
 			bufEnd = pos + bufSize; pos += end; first = false;
 			return true;
@@ -295,11 +314,13 @@ bool DsrcCompressorGPU::ProcessStream(const InputParameters& args, FILE* in)
 	return !IsError();
 }
 
+
 dsrcgpu_handle* DsrcCompressorGPU::CreateInstance(const InputParameters& args, const CompressionSettings& settings, const fq::FastqDatasetType& type)
 {
 	dsrcgpu_settings gs; memset(&gs, 0, sizeof(gs));
 	gs.dna_order = settings.dnaOrder; gs.quality_order = settings.qualityOrder; gs.tag_preserve_flags = settings.tagPreserveFlags;
 	gs.lossy = settings.lossy; gs.calculate_crc32 = settings.calculateCrc32;
+	gs.verify_after_compress = settings.calculateCrc32 && args.verifyCrc32;     // what the reference's worker does with -c (src/DsrcWorker.cpp:53-62)
 	dsrcgpu_dataset gd; memset(&gd, 0, sizeof(gd));
 	gd.quality_offset = type.qualityOffset; gd.plus_repetition = type.plusRepetition; gd.color_space = type.colorSpace;
 	dsrcgpu_handle* h = nullptr;
@@ -439,12 +460,14 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 						pl.cv.notify_all();
 					}
 				}
-				// blocks still owned by the writer
-				std::unique_lock<std::mutex> g(pl.m);
-				pl.cv.wait(g, [&] { return !pl.error.empty() || ((!inFlight[0] || !inFlight[0]->out) && (!inFlight[1] || !inFlight[1]->out)); });
 			}
 			catch (const std::exception& e) { pl.Fail(e.what()); }
-			for (Job* j : inFlight) if (j && !j->out) delete j;
+			{	// the writer may still be copying out of out[]: it is done with them when it has released them or has exited
+				std::unique_lock<std::mutex> g(pl.m);
+				pl.cv.wait(g, [&] { return pl.writerDone || ((!inFlight[0] || !inFlight[0]->out) && (!inFlight[1] || !inFlight[1]->out)); });
+				for (Job*& j : inFlight)
+					if (j) { for (auto it = pl.done.begin(); it != pl.done.end();) { if (it->second == j) it = pl.done.erase(it); else ++it; } delete j; j = nullptr; }
+			}
 			if (h) dsrcgpu_destroy(h);
 		};
 		for (uint32 i = 0; i < instances; ++i) workers.emplace_back(work, i);
@@ -515,6 +538,8 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 				}
 			}
 			catch (const std::exception& e) { pl.Fail(e.what()); }
+			std::lock_guard<std::mutex> g(pl.m);
+			pl.writerDone = true; pl.cv.notify_all();
 		});
 
 		// ---- cutter (this thread) -------------------------------------------------------------------------------
@@ -571,6 +596,187 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 	for (auto& kv : pl.ready) delete kv.second;
 	if (chain) dsrcgpu_chain_destroy(chain);
 	if (fd >= 0) close(fd);
+	return !IsError();
+}
+
+
+// ---- archive reader (DsrcFileReader, src/DsrcFile.cpp:172-318) -------------------------------------------------------------
+uint64 GetBE(const uchar* p, int bytes) { uint64 v = 0; for (int i = 0; i < bytes; ++i) v = (v << 8) | p[i]; return v; }
+
+ArchiveReader::~ArchiveReader() { Close(); }
+void ArchiveReader::Close() { if (fd >= 0) { close(fd); fd = -1; } }
+
+void ArchiveReader::Open(const std::string& path)
+{
+	fd = open(path.c_str(), O_RDONLY);
+	struct stat sb;
+	if (fd < 0 || fstat(fd, &sb) != 0) { Close(); throw DsrcException("Cannot open file to read:" + path); }
+	const uint64 fileSize = (uint64)sb.st_size;
+	if (fileSize == 0) { Close(); throw DsrcException("Empty file."); }
+	uchar head[40];
+	if (fileSize < 40 || pread(fd, head, 40, 0) != 40 || !(head[1] == 2 && head[2] == 0))     // VersionMajor.VersionMinor = 2.0 (src/DsrcFile.h:31-33)
+	{ Close(); throw DsrcException("Invalid archive or old unsupported version"); }
+	const uint64 footerSize = GetBE(head + 4, 4), footerOffset = GetBE(head + 8, 8), blockCount = GetBE(head + 24, 8);
+	if (blockCount == 0 || footerOffset + footerSize > fileSize || footerOffset < 40 || footerSize < 1 + 4 * blockCount + 13 || blockCount > fileSize / 4)
+	{ Close(); throw DsrcException("Corrupted DSRC archive header"); }
+	std::vector<uchar> foot(footerSize);
+	if (pread(fd, foot.data(), footerSize, (off_t)footerOffset) != (ssize_t)footerSize || foot[0] != 0xCC)
+	{ Close(); throw DsrcException("Corrupted DSRC archive footer"); }
+	blockSizes.resize(blockCount);
+	memcpy(blockSizes.data(), foot.data() + 1, blockCount * 4);          // host-endian uint32 array, as the reference reads it
+	const uchar* q = foot.data() + 1 + blockCount * 4;
+	type.colorSpace = (q[0] & 2) != 0; type.plusRepetition = (q[0] & 1) != 0; type.qualityOffset = q[1];
+	settings.lossy = (q[2] & 1) != 0; settings.calculateCrc32 = (q[2] & 2) != 0;
+	settings.dnaOrder = q[3]; settings.qualityOrder = q[4]; settings.tagPreserveFlags = GetBE(q + 5, 8);
+	blockOffs.resize(blockCount);
+	uint64 at = 40;
+	for (uint64 i = 0; i < blockCount; ++i) { blockOffs[i] = at; at += blockSizes[i]; }
+	if (at > footerOffset) { Close(); throw DsrcException("Corrupted DSRC archive footer"); }
+}
+
+void ArchiveReader::ReadBlock(uint64 i, uchar* dst) const
+{
+	uint64 got = 0;
+	while (got < blockSizes[i])
+	{
+		const ssize_t r = pread(fd, dst + got, blockSizes[i] - got, (off_t)(blockOffs[i] + got));
+		if (r <= 0) throw DsrcException("read error");
+		got += (uint64)r;
+	}
+}
+
+// Text bytes to reserve for consecutive blocks.  A block written from a FASTQ file declares its own chunk size (+1 for the
+// last newline, src/BlockCompressor.cpp:279-281); one written by the record-level API declares a running total over the
+// archive (BlockCompressor::Reset does not clear it, src/BlockCompressorExt.cpp:126), i.e. its own size is the difference
+// to the block before.  `exact` = false asks for the always-sufficient figure (used when the first try did not fit).
+void TextCaps(const std::vector<uint32>& words, uint32 wordBefore, bool haveBefore, bool exact, std::vector<uint64_t>& caps)
+{
+	caps.resize(words.size());
+	uint32 prev = wordBefore; bool have = haveBefore;
+	for (size_t i = 0; i < words.size(); ++i)
+	{
+		const uint64 own = (uint64)words[i] + 1;
+		const uint64 diff = (uint64)(uint32)(words[i] - prev) + 1;
+		caps[i] = (exact && have && diff > 1 && diff < own) ? diff : own;
+		prev = words[i]; have = true;
+	}
+}
+
+dsrcgpu_handle* CreateDecodeInstance(int device, const CompressionSettings& settings, const fq::FastqDatasetType& type)
+{
+	InputParameters a; a.device = device;
+	return DsrcCompressorGPU::CreateInstance(a, settings, type);
+}
+
+// Archive -> FASTQ.  `instances` workers each own one GPU scheduler instance; a worker takes the next batch of blocks,
+// reads it from the archive into page-locked memory, decompresses it and writes the text when the batches before it have
+// been written (one worker reads while another decodes while a third writes).
+bool DsrcDecompressorGPU::Process(const InputParameters& args)
+{
+	FILE* out = nullptr;
+	ArchiveReader rd;
+	std::vector<std::thread> workers;
+	std::mutex m; std::condition_variable cv;
+	std::string error;
+	try
+	{
+		rd.Open(args.inputFilename);
+		if (args.useFastqStdIo) out = stdout;
+		else { out = fopen(args.outputFilename.c_str(), "wb"); if (!out) throw DsrcException("Cannot open file to write:" + args.outputFilename); }
+
+		const uint64 nBlocks = rd.BlockCount();
+		std::vector<std::pair<uint64, uint64> > batches;
+		{
+			const uint64 budget = 192ull << 20;                 // compressed bytes per scheduler pass (about 0.75 GB of text)
+			uint64 lo = 0, bytes = 0;
+			for (uint64 i = 0; i < nBlocks; ++i)
+			{
+				bytes += rd.BlockSizes()[i];
+				const uint64 cnt = i + 1 - lo;
+				if ((args.batchBlocks && cnt >= args.batchBlocks) || (!args.batchBlocks && bytes >= budget)) { batches.emplace_back(lo, i + 1); lo = i + 1; bytes = 0; }
+			}
+			if (lo < nBlocks) batches.emplace_back(lo, nBlocks);
+		}
+		const uint32 instances = (uint32)std::max<uint64>(1, std::min<uint64>(std::min<uint32>(std::max(1u, args.threadNum), 8u), batches.size()));
+		uint64 next = 0, writeTurn = 0;
+
+		auto work = [&]()
+		{
+			dsrcgpu_handle* h = nullptr;
+			try
+			{
+				h = CreateDecodeInstance(args.device, rd.Settings(), rd.Type());
+				Pinned in, text;
+				for (;;)
+				{
+					uint64 k;
+					{
+						std::lock_guard<std::mutex> g(m);
+						if (!error.empty() || next >= batches.size()) break;
+						k = next++;
+					}
+					const uint64 lo = batches[k].first, hi = batches[k].second; const uint32 n = (uint32)(hi - lo);
+					std::vector<uint64_t> sizes(n), at(n), offs(n), tsz(n), caps;
+					uint64 inBytes = 0;
+					for (uint32 i = 0; i < n; ++i) { sizes[i] = rd.BlockSizes()[lo + i]; at[i] = inBytes; inBytes += (sizes[i] + 64) & ~(uint64)63; }
+					in.Reserve(inBytes);
+					std::vector<const uint8_t*> ptrs(n); std::vector<uint32> words(n);
+					for (uint32 i = 0; i < n; ++i)
+					{
+						rd.ReadBlock(lo + i, in.p + at[i]); ptrs[i] = in.p + at[i];
+						if (sizes[i] < 16) throw DsrcException("Corrupted DSRC archive: block too small");
+						words[i] = (uint32)GetBE(ptrs[i] + 12, 4);
+					}
+					// the block before this batch tells whether chunk sizes are running totals (record-level archives)
+					uint32 before = 0; bool haveBefore = false;
+					if (lo > 0)
+					{
+						uchar hb[16];
+						if (rd.BlockSizes()[lo - 1] >= 16 && pread(rd.Fd(), hb, 16, (off_t)rd.BlockOffset(lo - 1)) == 16) { before = (uint32)GetBE(hb + 12, 4); haveBefore = true; }
+					}
+					int rc = DSRCGPU_OK;
+					for (int attempt = 0; attempt < 2; ++attempt)
+					{
+						TextCaps(words, before, haveBefore, attempt == 0, caps);
+						uint64 cap = 0; for (uint64 c : caps) cap += c;
+						text.Reserve(cap + 64);
+						rc = dsrcgpu_decompress_batch(h, n, ptrs.data(), sizes.data(), caps.data(), text.p, text.cap, offs.data(), tsz.data(), nullptr);
+						if (rc != DSRCGPU_E_CAPACITY) break;
+					}
+					if (rc != DSRCGPU_OK) throw DsrcException(dsrcgpu_last_error(h));
+					{
+						std::unique_lock<std::mutex> g(m);
+						cv.wait(g, [&] { return !error.empty() || writeTurn == k; });
+						if (!error.empty()) break;
+					}
+					// texts are laid out back to back; they are contiguous whenever every block fills its reservation
+					for (uint32 i = 0; i < n;)
+					{
+						uint32 j = i; uint64 len = tsz[i];
+						while (j + 1 < n && offs[j] + tsz[j] == offs[j + 1]) { ++j; len += tsz[j]; }
+						if (len && fwrite(text.p + offs[i], 1, len, out) != len) throw DsrcException("Error writing FASTQ output (disk full?)");
+						i = j + 1;
+					}
+					{
+						std::lock_guard<std::mutex> g(m);
+						++writeTurn; cv.notify_all();
+					}
+				}
+			}
+			catch (const std::exception& e) { std::lock_guard<std::mutex> g(m); if (error.empty()) error = e.what(); cv.notify_all(); }
+			if (h) dsrcgpu_destroy(h);
+		};
+		for (uint32 i = 0; i < instances; ++i) workers.emplace_back(work);
+		for (auto& t : workers) t.join();
+		workers.clear();
+		if (!error.empty()) throw DsrcException(error);
+		if (out != stdout) { FILE* f = out; out = nullptr; if (fclose(f) != 0) throw DsrcException("Error writing FASTQ output (disk full?)"); }
+		else fflush(stdout);
+	}
+	catch (const DsrcException& e) { AddError(e.what()); }
+	catch (const std::exception& e) { AddError(e.what()); }
+	for (auto& t : workers) if (t.joinable()) t.join();
+	if (out && out != stdout) { fclose(out); if (IsError()) unlink(args.outputFilename.c_str()); }
 	return !IsError();
 }
 
@@ -642,9 +848,15 @@ void FastqFile::WriteNextRecord(const FastqRecord& rec_)
 // ---- DsrcArchive (write side) -----------------------------------------------------------------------------------
 struct DsrcArchive::ArchiveImpl
 {
-	enum State { StateNone, StateCompression } state = StateNone;
+	enum State { StateNone, StateCompression, StateDecompression } state = StateNone;
 	dsrcgpu_handle* h = nullptr;
 	comp::ArchiveWriter* writer = nullptr;
+	// reading
+	comp::ArchiveReader* reader = nullptr;
+	uint64 nextBlock = 0;
+	std::vector<uchar> text; uint64 textPos = 0;                      // decoded text of the current batch
+	std::vector<std::pair<uint64, uint64> > spans; size_t span = 0;  // [begin, end) of every block's text in `text`
+	uint32 lastWord = 0; bool haveLastWord = false;                  // chunkSize word of the block before the current batch
 	comp::CompressionSettings settings;
 	fq::FastqDatasetType type;
 	uint64 bufferSize = 0;
@@ -659,6 +871,8 @@ struct DsrcArchive::ArchiveImpl
 	{
 		if (h) { dsrcgpu_destroy(h); h = nullptr; }
 		delete writer; writer = nullptr;
+		delete reader; reader = nullptr;
+		text.clear(); spans.clear(); span = 0; textPos = 0; nextBlock = 0; haveLastWord = false;
 		chunks.clear(); chunkSizes.clear(); cur.clear(); curPayload = runningSize = pendingBytes = 0;
 		state = StateNone;
 	}
@@ -751,16 +965,106 @@ void DsrcArchive::FinishCompress()
 	impl->Release();
 }
 
-void DsrcArchive::StartDecompress(const std::string&)
+void DsrcArchive::StartDecompress(const std::string& filename_)
 {
-	throw DsrcException("DsrcArchive: reading records needs the block decompressor, which is not part of the MI355X path yet (SURVEY 8f-1); use the reference's DsrcArchive");
+	if (impl->state != ArchiveImpl::StateNone) throw DsrcException("Invalid state");
+	impl->reader = new comp::ArchiveReader();
+	try
+	{
+		impl->reader->Open(filename_);
+		// ArchiveSettings::ToInputParams (src/DsrcArchive.cpp:49-63): the archive's settings become the object's
+		impl->settings = impl->reader->Settings(); impl->type = impl->reader->Type();
+		params.dnaCompressionLevel = impl->settings.dnaOrder / 3;
+		params.qualityCompressionLevel = impl->settings.qualityOrder / 3;
+		params.lossyCompression = impl->settings.lossy;
+		params.calculateCrc32 = impl->settings.calculateCrc32;
+		params.tagPreserveFlags = impl->settings.tagPreserveFlags;
+		params.qualityOffset = impl->type.qualityOffset;
+		plusRepetition = impl->type.plusRepetition; colorSpace = impl->type.colorSpace;
+		impl->h = comp::CreateDecodeInstance(params.device, impl->settings, impl->type);
+	}
+	catch (...) { impl->Release(); throw; }
+	impl->nextBlock = 0; impl->text.clear(); impl->textPos = 0;
+	impl->state = ArchiveImpl::StateDecompression;
 }
-bool DsrcArchive::ReadNextRecord(FastqRecord&) { throw DsrcException("Invalid state"); }
-void DsrcArchive::FinishDecompress() { throw DsrcException("Invalid state"); }
 
-void DsrcModule::Decompress(const std::string&, const std::string&)
+// BlockCompressorExt::Feed for the next batch of blocks (src/BlockCompressorExt.cpp:59-66)
+bool DsrcArchive::FeedBatch()
 {
-	throw DsrcException("Decompression is not part of the MI355X hot path (SURVEY 8f-1); use the reference's DsrcModule::Decompress");
+	comp::ArchiveReader& rd = *impl->reader;
+	const uint64 nBlocks = rd.BlockCount();
+	if (impl->nextBlock >= nBlocks) return false;
+	uint64 hi = impl->nextBlock, bytes = 0;
+	while (hi < nBlocks && (hi == impl->nextBlock || bytes + rd.BlockSizes()[hi] <= (64ull << 20))) { bytes += rd.BlockSizes()[hi]; ++hi; }
+	const uint32 n = (uint32)(hi - impl->nextBlock);
+	std::vector<std::vector<uchar> > blocks(n);
+	std::vector<const uint8_t*> ptrs(n); std::vector<uint64_t> sizes(n), offs(n), tsz(n), caps; std::vector<uint32> words(n);
+	for (uint32 i = 0; i < n; ++i)
+	{
+		sizes[i] = rd.BlockSizes()[impl->nextBlock + i];
+		if (sizes[i] < 16) throw DsrcException("Corrupted DSRC archive: block too small");
+		blocks[i].resize(sizes[i]); rd.ReadBlock(impl->nextBlock + i, blocks[i].data()); ptrs[i] = blocks[i].data();
+		words[i] = (uint32)comp::GetBE(ptrs[i] + 12, 4);
+	}
+	int rc = DSRCGPU_OK;
+	for (int attempt = 0; attempt < 2; ++attempt)
+	{
+		comp::TextCaps(words, impl->lastWord, impl->haveLastWord, attempt == 0, caps);
+		uint64 cap = 0; for (uint64 c : caps) cap += c;
+		impl->text.resize(cap + 64);
+		rc = dsrcgpu_decompress_batch(impl->h, n, ptrs.data(), sizes.data(), caps.data(), impl->text.data(), impl->text.size(), offs.data(), tsz.data(), nullptr);
+		if (rc != DSRCGPU_E_CAPACITY) break;
+	}
+	if (rc != DSRCGPU_OK) { const std::string msg = dsrcgpu_last_error(impl->h); throw DsrcException(msg); }
+	impl->lastWord = words[n - 1]; impl->haveLastWord = true;
+	impl->spans.clear();
+	for (uint32 i = 0; i < n; ++i) impl->spans.emplace_back(offs[i], offs[i] + tsz[i]);
+	impl->span = 0; impl->textPos = n ? offs[0] : 0;
+	impl->nextBlock = hi;
+	return true;
+}
+
+// BlockCompressorExt::ExtractNextRecord (src/BlockCompressorExt.cpp:128-147): tag / sequence / quality as decoded; plus is
+// the tag with '+' in front when the archive repeats titles, else "+"
+bool DsrcArchive::ReadNextRecord(FastqRecord& rec_)
+{
+	if (impl->state != ArchiveImpl::StateDecompression) throw DsrcException("Invalid state");
+	for (;;)
+	{
+		while (impl->span < impl->spans.size() && impl->textPos >= impl->spans[impl->span].second)
+		{
+			++impl->span;
+			if (impl->span < impl->spans.size()) impl->textPos = impl->spans[impl->span].first;
+		}
+		if (impl->span < impl->spans.size()) break;
+		if (!FeedBatch()) return false;
+	}
+	const uchar* t = impl->text.data(); const uint64 end = impl->spans[impl->span].second;
+	std::string* part[4] = {&rec_.tag, &rec_.sequence, &rec_.plus, &rec_.quality};
+	for (int k = 0; k < 4; ++k)
+	{
+		uint64 e = impl->textPos;
+		while (e < end && t[e] != '\n') ++e;
+		if (k != 2) part[k]->assign((const char*)t + impl->textPos, (size_t)(e - impl->textPos));
+		impl->textPos = e < end ? e + 1 : e;
+	}
+	if (impl->type.plusRepetition) { rec_.plus = rec_.tag; if (!rec_.plus.empty()) rec_.plus[0] = '+'; }
+	else if (rec_.plus.length() != 1) rec_.plus.assign(1, '+');
+	return true;
+}
+
+void DsrcArchive::FinishDecompress()
+{
+	if (impl->state != ArchiveImpl::StateDecompression) throw DsrcException("Invalid state");
+	impl->Release();
+}
+
+void DsrcModule::Decompress(const std::string& in, const std::string& out)
+{
+	comp::DsrcDecompressorGPU op;
+	comp::InputParameters p = params;
+	p.inputFilename = in; p.outputFilename = out;
+	if (!op.Process(p)) throw DsrcException(op.GetError());
 }
 } // namespace wrap
 } // namespace dsrc

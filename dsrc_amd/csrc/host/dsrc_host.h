@@ -76,6 +76,7 @@ struct InputParameters          // src/Common.h:149-193, plus the GPU knobs at t
 	uint32 fastqBufferSizeMB = 8;
 	bool lossyCompression = false;
 	bool calculateCrc32 = false;
+	bool verifyCrc32 = true;        // with calculateCrc32: decode every block after writing it and compare (reference behaviour, src/DsrcWorker.cpp:53-62)
 	bool useFastqStdIo = false;
 	std::string inputFilename;
 	std::string outputFilename;
@@ -116,6 +117,14 @@ private:
 	void LogSizes(const ArchiveWriter& writer_);
 };
 
+// Drop-in for DsrcDecompressorMT / DsrcDecompressorST (src/DsrcOperator.cpp:397-521): DsrcFileReader -> batches of
+// blocks -> dsrcgpu_decompress_batch (GPU block scheduler) -> FASTQ file / stdout, block order kept.
+class DsrcDecompressorGPU : public IDsrcOperator
+{
+public:
+	bool Process(const InputParameters& args_);
+};
+
 // ---- pieces (exposed for tests) -----------------------------------------------------------------------------
 
 // IFastqStreamReader::ReadNextChunk on a FILE* (src/FastqStream.cpp:18-98)
@@ -145,12 +154,42 @@ public:
 	void Finish(const fq::FastqDatasetType& type, const CompressionSettings& settings);
 	const fq::StreamsInfo& Raw() const { return rawInfo; }
 	const fq::StreamsInfo& Comp() const { return compInfo; }
+	void Abandon();                  // close and remove the unfinished archive
 	~ArchiveWriter();
 private:
+	void Put(const void* p, uint64 n);
+	std::string name;
 	FILE* f = nullptr;
 	std::vector<uint32> blockSizes;
 	fq::StreamsInfo rawInfo, compInfo;
 };
+
+// DsrcFileReader (src/DsrcFile.cpp:172-318): header, footer (block sizes, dataset type, compression settings)
+class ArchiveReader
+{
+public:
+	~ArchiveReader();
+	void Open(const std::string& path);           // throws DsrcException with the reference's messages
+	void Close();
+	int Fd() const { return fd; }
+	uint64 BlockCount() const { return blockSizes.size(); }
+	const std::vector<uint32>& BlockSizes() const { return blockSizes; }
+	uint64 BlockOffset(uint64 i) const { return blockOffs[i]; }
+	const fq::FastqDatasetType& Type() const { return type; }
+	const CompressionSettings& Settings() const { return settings; }
+	void ReadBlock(uint64 i, uchar* dst) const;
+private:
+	int fd = -1;
+	std::vector<uint32> blockSizes;
+	std::vector<uint64> blockOffs;
+	fq::FastqDatasetType type;
+	CompressionSettings settings;
+};
+
+// helpers shared with the record-level API
+uint64 GetBE(const uchar* p, int bytes);
+void TextCaps(const std::vector<uint32>& words, uint32 wordBefore, bool haveBefore, bool exact, std::vector<uint64_t>& caps);
+dsrcgpu_handle* CreateDecodeInstance(int device, const CompressionSettings& settings, const fq::FastqDatasetType& type);
 
 } // namespace comp
 
@@ -227,7 +266,9 @@ private:
 // dsrcgpu_set_record_layout + dsrcgpu_compress_batch, and the archive is the one the reference's DsrcArchive writes.
 // As in the reference this API maps QualityCompressionLevel to qualityOrder = 3 * level whether or not the mode is
 // lossy, so lossless archives are only defined for level 0 (others are refused), and it ignores Crc32Checking and
-// TagFieldFilterMask.  Reading (StartDecompress / ReadNextRecord) needs the block decompressor and throws.
+// TagFieldFilterMask.  Reading (StartDecompress / ReadNextRecord / FinishDecompress, src/DsrcArchive.cpp:170-215,
+// BlockCompressorExt::Feed / ExtractNextRecord src/BlockCompressorExt.cpp:49-66,128-147): blocks are decoded on the GPU a
+// batch at a time and handed out record by record; the settings come from the archive's footer.
 class DsrcArchive : public Configurable
 {
 public:
@@ -244,6 +285,7 @@ private:
 	ArchiveImpl* impl;
 	void CloseChunk();
 	void FlushBatch();
+	bool FeedBatch();
 	DsrcArchive(const DsrcArchive&); DsrcArchive& operator=(const DsrcArchive&);
 };
 

@@ -35,7 +35,10 @@ typedef struct dsrcgpu_settings
 	                                * caller's device buffer in the *_device entry point), as BlockCompressor::Store does to its input */
 	uint8_t  lossy;
 	uint8_t  calculate_crc32;
-	uint8_t  reserved[6];
+	uint8_t  verify_after_compress;/* with calculate_crc32: every compress call decodes the blocks it has written (on the device, nothing is
+	                                * copied back) and fails with DSRCGPU_E_CRC "CRC32 checksums mismatch." unless the stored checksums match
+	                                * -- the reference's worker does this whenever -c is given (src/DsrcWorker.cpp:53-62) */
+	uint8_t  reserved[5];
 } dsrcgpu_settings;
 
 /* fq::FastqDatasetType (src/Common.h:56-80), decided once per file by FastqParser::Analyze on chunk 0. */
@@ -55,7 +58,8 @@ enum
 	DSRCGPU_E_NOMEM       = -3,
 	DSRCGPU_E_CAPACITY    = -4,   /* caller's output buffer too small */
 	DSRCGPU_E_INPUT       = -5,   /* a chunk could not be coded (no records, invalid bases, reference-UB input ...) */
-	DSRCGPU_E_STATE       = -6
+	DSRCGPU_E_STATE       = -6,
+	DSRCGPU_E_CRC         = -7    /* verify_after_compress: a block did not decode back to the checksums stored in it */
 };
 
 /* Replaces: BlockCompressor::BlockCompressor (src/BlockCompressor.cpp:53-94) x worker threads.
@@ -88,6 +92,29 @@ int dsrcgpu_compress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_f
 								  const uint64_t* sizes, void* d_blocks, uint64_t blocks_cap,
 								  uint64_t* block_offs, uint64_t* block_sizes,
 								  uint64_t* raw_sizes, uint64_t* comp_sizes);
+
+/* ---- decompression -------------------------------------------------------------------------------------------------
+ * Replaces one call of BlockCompressor::Read (src/BlockCompressor.cpp:262-297) inside DsrcDecompressor::Process
+ * (src/DsrcWorker.cpp:75-104): block bytes -> the FASTQ text of the chunk, every line (also the last) ended by '\n'.
+ * The handle's settings and dataset must be the archive's (DsrcFileFooter, src/DsrcFile.cpp:142-170); a block that does
+ * not end exactly where its last stream ends is refused (DSRCGPU_E_INPUT), as are blocks the reference's own decoder
+ * cannot read back deterministically (colour space without a constant primer; streams that run off the end of the block).
+ * crc_ok (may be NULL): per block, 1 if the checksum words stored with calculate_crc32 equal the checksums of the
+ * decoded records, 0 otherwise -- BlockCompressor::VerifyChecksum (src/BlockCompressor.cpp:576-594), which the
+ * reference's compressing worker runs on every block it has just written (src/DsrcWorker.cpp:53-62); without
+ * calculate_crc32 every entry is 1.
+ * text_caps (may be NULL): text bytes to reserve per block instead of the chunkSize word + 1; needed for archives written
+ * by the record-level API, whose chunkSize words are running totals (see dsrcgpu_set_record_layout).
+ * n blocks in one scheduler pass; texts are laid out back to back in block order (text_offs / text_sizes). */
+int dsrcgpu_decompress_block(dsrcgpu_handle* h, const uint8_t* block, uint64_t size,
+							 uint8_t* text, uint64_t text_cap, uint64_t* text_size, uint32_t* crc_ok);
+int dsrcgpu_decompress_batch(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* blocks, const uint64_t* sizes,
+							 const uint64_t* text_caps, uint8_t* text, uint64_t text_cap,
+							 uint64_t* text_offs, uint64_t* text_sizes, uint32_t* crc_ok);
+/* Device-resident variant (block i is d_blocks[offs[i] .. offs[i] + sizes[i])); no payload copies inside the call. */
+int dsrcgpu_decompress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_blocks, const uint64_t* offs,
+									const uint64_t* sizes, const uint64_t* text_caps, void* d_text, uint64_t text_cap,
+									uint64_t* text_offs, uint64_t* text_sizes, uint32_t* crc_ok);
 
 /* Queue form of DsrcCompressor::Process (src/DsrcWorker.cpp:39-70):
  *   fastqQueue.Pop(partId, chunk)            -> dsrcgpu_submit(partId, chunk)      (chunk bytes are copied)
