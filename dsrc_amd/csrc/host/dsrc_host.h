@@ -222,6 +222,7 @@ public:
 	void SetColorSpace(bool use_) { colorSpace = use_; }
 	bool IsColorSpace() const { return colorSpace; }
 	void SetDevice(int device_) { params.device = device_; }
+	int GetDevice() const { return params.device; }
 protected:
 	comp::InputParameters params;
 	bool plusRepetition = false, colorSpace = false;

@@ -47,6 +47,10 @@ def test_illumina_archive_identical(files, flags):
     _run([REF_BIN, "d", "-t1", ours, back])
     if "-l" not in flags:
         assert open(back, "rb").read() == open(ill, "rb").read()
+    # and our own decompressor gives what the reference's gives, for the reference's archive
+    mine = str(d / "mine.fastq")
+    _run([CLI, "d", "-t3", "-n5", theirs, mine])
+    assert md5(mine) == md5(back)
 
 
 def test_iontorrent_lossy_archive_identical(files):
@@ -87,8 +91,22 @@ def test_pydsrc_module_names(files):
     assert md5(ours) == md5(theirs)
     with pytest.raises(RuntimeError):
         m.DNACompressionLevel = 4
+    back = str(d / "py_back.fastq")
+    pydsrc.DsrcModule().Decompress(ours, back)                  # in-process, settings from the archive footer
+    assert open(back, "rb").read() == open(ill, "rb").read()
     with pytest.raises(RuntimeError):
-        m.Decompress(ours, str(d / "x.fastq"))
+        m.Decompress(str(d / "missing.dsrc"), back)
+    # record-level reading of a `dsrc c` archive
+    a = pydsrc.DsrcArchive(); a.StartDecompress(ours)
+    assert (a.DNACompressionLevel, a.QualityOffset, a.LossyCompression) == (2, 33, False)
+    rec = pydsrc.FastqRecord(); n = 0; first = None
+    while a.ReadNextRecord(rec):
+        if first is None:
+            first = (rec.tag, rec.sequence, rec.plus, rec.quality)
+        n += 1
+    a.FinishDecompress()
+    lines = open(ill, "rb").read().split(b"\n")
+    assert n == 30000 and first == tuple(x.decode() for x in lines[:4])
 
 
 @pytest.mark.parametrize("fields", ["-f1,2", "-f2,4,5", "-f1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16"])
@@ -121,3 +139,51 @@ def test_config1_full_size_archive_md5(tmp_path):
         dst = tmp_path / (key + ".dsrc")
         _run([CLI, "c", *G[key]["flags"], str(src), str(dst)])
         assert (os.path.getsize(dst), md5(dst)) == (G[key]["size"], G[key]["md5"]), key
+
+
+def test_decompress_every_golden_archive(oracle, tmp_path):
+    """`dsrc-amd d` on every whole-archive golden vector of the reference (tests/golden/golden.json, solid_golden.json:
+    archives re-made by the oracle and pinned by their md5 / sha256): the output is the input for lossless levels, and what
+    the reference's `dsrc d` writes for all of them."""
+    import json
+    from tests.test_oracle_golden import G, _file_bytes
+    from tests.cases import fuzz_solid
+    if not os.path.exists(CLI):
+        pytest.skip("dsrc-amd not built")
+    src = tmp_path / "in.fastq"; arc = tmp_path / "a.dsrc"; out = tmp_path / "out.fastq"; refout = tmp_path / "ref.fastq"
+    n = 0
+    for a in G["archives"]:
+        data = _file_bytes(a["name"]); src.write_bytes(data)
+        d, q, lossy, crc = a["levels"]
+        assert oracle.compress_file(str(src), str(arc), d, q, lossy, crc, 0, a["buf_mb"]) == 0
+        assert md5(arc) == a["md5"]
+        _run([CLI, "d", "-t2", "-n3", str(arc), str(out)])
+        if not lossy:
+            assert out.read_bytes() == data.replace(b"\r\n", b"\n"), (a["name"], a["levels"])
+        if os.path.exists(REF_BIN):
+            _run([REF_BIN, "d", "-t1", str(arc), str(refout)])
+            assert md5(out) == md5(refout), (a["name"], a["levels"])
+        n += 1
+    S = json.load(open(os.path.join(ROOT, "tests", "golden", "solid_golden.json")))
+    for a in S["archives"]:
+        data = fuzz_solid(a["seed"], a["nrec"])[0] + b"\n"; src.write_bytes(data)
+        _run([CLI, "c", *a["flags"], "-b%d" % a["buf_mb"], str(src), str(arc)])
+        assert hashlib.sha256(arc.read_bytes()).hexdigest() == a["sha256"]
+        r = subprocess.run([CLI, "d", str(arc), str(out)], capture_output=True)
+        if os.path.exists(REF_BIN) and r.returncode == 0:
+            _run([REF_BIN, "d", "-t1", str(arc), str(refout)])
+            assert md5(out) == md5(refout), a
+        n += 1
+    assert n >= 20
+
+
+def test_verify_pass_with_c(files):
+    """-c runs the decode-and-compare pass on the device after every batch (reference: src/DsrcWorker.cpp:53-62); the
+    archive is the same with and without it (-x skips it)."""
+    if not os.path.exists(CLI):
+        pytest.skip("dsrc-amd not built")
+    d, ill, ion = files
+    a = str(d / "v1.dsrc"); b = str(d / "v2.dsrc")
+    _run([CLI, "c", "-d3", "-q2", "-c", "-b1", "-n4", ill, a])
+    _run([CLI, "c", "-d3", "-q2", "-c", "-x", "-b1", "-n4", ill, b])
+    assert md5(a) == md5(b)

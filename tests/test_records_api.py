@@ -95,6 +95,41 @@ def test_host_archive_on_emulator(inputs):
     assert subprocess.run([EMU_HOST, paths["illumina3200"], out, "0", "0", "0", "1", "0"], capture_output=True).returncode == 1
 
 
+def test_host_archive_read_side_on_emulator(inputs, oracle):
+    """DsrcArchive::StartDecompress / ReadNextRecord / FinishDecompress (reference src/DsrcArchive.cpp:170-215) on the
+    emulator: records come back from an archive written by the record-level API (chunkSize words are running totals)
+    and from one written by `dsrc c` (own sizes), with the settings taken from the footer."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emu")], stdout=subprocess.DEVNULL)
+    d, paths = inputs
+    src = paths["illumina3200"]
+    a = str(d / "rd_rec.dsrc"); b = str(d / "rd_file.dsrc"); back = str(d / "rd_back.fastq")
+    assert oracle.compress_records_file(src, a, 0, 0, False, 33, 1) == 0
+    assert oracle.compress_file(src, b, 1, 1, False, True, 0, 1) == 0
+    for arc in (a, b):
+        r = subprocess.run([EMU_HOST, "-x", arc, back], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        assert b"records: 3200" in r.stderr
+        assert open(back, "rb").read() == open(src, "rb").read()
+
+
+@pytest.mark.gpu
+def test_gpu_archive_read_side(inputs, oracle):
+    """Every golden record-level archive (written by the reference's DsrcArchive) read back record by record on the GPU."""
+    assert os.path.exists(GPU_HOST), "dsrc-amd-records not built"
+    d, paths = inputs
+    arc = str(d / "rr.dsrc"); back = str(d / "rr.fastq")
+    for e in G["archives"]:
+        dl, ql, lossy = e["levels"]
+        assert oracle.compress_records_file(paths[e["name"]], arc, dl, ql, bool(lossy), e["quality_offset"], e["buf_mb"]) == 0
+        assert sha(open(arc, "rb").read()) == e["sha256"]
+        subprocess.check_call([GPU_HOST, "-x", arc, back], stderr=subprocess.DEVNULL)
+        got = open(back, "rb").read(); src = open(paths[e["name"]], "rb").read()
+        if not lossy:
+            assert got == src, e
+        else:
+            assert got.split(b"\n")[0::4] == src.split(b"\n")[0::4] and len(got) == len(src)
+
+
 @pytest.mark.gpu
 def test_gpu_host_archives(inputs):
     assert os.path.exists(GPU_HOST), "dsrc-amd-records not built"
