@@ -33,6 +33,7 @@ BUF = 8 << 20                     # -b8 (reference default, src/Common.h:156)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 RECS_PER_BLOCK = 22300
 PMC_RC_BYTES_PER_BLOCK = (20.0005e6 * 2 + 13.3255e6) * 1024 / 512   # measured, see roofline.traffic below
+PMC_SORT_BYTES_PER_BLOCK = 113e9 / 512                            # k_sort: 100-126 GB per 512-block batch (same profile)
 MAX_RESIDENT = 3                  # distinct input shards kept in HBM per scheduler instance (2 when N > 1: rank 0 also holds the gathered streams)
 
 
@@ -71,29 +72,36 @@ def cut_blocks(off: np.ndarray, nblocks: int):
     return starts, sizes
 
 
-def cpu_baseline(sample: bytes, d: int, q: int):
-    """The unmodified reference (oracle/_ref, DsrcCompressorMT) on the host cores, or our C port on one core when
-    _ref is absent.  Reported beside the GPU number; it is not the target."""
+def cpu_baseline(write_sample, d: int, q: int):
+    """The unmodified reference (oracle/_ref: DsrcCompressorMT, then DsrcDecompressorMT on its own archive) on the host
+    cores, or our C port on one core when _ref is absent.  Reported beside the GPU numbers; it is not the target.
+    write_sample(file) writes the sample FASTQ and returns its size."""
     import tempfile
     from tests._oracle import Oracle, Ref, have_ref
     # the reference's queues use a 64-bit completion mask: thread counts >= 64 are undefined (SURVEY Appendix B.20)
     cores = min(os.cpu_count() or 1, 60)
+    dec = None
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
-        src = os.path.join(td, "s.fastq"); dst = os.path.join(td, "s.dsrc")
+        src = os.path.join(td, "s.fastq"); dst = os.path.join(td, "s.dsrc"); back = os.path.join(td, "b.fastq")
         with open(src, "wb") as f:
-            f.write(sample)
+            size = write_sample(f)
         if have_ref():
             r = Ref()
             t = time.time(); rc = r.compress_file(src, dst, d, q, False, False, 33, 8, cores); dt = time.time() - t
             kind = "reference"
+            os.unlink(src)
+            t = time.time(); rc2 = r.decompress_file(dst, back, cores); dt2 = time.time() - t
+            if rc2 == 0 and os.path.getsize(back) == size:
+                dec = {"value": round(size / dt2 / 1e6, 2), "unit": "MB/s", "cores": cores, "kind": "reference",
+                       "sample": f"`dsrc d -t{cores}` of the archive of the same {size} bytes, tmpfs to tmpfs, wall {dt2:.2f} s"}
         else:
             o = Oracle(); cores = 1
             t = time.time(); rc = o.compress_file(src, dst, d, q, False, False, 33, 8); dt = time.time() - t
             kind = "port"
         assert rc == 0
-    return {"value": round(len(sample) / dt / 1e6, 2), "unit": "MB/s", "cores": cores, "kind": kind,
-            "sample": f"{len(sample)} bytes of the same synthetic FASTQ ({len(sample) // BUF + 1} blocks), -d{d} -q{q} -b8, "
-                      f"input and output in tmpfs, {cores} worker threads, wall {dt:.2f} s"}
+    return {"value": round(size / dt / 1e6, 2), "unit": "MB/s", "cores": cores, "kind": kind,
+            "sample": f"{size} bytes of the same synthetic FASTQ ({size // BUF + 1} blocks), -d{d} -q{q} -b8, "
+                      f"input and output in tmpfs, {cores} worker threads, wall {dt:.2f} s"}, dec
 
 
 class Lane:
@@ -134,7 +142,7 @@ class Lane:
         res = self.h.compress_batch_device(d_in, starts, sizes, self.outs[k % len(self.outs)][0], self.cap_out)
         t1 = time.perf_counter()
         self.results[k] = res
-        self.timing.append(self.h.last_timing())
+        self.timing.append(self.h.last_timing() + self.h.last_stage_timing())
         self.trace.append((k, t0, t1) + self.timing[-1][:2])
         return res
 
@@ -166,6 +174,50 @@ class StepGates:
             self.gathered.add(s); self.cv.notify_all()
 
 
+def measure_decode(lanes, cfg, n_blocks, last_step):
+    """Secondary line: the same blocks back through the GPU decompressor (dsrcgpu_decompress_batch_device), everything in
+    HBM.  The blocks are the ones instance 0 wrote in its last sub-batch, taken as many times as needed to make
+    `n_blocks` (every copy is decoded into its own text; the decoder's work does not depend on the data being distinct).
+    The other instances are closed first: a decoding pass wants the HBM for model tables (one per block in flight)."""
+    ln = lanes[0]
+    for other in lanes[1:]:
+        for d_in, _, _ in other.sub:
+            other.h.dev_free(d_in)
+        for ptr, tensor in other.outs:
+            if tensor is None:
+                other.h.dev_free(ptr)
+        other.sub = []; other.outs = []
+        other.h.close()
+    o_offs, o_sizes, _, _ = ln.results[last_step]
+    d_blk = ln.outs[last_step % len(ln.outs)][0]
+    d_in, starts, sizes = ln.shard(last_step)
+    reps = max(1, (n_blocks + len(o_offs) - 1) // len(o_offs))
+    offs = (o_offs * reps)[:n_blocks]; szs = (o_sizes * reps)[:n_blocks]
+    text_bytes = sum((sizes * reps)[:n_blocks]) + n_blocks
+    d_txt = ln.h.dev_alloc(text_bytes + 4096)
+    try:
+        t_offs, t_sizes, ok = ln.h.decompress_batch_device(d_blk, offs, szs, d_txt, text_bytes + 4096, verify=True)    # warm-up: sizes the arena
+        t0 = time.perf_counter()
+        t_offs, t_sizes, ok = ln.h.decompress_batch_device(d_blk, offs, szs, d_txt, text_bytes + 4096, verify=True)
+        dt = time.perf_counter() - t0
+        gpu_ms = ln.h.last_timing()[0]
+        assert sum(t_sizes) == text_bytes and all(ok)
+        # parity: the text of the first and the last copy is the chunk that was compressed
+        for i in (0, n_blocks - 1):
+            src = ln.h.dev_download(d_in + starts[i % len(starts)], sizes[i % len(starts)])
+            assert ln.h.dev_download(d_txt + t_offs[i], t_sizes[i]) == src + b"\n", f"decode parity check failed on block {i}"
+    finally:
+        ln.h.dev_free(d_txt)
+    alg = text_bytes + sum(szs)
+    return {"metric": f"raw FASTQ MB/s decompressed (text identical to the input) at -d{cfg.dna_order // 3} -q{cfg.quality_order}",
+            "value": round(text_bytes / dt / 1e6, 1), "unit": "MB/s", "blocks": n_blocks, "ms": round(dt * 1e3, 1),
+            "data": f"{len(o_offs)} distinct blocks of the timed region x {reps}, compressed blocks and decoded text resident in HBM; one scheduler instance, one pass",
+            "roofline": {"bound": "hbm", "kernel": "k_dec_streams (one wavefront per block: range / Huffman decoding of the quality and DNA streams)",
+                         "achieved": round(alg / (gpu_ms / 1e3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (gpu_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 6), "kernel_ms": round(gpu_ms, 1), "launch_bytes": int(alg), "traffic": None,
+                         "note": "algorithmic bytes = block bytes in + text bytes out of the pass; a decoded stream is a chain of dependent model-row reads (about one HBM latency per symbol), so the pass is bound by latency x blocks in flight, not by bandwidth (DESIGN section 11)"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,6 +228,9 @@ def main():
     ap.add_argument("--dna", type=int, default=3)
     ap.add_argument("--qua", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-blocks", type=int, default=int(os.environ.get("DSRC_BENCH_CPU_BLOCKS", "480")), help="8 MiB chunks of the CPU baseline sample (480 = 4 GB)")
+    ap.add_argument("--decode-blocks", type=int, default=int(os.environ.get("DSRC_BENCH_DECODE_BLOCKS", "1200")),
+                    help="blocks of the secondary decompression measurement (0 = skip)")
     ap.add_argument("--check", type=int, default=2, help="blocks of the first sub-batch to verify against the oracle")
     args = ap.parse_args()
 
@@ -207,6 +262,16 @@ def main():
         return h.dev_alloc(cap), None
 
     lanes = [Lane(cfg, local, sub_blocks, total_steps, rank, i, P, alloc_out, n_out=2 if dist is not None else 1) for i in range(P)]
+
+    if dist is not None:
+        # block-to-block state across ranks (dsrc_amd/dist.py): rank r starts as if ranks 0..r-1 had compressed their chunks
+        from dsrc_amd import synth as synth_
+        from dsrc_amd._lib import load as load_lib
+        from dsrc_amd.dist import exchange_fields_capacity
+        t0 = synth_.illumina_title(1 + rank * P * MAX_RESIDENT * (int(sub_blocks * RECS_PER_BLOCK * 1.02) + 1000))
+        seed = exchange_fields_capacity([load_lib().dsrcgpu_title_fields(t0, len(t0), 0)], device=torch.device("cuda", local))
+        for ln in lanes:
+            ln.h.set_fields_capacity(seed)
 
     def sync_all():
         if torch is not None:
@@ -344,15 +409,45 @@ def main():
                          "kernel_ms": round(rc_ms, 2), "launch_bytes": int(alg), "batch_ms": round(batch_ms, 2),
                          "note": "algorithmic bytes = chunk bytes in + block bytes out of one sub-batch launch (SURVEY 8d); kernel_ms = k_rc + k_rc_emit from HIP events on the range-coder stream, measured while other scheduler instances share the GPU (alone: 141 ms)"},
         }
+        sort_ms = sum(x[3] for x in tm) / max(1, len(tm)); replay_ms = sum(x[4] for x in tm) / max(1, len(tm))
+        if sort_ms > 0:
+            # the kernel that bounds the THROUGHPUT (k_rc above is the longest launch, but it is hidden behind the other
+            # instances' front ends): the context sort.  Same algorithmic bytes per launch group, its own summed HIP-event time
+            line["roofline_frontend"] = {
+                "bound": "hbm", "kernel": "k_sort (stable LSD radix sort of (context, symbol, t) per stream; all launches of one sub-batch)",
+                "achieved": round(alg / (sort_ms / 1e3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(alg / (sort_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5), "kernel_ms": round(sort_ms, 2), "replay_ms": round(replay_ms, 2),
+                "launch_bytes": int(alg), "traffic": int(PMC_SORT_BYTES_PER_BLOCK * sub_blocks),
+                "note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE of the k_sort launches of a 512-block batch / 512 (profiles/r01_pmc_b512_p1_d3q2.txt); "
+                        "replay_ms = k_replay_seams + k_replay of the same sub-batch"}
+        decode_line = None
+        if args.decode_blocks > 0 and world == 1:
+            decode_line = measure_decode(lanes, cfg, args.decode_blocks, total_steps - 1)
+            if decode_line:
+                line["decompress"] = decode_line
         if not args.no_cpu and world == 1:
             ln = lanes[0]
-            d_in, starts, sizes = ln.shard(0)
-            need = min(120, sub_blocks)
-            sample = ln.h.dev_download(d_in, starts[need - 1] + sizes[need - 1] + 1)
-            line["cpu_baseline"] = cpu_baseline(sample, args.dna, args.qua)
+            need = max(1, args.cpu_blocks)
+
+            def write_sample(f):
+                left = need; k = 0; total = 0
+                while left > 0:
+                    d_in, starts, sizes = ln.sub[k % ln.n_res]
+                    m = min(left, len(starts))
+                    end = starts[m - 1] + sizes[m - 1] + 1
+                    step = 256 << 20
+                    for o in range(0, end, step):
+                        f.write(ln.h.dev_download(d_in + o, min(step, end - o)))
+                    total += end; left -= m; k += 1
+                    if k >= ln.n_res and left > 0:
+                        k = 0          # fewer distinct shards than asked for: the sample repeats them
+                return total
+            line["cpu_baseline"], dec_cpu = cpu_baseline(write_sample, args.dna, args.qua)
+            if decode_line and dec_cpu:
+                line["decompress"]["cpu_baseline"] = dec_cpu
         out_line = json.dumps(line)
     for ln in lanes:
-        ln.h.close()
+        ln.h.close()          # idempotent
     if dist is not None:
         dist.destroy_process_group()
     if out_line is not None:

@@ -21,6 +21,8 @@ EXPORTS = [
     "dsrcgpu_dev_download", "dsrcgpu_chain_create", "dsrcgpu_chain_destroy", "dsrcgpu_set_chain", "dsrcgpu_host_alloc",
     "dsrcgpu_host_free", "dsrcgpu_selftest", "dsrcgpu_set_record_layout",
     "dsrcgpu_decompress_block", "dsrcgpu_decompress_batch", "dsrcgpu_decompress_batch_device",
+    "dsrcgpu_title_fields", "dsrcgpu_fields_capacity_after", "dsrcgpu_set_fields_capacity", "dsrcgpu_get_fields_capacity",
+    "dsrcgpu_chain_seed", "dsrcgpu_last_stage_timing", "dsrcgpu_try_collect",
 ]
 
 
@@ -65,8 +67,25 @@ def load():
     L.dsrcgpu_chain_destroy.argtypes = [C.c_void_p]
     L.dsrcgpu_set_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.dsrcgpu_set_record_layout.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.dsrcgpu_title_fields.restype = C.c_uint32
+    L.dsrcgpu_title_fields.argtypes = [C.c_char_p, C.c_uint32, C.c_uint64]
+    L.dsrcgpu_fields_capacity_after.restype = C.c_uint32
+    L.dsrcgpu_fields_capacity_after.argtypes = [C.c_uint32, C.c_uint32]
+    L.dsrcgpu_chain_seed.argtypes = [C.c_void_p, C.c_uint32]
     _lib = L
     return L
+
+
+def fields_capacity_fold(chunks, tag_flags: int = 0, cap: int = 0) -> int:
+    """The block-to-block state (capacity of the reference's TagStats::fields) after `chunks` have been compressed in
+    order, from the first title line of each chunk alone (include/dsrc_gpu.h: dsrcgpu_fields_capacity_after)."""
+    L = load()
+    for c in chunks:
+        e = 0
+        while e < len(c) and c[e] not in (10, 13):
+            e += 1
+        cap = L.dsrcgpu_fields_capacity_after(cap, L.dsrcgpu_title_fields(bytes(c[:e]), e, tag_flags))
+    return cap
 
 
 class Chain:
@@ -78,6 +97,11 @@ class Chain:
         rc = self.L.dsrcgpu_chain_create(C.byref(self.c))
         if rc != 0:
             raise DsrcGpuError(rc, "dsrcgpu_chain_create failed")
+
+    def seed(self, fields_capacity: int):
+        rc = self.L.dsrcgpu_chain_seed(self.c, fields_capacity)
+        if rc != 0:
+            raise DsrcGpuError(rc, "dsrcgpu_chain_seed: the chain has already started")
 
     def close(self):
         if getattr(self, "c", None):
@@ -121,6 +145,15 @@ class Handle:
     def set_chain(self, chain, seq: int):
         """The next batch call on this handle is batch number `seq` of `chain` (None detaches)."""
         self._chk(self.L.dsrcgpu_set_chain(self.h, chain.c if chain is not None else None, C.c_uint64(seq)))
+
+    def set_fields_capacity(self, cap: int):
+        """Seed the block-to-block state of a handle that starts in the middle of an archive (see fields_capacity_fold)."""
+        self._chk(self.L.dsrcgpu_set_fields_capacity(self.h, C.c_uint32(cap)))
+
+    def get_fields_capacity(self) -> int:
+        v = C.c_uint32()
+        self._chk(self.L.dsrcgpu_get_fields_capacity(self.h, C.byref(v)))
+        return v.value
 
     def set_record_layout(self, chunk_sizes):
         """The next batch call compresses chunks assembled from records (reference: BlockCompressorExt);
@@ -188,10 +221,11 @@ class Handle:
     def flush(self):
         self._chk(self.L.dsrcgpu_flush(self.h))
 
-    def collect(self):
+    def collect(self, wait: bool = True):
         pid = C.c_int64(); blk = C.POINTER(C.c_uint8)(); sz = C.c_uint64()
         raw = (C.c_uint64 * 4)(); comp = (C.c_uint64 * 4)()
-        rc = self._chk(self.L.dsrcgpu_collect(self.h, C.byref(pid), C.byref(blk), C.byref(sz), raw, comp))
+        fn = self.L.dsrcgpu_collect if wait else self.L.dsrcgpu_try_collect
+        rc = self._chk(fn(self.h, C.byref(pid), C.byref(blk), C.byref(sz), raw, comp))
         if rc == 0:
             return None
         data = bytes(C.cast(blk, C.POINTER(C.c_uint8 * sz.value)).contents) if sz.value else b""
@@ -207,6 +241,11 @@ class Handle:
         ms = C.c_float(); rc_ms = C.c_float(); n = C.c_uint32()
         self.L.dsrcgpu_last_timing(self.h, C.byref(ms), C.byref(rc_ms), C.byref(n))
         return ms.value, rc_ms.value, n.value
+
+    def last_stage_timing(self):
+        a = C.c_float(); b = C.c_float()
+        self.L.dsrcgpu_last_stage_timing(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     # device helpers -------------------------------------------------
     def dev_alloc(self, nbytes: int) -> int:

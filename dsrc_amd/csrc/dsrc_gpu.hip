@@ -18,6 +18,7 @@
 #include <deque>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dsrc_gpu.h"
@@ -49,8 +50,21 @@ struct Arena
 	}
 };
 
-struct Pending { int64_t part_id; std::vector<u8> data; };
-struct Done { int64_t part_id; u8* block; u64 size; u64 raw[4]; u64 comp[4]; };
+// Queue form (dsrcgpu_submit / flush / collect / release): a ring of batches in page-locked memory.  submit() copies a
+// chunk into the batch being filled, flush() hands that batch to the handle's scheduler thread and returns, collect()
+// hands out the blocks of finished batches in submission order as pointers INTO the batch's output buffer, release()
+// gives them back; a batch buffer is reused once all its blocks have been released.
+struct QBatch
+{
+	enum State { Free, Filling, Queued, Done } state = Free;
+	std::vector<int64_t> ids; std::vector<u64> in_off, sizes;
+	u8* in = nullptr; u64 in_cap = 0, in_used = 0;
+	u8* out = nullptr; u64 out_cap = 0;
+	std::vector<u64> o_offs, o_sizes, raw, comp;
+	u32 next_collect = 0, outstanding = 0;
+	int rc = 0; std::string err;
+};
+#define DSRC_QUEUE_DEPTH 3
 
 } // namespace
 
@@ -80,11 +94,18 @@ struct dsrcgpu_handle
 	u32* d_crc_tab = nullptr;
 	std::string err;
 	u8* last_d_out = nullptr;        // device address of the blocks the last run_batch assembled (valid until the arena is reused)
-	std::vector<Pending> pending;
-	std::deque<Done> done;
+	QBatch qb[DSRC_QUEUE_DEPTH]; u32 q_fill = 0, q_collect = 0;     // ring: batches are filled, run and collected in this order
+	u32 q_pending = 0;                                               // flushed batches that still have blocks to hand out
+	std::deque<u32> q_run;
+	std::mutex q_m; std::condition_variable q_cv;
+	std::thread q_thread; bool q_stop = false, q_started = false;
+	int q_rc = 0; std::string q_err;                                 // first failure of the scheduler thread (sticky)
 	float batch_ms = 0.f, rc_ms = 0.f;
 	u32 rc_launches = 0;
 	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+	// per-stage HIP-event timing of the last batch: pairs of events around every k_sort launch and every replay group
+	std::vector<hipEvent_t> stage_ev; std::vector<u32> stage_kind; u32 stage_used = 0;       // kind: 0 sort, 1 replay
+	float sort_ms = 0.f, replay_ms = 0.f, decode_stream_ms = 0.f;
 };
 
 namespace
@@ -152,6 +173,12 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	auto mark = [&](const char* what) { if (trace) { char b[64]; snprintf(b, sizeof b, " %s %.1f", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count()); tl += b; } };
 	hipStream_t s = h->stream;
 	Arena& A = h->arena;
+	h->stage_used = 0; h->stage_kind.clear();
+	auto stage_mark = [&](u32 kind)      // two calls bracket a stage
+	{
+		if (h->stage_used == h->stage_ev.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return; h->stage_ev.push_back(e); }
+		(void)hipEventRecord(h->stage_ev[h->stage_used++], s); h->stage_kind.push_back(kind);
+	};
 	const u32 dna_order = h->set.dna_order, qo = h->set.quality_order;
 	const bool lossy = h->set.lossy != 0, crc = h->set.calculate_crc32 != 0;
 
@@ -630,7 +657,9 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		for (size_t sl = 0; sl + 1 < slice_lo.size(); ++sl)
 		{
 			const u32 s_lo = slice_lo[sl], s_hi = slice_lo[sl + 1];
+			stage_mark(0);
 			hipLaunchKernelGGL(k_sort, dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state); KCHK();
+			stage_mark(0); stage_mark(1);
 			for (u32 lo = s_lo; lo < s_hi;)
 			{
 				u32 hi = lo;
@@ -653,6 +682,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 				KCHK();
 				lo = hi;
 			}
+			stage_mark(1);
 		}
 		// the serial coder runs on its own high-priority stream: its few waves must not queue behind the
 		// data-parallel kernels of another scheduler instance sharing the GPU
@@ -706,6 +736,12 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	if (getenv("DSRC_GPU_DEBUG")) fprintf(stderr, "[dsrc_gpu] batch of %u chunks, %zu input bytes: arena used %zu of %zu bytes\n", B, in_total, A.top, A.cap);
 	hipEventElapsedTime(&h->batch_ms, h->ev[0], h->ev[1]);
 	if (h->rc_launches) hipEventElapsedTime(&h->rc_ms, h->ev[2], h->ev[3]); else h->rc_ms = 0.f;
+	h->sort_ms = h->replay_ms = 0.f;
+	for (u32 i = 0; i + 1 < h->stage_used; i += 2)
+	{
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, h->stage_ev[i], h->stage_ev[i + 1]) == hipSuccess) (h->stage_kind[i] == 0 ? h->sort_ms : h->replay_ms) += ms;
+	}
 	return DSRCGPU_OK;
 }
 
@@ -768,6 +804,18 @@ u64 dec_table_words(const dsrcgpu_settings& set)
 	return std::max<u64>(std::max(q, d), 16);
 }
 
+// bytes of HBM the model-table slots of one decode pass may take: DSRC_GPU_DEC_TABLE_MB, else 70 % of what is free once
+// the rest of the pass (`other` bytes of arena) is accounted for, but never more than 160 GiB
+u64 dec_table_budget(const dsrcgpu_handle* h, size_t other)
+{
+	if (const char* env = getenv("DSRC_GPU_DEC_TABLE_MB")) return (u64)atol(env) << 20;
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (u64)8192 << 20;
+	const u64 avail = (u64)free_b + h->arena.cap;             // the arena is re-allocated when it has to grow
+	const u64 rest = avail > other + ((u64)2048 << 20) ? avail - other - ((u64)2048 << 20) : 0;
+	return std::min<u64>(std::max<u64>(rest * 7 / 10, (u64)256 << 20), (u64)160 << 30);
+}
+
 int run_decode(dsrcgpu_handle* h, DecodeIO io)
 {
 	const u32 B = io.n;
@@ -778,6 +826,7 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 	prm.dna_order = h->set.dna_order; prm.quality_order = h->set.quality_order; prm.lossy = h->set.lossy ? 1u : 0u;
 	prm.crc = h->set.calculate_crc32 ? 1u : 0u; prm.quality_offset = h->ds.quality_offset; prm.n_blocks = B;
 	prm.tag_flags = (u32)h->set.tag_preserve_flags; prm.plus_rep = h->ds.plus_repetition ? 1u : 0u; prm.color_space = h->ds.color_space ? 1u : 0u;
+	prm.serial_quality = getenv("DSRC_GPU_DEC_SERIAL") ? 1u : 0u;
 
 	std::vector<DecDesc> desc(B); std::vector<DecState> st(B);
 	memset(desc.data(), 0, sizeof(DecDesc) * B);
@@ -820,12 +869,9 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 	rp.q_off = nullptr; rp.d_off = AP<u32>(h, A.alloc(recs * 4));
 	const size_t o_d = A.alloc(dbytes + 64), o_nodes = A.alloc(nodes * 4 + 64), o_fld = A.alloc(fbytes + 64);
 	prm.table_words = (u32)dec_table_words(h->set);
-	u32 slots;
-	{
-		const char* env = getenv("DSRC_GPU_DEC_TABLE_MB");
-		const u64 budget = (env ? (u64)atol(env) : (u64)32768) << 20;
-		slots = (u32)std::max<u64>(1, std::min<u64>(B, budget / ((u64)prm.table_words * 4)));
-	}
+	// Model tables: one slot per block in flight.  A stream advances one symbol per dependent row read (~1 us), so the
+	// rate of the range-decoded levels is (slots in flight) / latency: the slots take what HBM is left
+	const u32 slots = (u32)std::max<u64>(1, std::min<u64>(B, dec_table_budget(h, A.top) / ((u64)prm.table_words * 4)));
 	const size_t o_tab = A.alloc((size_t)slots * prm.table_words * 4 + 64);
 	u8* d_out = io.d_out;
 	size_t o_out = 0;
@@ -878,9 +924,9 @@ size_t estimate_decode_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
 {
 	size_t tot = 0;
 	for (u32 i = 0; i < n; ++i) tot += (size_t)sizes[i] + 4096;
-	const u64 budget = (u64)32768 << 20;
 	const u64 tw = dec_table_words(h->set) * 4;
-	return tot * 12 + (size_t)std::min<u64>(budget, tw * n) + (size_t)n * (2u << 20) + (16u << 20);
+	const size_t other = tot * 12 + (size_t)n * (2u << 20) + (16u << 20);
+	return other + (size_t)std::min<u64>(dec_table_budget(h, other), tw * n);
 }
 
 // The reference's compressing worker decodes every block it has just written and compares the checksums
@@ -981,10 +1027,16 @@ void dsrcgpu_destroy(dsrcgpu_handle* h)
 {
 	if (!h) return;
 	(void)hipSetDevice(h->device);
-	for (auto& d : h->done) free(d.block);
+	if (h->q_started)
+	{
+		{ std::lock_guard<std::mutex> g(h->q_m); h->q_stop = true; h->q_cv.notify_all(); }
+		h->q_thread.join();
+	}
+	for (QBatch& b : h->qb) { if (b.in) hipHostFree(b.in); if (b.out) hipHostFree(b.out); }
 	if (h->arena.base) hipFree(h->arena.base);
 	if (h->d_crc_tab) hipFree(h->d_crc_tab);
 	for (int i = 0; i < 5; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
+	for (hipEvent_t e : h->stage_ev) hipEventDestroy(e);
 	if (h->rc_stream) hipStreamDestroy(h->rc_stream);
 	if (h->stream) hipStreamDestroy(h->stream);
 	delete h;
@@ -1089,35 +1141,118 @@ int dsrcgpu_compress_block(dsrcgpu_handle* h, const uint8_t* fastq, uint64_t siz
 	return dsrcgpu_compress_batch(h, 1, ins, &size, block, block_cap, &off, block_size, raw_sizes, comp_sizes);
 }
 
+namespace
+{
+int pinned_grow(u8*& p, u64& cap, u64 used, u64 need)
+{
+	if (need <= cap) return DSRCGPU_OK;
+	u64 want = std::max<u64>(need + need / 4, (u64)64 << 20);
+	void* q = nullptr;
+	if (hipHostMalloc(&q, want, hipHostMallocPortable) != hipSuccess) return DSRCGPU_E_NOMEM;
+	if (p) { if (used) memcpy(q, p, used); hipHostFree(p); }
+	p = (u8*)q; cap = want;
+	return DSRCGPU_OK;
+}
+
+// the handle's scheduler thread: runs queued batches in order through the synchronous batch entry point
+void queue_thread(dsrcgpu_handle* h)
+{
+	(void)hipSetDevice(h->device);
+	for (;;)
+	{
+		u32 k;
+		{
+			std::unique_lock<std::mutex> g(h->q_m);
+			h->q_cv.wait(g, [&] { return h->q_stop || !h->q_run.empty(); });
+			if (h->q_run.empty()) return;
+			k = h->q_run.front(); h->q_run.pop_front();
+		}
+		QBatch& b = h->qb[k];
+		const u32 n = (u32)b.ids.size();
+		std::vector<const uint8_t*> ptrs(n);
+		for (u32 i = 0; i < n; ++i) ptrs[i] = b.in + b.in_off[i];
+		b.o_offs.assign(n, 0); b.o_sizes.assign(n, 0); b.raw.assign(4 * n, 0); b.comp.assign(4 * n, 0);
+		u64 cap = b.in_used * 2 / 5 + (u64)n * (1u << 16);       // typical ratio 0.2-0.33; the worst case once if that is short
+		int rc = DSRCGPU_OK;
+		for (int attempt = 0; attempt < 2; ++attempt)
+		{
+			rc = pinned_grow(b.out, b.out_cap, 0, cap);
+			if (rc) { h->err = "cannot allocate page-locked output memory"; break; }
+			rc = dsrcgpu_compress_batch(h, n, ptrs.data(), b.sizes.data(), b.out, b.out_cap, b.o_offs.data(), b.o_sizes.data(), b.raw.data(), b.comp.data());
+			if (rc != DSRCGPU_E_CAPACITY) break;
+			cap = b.in_used + (u64)n * (1u << 16);
+		}
+		std::lock_guard<std::mutex> g(h->q_m);
+		b.rc = rc; if (rc) { b.err = h->err; if (!h->q_rc) { h->q_rc = rc; h->q_err = b.err; } }
+		b.state = QBatch::Done; b.next_collect = 0; b.outstanding = 0;
+		h->q_cv.notify_all();
+	}
+}
+
+int queue_collect(dsrcgpu_handle* h, bool wait, int64_t* part_id, uint8_t** block, uint64_t* block_size, uint64_t raw_sizes[4], uint64_t comp_sizes[4])
+{
+	std::unique_lock<std::mutex> g(h->q_m);
+	for (;;)
+	{
+		// the batch to collect from: the oldest flushed one that still has blocks to hand out
+		while (h->q_pending)
+		{
+			const QBatch& c = h->qb[h->q_collect];
+			const bool spent = c.state == QBatch::Free || (c.state == QBatch::Done && !c.rc && c.next_collect == c.ids.size());
+			if (!spent) break;
+			h->q_collect = (h->q_collect + 1) % DSRC_QUEUE_DEPTH; --h->q_pending;
+		}
+		if (!h->q_pending) return 0;                          // nothing flushed that has not been collected
+		QBatch& b = h->qb[h->q_collect];
+		if (b.state == QBatch::Queued)
+		{
+			if (!wait) return 0;
+			h->q_cv.wait(g, [&] { return b.state != QBatch::Queued; });
+			continue;
+		}
+		if (b.rc) return fail(h, b.rc, "%s", b.err.c_str());
+		const u32 i = b.next_collect++;
+		++b.outstanding;
+		*part_id = b.ids[i]; *block = b.out + b.o_offs[i]; *block_size = b.o_sizes[i];
+		for (int k = 0; k < 4; ++k) { if (raw_sizes) raw_sizes[k] = b.raw[4 * i + k]; if (comp_sizes) comp_sizes[k] = b.comp[4 * i + k]; }
+		return 1;
+	}
+}
+} // namespace
+
 int dsrcgpu_submit(dsrcgpu_handle* h, int64_t part_id, const uint8_t* fastq, uint64_t size)
 {
 	if (!h) return DSRCGPU_E_ARG;
 	if (!fastq || size == 0) return fail(h, DSRCGPU_E_ARG, "empty chunk");
-	Pending p; p.part_id = part_id; p.data.assign(fastq, fastq + size);
-	h->pending.push_back(std::move(p));
+	std::unique_lock<std::mutex> g(h->q_m);
+	if (h->q_rc) return fail(h, h->q_rc, "%s", h->q_err.c_str());
+	QBatch* b = &h->qb[h->q_fill];
+	if (b->state != QBatch::Filling)
+	{	// a ring slot is free again once every block of the batch it held has been released
+		h->q_cv.wait(g, [&] { return h->qb[h->q_fill].state == QBatch::Free || h->q_rc; });
+		if (h->q_rc) return fail(h, h->q_rc, "%s", h->q_err.c_str());
+		b->state = QBatch::Filling; b->ids.clear(); b->in_off.clear(); b->sizes.clear(); b->in_used = 0;
+	}
+	const u64 at = (b->in_used + 255) & ~(u64)255;
+	if (pinned_grow(b->in, b->in_cap, b->in_used, at + size + 256) != DSRCGPU_OK) return fail(h, DSRCGPU_E_NOMEM, "cannot allocate page-locked staging memory");
+	g.unlock();
+	memcpy(b->in + at, fastq, size);                          // only the submitter touches a Filling batch
+	b->ids.push_back(part_id); b->in_off.push_back(at); b->sizes.push_back(size); b->in_used = at + size;
 	return DSRCGPU_OK;
 }
 
 int dsrcgpu_flush(dsrcgpu_handle* h)
 {
 	if (!h) return DSRCGPU_E_ARG;
-	const u32 n = (u32)h->pending.size();
-	if (n == 0) return DSRCGPU_OK;
-	std::vector<const uint8_t*> ins(n); std::vector<u64> sizes(n), offs(n), osz(n), raw(4 * n), comp(4 * n);
-	u64 cap = 0;
-	for (u32 i = 0; i < n; ++i) { ins[i] = h->pending[i].data.data(); sizes[i] = h->pending[i].data.size(); cap += sizes[i] + (1u << 16); }
-	std::vector<u8> out(cap);
-	int rc = dsrcgpu_compress_batch(h, n, ins.data(), sizes.data(), out.data(), cap, offs.data(), osz.data(), raw.data(), comp.data());
-	if (rc) return rc;
-	for (u32 i = 0; i < n; ++i)
-	{
-		Done d; d.part_id = h->pending[i].part_id; d.size = osz[i];
-		d.block = (u8*)malloc(osz[i] ? osz[i] : 1);
-		memcpy(d.block, out.data() + offs[i], osz[i]);
-		for (int k = 0; k < 4; ++k) { d.raw[k] = raw[4 * i + k]; d.comp[k] = comp[4 * i + k]; }
-		h->done.push_back(d);
-	}
-	h->pending.clear();
+	std::unique_lock<std::mutex> g(h->q_m);
+	if (h->q_rc) return fail(h, h->q_rc, "%s", h->q_err.c_str());
+	QBatch& b = h->qb[h->q_fill];
+	if (b.state != QBatch::Filling || b.ids.empty()) return DSRCGPU_OK;
+	if (!h->q_started) { h->q_started = true; h->q_thread = std::thread(queue_thread, h); }
+	b.state = QBatch::Queued; ++h->q_pending;
+	h->q_run.push_back(h->q_fill);
+	h->q_fill = (h->q_fill + 1) % DSRC_QUEUE_DEPTH;
+	h->q_cv.notify_all();
 	return DSRCGPU_OK;
 }
 
@@ -1125,14 +1260,28 @@ int dsrcgpu_collect(dsrcgpu_handle* h, int64_t* part_id, uint8_t** block, uint64
 {
 	if (!h) return DSRCGPU_E_ARG;
 	if (!part_id || !block || !block_size) return fail(h, DSRCGPU_E_ARG, "null argument");
-	if (h->done.empty()) return 0;
-	Done d = h->done.front(); h->done.pop_front();
-	*part_id = d.part_id; *block = d.block; *block_size = d.size;
-	for (int k = 0; k < 4; ++k) { if (raw_sizes) raw_sizes[k] = d.raw[k]; if (comp_sizes) comp_sizes[k] = d.comp[k]; }
-	return 1;
+	return queue_collect(h, true, part_id, block, block_size, raw_sizes, comp_sizes);
 }
 
-int dsrcgpu_release(dsrcgpu_handle* h, uint8_t* block) { (void)h; free(block); return DSRCGPU_OK; }
+int dsrcgpu_try_collect(dsrcgpu_handle* h, int64_t* part_id, uint8_t** block, uint64_t* block_size, uint64_t raw_sizes[4], uint64_t comp_sizes[4])
+{
+	if (!h) return DSRCGPU_E_ARG;
+	if (!part_id || !block || !block_size) return fail(h, DSRCGPU_E_ARG, "null argument");
+	return queue_collect(h, false, part_id, block, block_size, raw_sizes, comp_sizes);
+}
+
+int dsrcgpu_release(dsrcgpu_handle* h, uint8_t* block)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	std::lock_guard<std::mutex> g(h->q_m);
+	for (QBatch& b : h->qb)
+		if (b.state == QBatch::Done && b.out && block >= b.out && block < b.out + b.out_cap && b.outstanding)
+		{
+			if (--b.outstanding == 0 && b.next_collect == b.ids.size()) { b.state = QBatch::Free; h->q_cv.notify_all(); }
+			return DSRCGPU_OK;
+		}
+	return fail(h, DSRCGPU_E_ARG, "dsrcgpu_release: not a block handed out by dsrcgpu_collect");
+}
 
 int dsrcgpu_selftest(dsrcgpu_handle* h, uint32_t* mismatches)
 {
@@ -1168,11 +1317,45 @@ int dsrcgpu_set_chain(dsrcgpu_handle* h, dsrcgpu_chain* c, uint64_t seq)
 	return DSRCGPU_OK;
 }
 
+int dsrcgpu_chain_seed(dsrcgpu_chain* c, uint32_t fields_capacity)
+{
+	if (!c) return DSRCGPU_E_ARG;
+	std::lock_guard<std::mutex> g(c->m);
+	if (c->next_seq != 0) return DSRCGPU_E_STATE;
+	c->fields_cap = fields_capacity;
+	return DSRCGPU_OK;
+}
+
+int dsrcgpu_set_fields_capacity(dsrcgpu_handle* h, uint32_t cap) { if (!h) return DSRCGPU_E_ARG; h->fields_cap = cap; return DSRCGPU_OK; }
+int dsrcgpu_get_fields_capacity(const dsrcgpu_handle* h, uint32_t* cap) { if (!h || !cap) return DSRCGPU_E_ARG; *cap = h->fields_cap; return DSRCGPU_OK; }
+
+// TagAnalyzer::InitializeFieldsStats' field split (src/TagModeler.cpp:159-222) on the title the compressor will see,
+// i.e. after FastqParserExt's rewrite when a field filter is set (src/FastqParser.cpp:198-251)
+uint32_t dsrcgpu_title_fields(const uint8_t* title, uint32_t len, uint64_t tag_preserve_flags)
+{
+	auto is_sep = [](uint8_t c) { return c == ' ' || c == '.' || c == '_' || c == ',' || c == '=' || c == ':' || c == '/' || c == '-' || c == '#' || c == 0; };
+	uint32_t seps = 0;
+	for (uint32_t i = 0; i < len; ++i) seps += is_sep(title[i]) ? 1u : 0u;
+	if (!tag_preserve_flags) return seps + 1;
+	// kept fields are copied with their end byte; every kept field but the title's last one ends in a separator, and the
+	// tokenizer adds the field after the last separator
+	uint32_t kept = 0;
+	for (uint32_t k = 1; k <= seps && k < 31; ++k) kept += (tag_preserve_flags >> k) & 1u;
+	return kept + 1;
+}
+
+uint32_t dsrcgpu_fields_capacity_after(uint32_t cap, uint32_t n_fields)
+{
+	for (uint32_t i = 0; i < n_fields; ++i) if (i == cap) cap = cap ? cap * 2 : 1;
+	return cap;
+}
+
 int dsrcgpu_host_alloc(uint64_t bytes, void** out)
 {
 	if (!out) return DSRCGPU_E_ARG;
 	*out = nullptr;
-	return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? DSRCGPU_OK : DSRCGPU_E_NOMEM;
+	// portable: the same buffer feeds scheduler instances on any device of the node
+	return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable) == hipSuccess ? DSRCGPU_OK : DSRCGPU_E_NOMEM;
 }
 
 int dsrcgpu_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? DSRCGPU_OK : DSRCGPU_E_HIP; }
@@ -1183,6 +1366,14 @@ int dsrcgpu_last_timing(const dsrcgpu_handle* h, float* batch_ms, float* rc_ms, 
 	if (batch_ms) *batch_ms = h->batch_ms;
 	if (rc_ms) *rc_ms = h->rc_ms;
 	if (rc_launches) *rc_launches = h->rc_launches;
+	return DSRCGPU_OK;
+}
+
+int dsrcgpu_last_stage_timing(const dsrcgpu_handle* h, float* sort_ms, float* replay_ms)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	if (sort_ms) *sort_ms = h->sort_ms;
+	if (replay_ms) *replay_ms = h->replay_ms;
 	return DSRCGPU_OK;
 }
 

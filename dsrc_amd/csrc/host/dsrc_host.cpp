@@ -315,7 +315,7 @@ bool DsrcCompressorGPU::ProcessStream(const InputParameters& args, FILE* in)
 }
 
 
-dsrcgpu_handle* DsrcCompressorGPU::CreateInstance(const InputParameters& args, const CompressionSettings& settings, const fq::FastqDatasetType& type)
+dsrcgpu_handle* DsrcCompressorGPU::CreateInstance(const InputParameters& args, const CompressionSettings& settings, const fq::FastqDatasetType& type, int device)
 {
 	dsrcgpu_settings gs; memset(&gs, 0, sizeof(gs));
 	gs.dna_order = settings.dnaOrder; gs.quality_order = settings.qualityOrder; gs.tag_preserve_flags = settings.tagPreserveFlags;
@@ -324,7 +324,7 @@ dsrcgpu_handle* DsrcCompressorGPU::CreateInstance(const InputParameters& args, c
 	dsrcgpu_dataset gd; memset(&gd, 0, sizeof(gd));
 	gd.quality_offset = type.qualityOffset; gd.plus_repetition = type.plusRepetition; gd.color_space = type.colorSpace;
 	dsrcgpu_handle* h = nullptr;
-	if (dsrcgpu_create(&gs, &gd, args.device, 0, &h) != DSRCGPU_OK)
+	if (dsrcgpu_create(&gs, &gd, device >= 0 ? device : args.device, 0, &h) != DSRCGPU_OK)
 	{
 		const std::string msg = h ? dsrcgpu_last_error(h) : "cannot create the GPU compressor";
 		if (h) dsrcgpu_destroy(h);
@@ -391,21 +391,25 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 
 		const uint32 batch = args.batchBlocks ? args.batchBlocks : (uint32)std::max<uint64>(1, (1536ull << 20) / bufSize);
 		const uint64 nBatchesMax = (fileSize / bufSize + batch) / batch;
-		const uint32 instances = (uint32)std::max<uint64>(1, std::min<uint64>(std::min<uint32>(std::max(1u, args.threadNum), 8u), nBatchesMax));
+		// Several GPUs of one node: threadNum instances per device, all on the same work queue and the same
+		// chain -- the chain lives in host memory, so the state of batch s reaches batch s+1 whichever device runs it, and
+		// the archive is still the one `dsrc c -t1` writes.  No device-to-device traffic: blocks go to the ordered writer.
+		const std::vector<int> devs = args.devices.empty() ? std::vector<int>(1, args.device) : args.devices;
+		const uint32 instances = (uint32)std::max<uint64>(1, std::min<uint64>((uint64)std::min<uint32>(std::max(1u, args.threadNum), 8u) * devs.size(), nBatchesMax));
 		if (dsrcgpu_chain_create(&chain) != DSRCGPU_OK) throw DsrcException("cannot create the batch chain");
 		writer.Start(args.outputFilename);
 
 		const bool trace = getenv("DSRC_HOST_TRACE") != nullptr;
 		const auto tStart = std::chrono::steady_clock::now();
 		// ---- workers ------------------------------------------------------------------------------------------
-		auto work = [&](uint32 /*idx*/)
+		auto work = [&](uint32 idx)
 		{
 			dsrcgpu_handle* h = nullptr;
 			Pinned out[2];
 			std::vector<Job*> inFlight(2, nullptr);       // the job whose blocks still sit in out[k]
 			try
 			{
-				h = CreateInstance(args, settings, type);
+				h = CreateInstance(args, settings, type, devs[idx % devs.size()]);
 				for (uint32 turn = 0;; ++turn)
 				{
 					Job* job = nullptr;
@@ -697,15 +701,16 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 			}
 			if (lo < nBlocks) batches.emplace_back(lo, nBlocks);
 		}
-		const uint32 instances = (uint32)std::max<uint64>(1, std::min<uint64>(std::min<uint32>(std::max(1u, args.threadNum), 8u), batches.size()));
+		const std::vector<int> devs = args.devices.empty() ? std::vector<int>(1, args.device) : args.devices;
+		const uint32 instances = (uint32)std::max<uint64>(1, std::min<uint64>((uint64)std::min<uint32>(std::max(1u, args.threadNum), 8u) * devs.size(), batches.size()));
 		uint64 next = 0, writeTurn = 0;
 
-		auto work = [&]()
+		auto work = [&](uint32 idx)
 		{
 			dsrcgpu_handle* h = nullptr;
 			try
 			{
-				h = CreateDecodeInstance(args.device, rd.Settings(), rd.Type());
+				h = CreateDecodeInstance(devs[idx % devs.size()], rd.Settings(), rd.Type());
 				Pinned in, text;
 				for (;;)
 				{
@@ -766,7 +771,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 			catch (const std::exception& e) { std::lock_guard<std::mutex> g(m); if (error.empty()) error = e.what(); cv.notify_all(); }
 			if (h) dsrcgpu_destroy(h);
 		};
-		for (uint32 i = 0; i < instances; ++i) workers.emplace_back(work);
+		for (uint32 i = 0; i < instances; ++i) workers.emplace_back(work, i);
 		for (auto& t : workers) t.join();
 		workers.clear();
 		if (!error.empty()) throw DsrcException(error);

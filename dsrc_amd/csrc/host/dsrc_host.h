@@ -82,6 +82,7 @@ struct InputParameters          // src/Common.h:149-193, plus the GPU knobs at t
 	std::string outputFilename;
 	// GPU path
 	int device = 0;
+	std::vector<int> devices;      // more than one: scheduler instances are spread over these GPUs of the node (threadNum instances EACH); one archive
 	uint32 batchBlocks = 0;        // chunks per scheduler pass; 0 = as many as fit ~1.5 GiB of input
 };
 
@@ -111,7 +112,7 @@ class DsrcCompressorGPU : public IDsrcOperator
 {
 public:
 	bool Process(const InputParameters& args_);
-	static dsrcgpu_handle* CreateInstance(const InputParameters& args_, const CompressionSettings& settings_, const fq::FastqDatasetType& type_);
+	static dsrcgpu_handle* CreateInstance(const InputParameters& args_, const CompressionSettings& settings_, const fq::FastqDatasetType& type_, int device_ = -1);
 private:
 	bool ProcessStream(const InputParameters& args_, FILE* in_);      // stdin / pipes: one scheduler instance
 	void LogSizes(const ArchiveWriter& writer_);

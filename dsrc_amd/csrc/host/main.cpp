@@ -1,7 +1,7 @@
 // dsrc-amd: command line of the MI355X DSRC path.  Same modes and switches as the reference's `dsrc`
 // (src/main.cpp:94-308): `c` with -d<n> -q<n> -l -c -f<..> -o<n> -b<n> -m<n>, `d`, and for both -t<n> -s -v.
 // Here -t<n> is the number of GPU scheduler instances (host threads working on consecutive batches, 1..8 are used;
-// the range check is the reference's 1..64); extra switches: -g<device>, -n<blocks per batch>,
+// the range check is the reference's 1..64) PER DEVICE; extra switches: -g<device>[,<device>..] (GPUs of the node to use), -n<blocks per batch>,
 // -x (with -c: store the checksums but skip the decode-and-compare pass the reference runs after every block).
 #include <cstdlib>
 #include <cstring>
@@ -15,7 +15,7 @@ static int usage()
 {
 	std::cerr << "usage: dsrc-amd <c|d> [options] <input filename> <output filename>\n"
 				 "compression options: -d<0-3> -q<0-2> -f<1,..> -b<MB> -o<offset> -l -c -m<0-2>\n"
-				 "both: -t<n> (GPU scheduler instances) -s (stdin/stdout for raw FASTQ) -v   GPU: -g<device> -n<blocks per batch> -x (no verify pass with -c)\n";
+				 "both: -t<n> (GPU scheduler instances) -s (stdin/stdout for raw FASTQ) -v   GPU: -g<device>[,<device>..] -n<blocks per batch> -x (no verify pass with -c)\n";
 	return -1;
 }
 
@@ -62,7 +62,15 @@ int main(int argc, const char* argv[])
 		case 'x': p.verifyCrc32 = false; break;
 		case 's': p.useFastqStdIo = true; break;
 		case 'v': verbose = true; break;
-		case 'g': p.device = v; break;
+		case 'g':       // -g<dev>[,<dev>..]: GPUs of this node to spread the scheduler instances over
+		{
+			const char* q = a + 2;
+			p.devices.clear();
+			while (*q) { p.devices.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+			if (p.devices.empty()) { std::cerr << "Error: -g needs a device number\n"; return -1; }
+			p.device = p.devices[0];
+			break;
+		}
 		case 'n': p.batchBlocks = (uint32)v; break;
 		case 'm':
 			if (v == 2) { p.dnaCompressionLevel = 3; p.qualityCompressionLevel = 2; p.fastqBufferSizeMB = 256; }

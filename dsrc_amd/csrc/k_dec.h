@@ -33,6 +33,7 @@ struct DecParams
 	u32 dna_order, quality_order, lossy, crc, quality_offset;
 	u32 n_blocks, tag_flags, plus_rep, color_space;
 	u32 table_words;           // u32 words per model-table slot
+	u32 serial_quality;        // 1: the order-context quality decoder runs on one lane (DSRC_GPU_DEC_SERIAL; tests, comparison)
 };
 
 struct DecDesc          // host -> device
@@ -602,6 +603,101 @@ __device__ void qua_order_decode(BitSrc& s, u16* tab, u32 ord, u32 rescale, cons
 	S->d_total = d_total;
 }
 
+// floor(n / d) for the range decoder: n < 2^53 on every valid stream (buffer < range x total), so one f64 division is at
+// most one off and two integer checks make it exact; larger numerators (corrupt data) take the integer division
+__device__ __forceinline__ u32 div_u64_u32(u64 n, u32 d)
+{
+	if (n >> 52) return (u32)(n / d);
+	u64 q = (u64)((double)n / (double)d);
+	if (q * d > n) --q;
+	else if ((q + 1) * d <= n) ++q;
+	return (u32)q;
+}
+
+// The same decoder with the WAVE on one stream (N <= 64): lane i holds counter i of the current row, so the row is one
+// coalesced load, its total and the cumulative frequencies one prefix scan, the symbol search one ballot.  What stays
+// serial per symbol is a dependent row read (~0.4 us from HBM) plus ~100 instructions, instead of ~400 instructions that
+// one lane needs for a 32-counter row.  Counter traffic goes through workgroup-scope atomics (plain loads / stores that
+// are coherent within the CU): lane j reads counters that lane j' wrote a few symbols earlier.
+template <u32 N>
+__device__ void qua_order_decode_wave(BitSrc& s, u16* tab, u32 ord, u32 rescale, const u8* translate, u32 lossy,
+									  const DecDesc& d, DecState* S, RecPools rp, u8* text)
+{
+	const u32 lane = lane_id();
+	const u32 abits = dec_int_log2(N);
+	const u64 sym_mask = ((u64)1 << abits) - 1;
+	const u32 bits_lo = (ord / 2) * abits, bits_hi = (ord / 2 + 1) * abits;
+	const u64 lo_mask = bits_lo ? (((u64)1 << bits_lo) - 1) : 0;
+	const u64 hi_mask = ((u64)1 << bits_hi) - 1;
+	const u64 swap_mask = lo_mask | ~hi_mask;
+	const u64 hash_mask = ((u64)1 << (ord * abits)) - 1;
+	u64 hash = 0, sym_buf = 0;
+	RangeDec rd; rd_start(rd, s);
+	u32 d_total = 0;
+	const u32 n_recs = S->n_recs;
+	for (u32 k = 0; k < n_recs && !s.err; ++k)
+	{
+		const u64 g = (u64)d.rec_base + k;
+		const u32 ql = rp.len[g];
+		u8* q = text + rp.qual_off[g];
+		u32 ncount = 0, pctx = 0, rem = 0;            // pctx = j * rescale / ql, kept incrementally
+		for (u32 j = 0; j < ql; ++j)
+		{
+			const u64 h = ((hash & hash_mask) << abits) | pctx;
+			u16* row = tab + h * N;
+			u32 c = lane < N ? (u32)__hip_atomic_load(row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+			u32 incl = wave_incl_scan(c);
+			u32 acc = (u32)__shfl((int)incl, (int)(N - 1));
+			bool rescaled = false;
+			if (acc >= (1u << 16) - N * 2)
+			{	// TSymbolCoderRC::Rescale: the halved counters stay in the row
+				c -= c >> 1;
+				incl = wave_incl_scan(c);
+				acc = (u32)__shfl((int)incl, (int)(N - 1));
+				rescaled = true;
+			}
+			rd.range /= acc;
+			if (rd.range == 0) { s.err |= DEC_ERR_FORMAT; rd.range = 1; }
+			const u32 cul = div_u64_u32(rd.buffer, rd.range);
+			const u64 m = __ballot(lane < N && incl > cul);
+			u32 idx;
+			if (m == 0) { s.err |= DEC_ERR_FORMAT; idx = N - 1; }     // the reference walks off the row here
+			else idx = (u32)__ffsll((long long)m) - 1u;
+			const u32 f = (u32)__shfl((int)c, (int)idx);
+			const u32 hi = (u32)__shfl((int)incl, (int)idx) - f;
+			const u32 rr = hi * rd.range;                          // uint32 product
+			rd.buffer -= rr; rd.low += rr;
+			rd.range *= f;
+			while (rd.range <= 0x00FFFFFFu)
+			{
+				if ((rd.low ^ (rd.low + rd.range)) & 0xFF00000000000000ull)
+				{
+					const u32 lo = (u32)rd.low;
+					rd.range = (lo | 0x00FFFFFFu) - lo;
+				}
+				rd.buffer = (rd.buffer << 8) + bs_byte(s);
+				rd.low <<= 8; rd.range <<= 8;
+				if (rd.range == 0) { s.err |= DEC_ERR_FORMAT; rd.range = 0xFFFFFFFFu; break; }
+			}
+			if (lane == idx) __hip_atomic_store(row + lane, (u16)(c + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			else if (rescaled && lane < N) __hip_atomic_store(row + lane, (u16)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			const u32 qv = translate ? translate[idx] : idx;
+			if (lane == 0) q[j] = (u8)qv;
+			ncount += q_special(qv, lossy) ? 1u : 0u;
+			hash <<= abits;
+			const u64 next_buf = (hash >> bits_lo) & sym_mask;
+			const u64 swp = (next_buf + sym_buf) / 2;
+			hash &= swap_mask; hash |= swp << bits_lo; hash |= idx;
+			sym_buf = next_buf;
+			rem += rescale;
+			while (rem >= ql) { rem -= ql; ++pctx; }
+		}
+		if (lane == 0) { rp.kept[g] = (u16)(ql - ncount); rp.d_off[g] = d_total; }
+		d_total += ql - ncount;
+	}
+	if (lane == 0) S->d_total = d_total;
+}
+
 template <u32 N>
 __device__ void dna_order_decode(BitSrc& s, u16* tab, u32 ord, const DecDesc& d, DecState* S, RecPools rp, u8* dst)
 {
@@ -623,6 +719,7 @@ __global__ void __launch_bounds__(64) k_dec_streams(const u8* in, const DecDesc*
 {
 	__shared__ u8 s_sym[256];
 	__shared__ u32 s_flag;
+	__shared__ u32 s_par[5];
 	u32* table = tables + (u64)blockIdx.x * prm.table_words;
 	for (u32 b = blockIdx.x; b < prm.n_blocks; b += gridDim.x)
 	{
@@ -663,22 +760,44 @@ __global__ void __launch_bounds__(64) k_dec_streams(const u8* in, const DecDesc*
 			}
 			s_flag = (q_rc && !s.err) ? (qN | (q_ord << 8)) : 0u;
 		}
+		if (threadIdx.x == 0) { s_par[0] = q_rescale; s_par[1] = q_translate ? 1u : 0u; s_par[2] = (u32)s.bit; s_par[3] = (u32)(s.bit >> 32); s_par[4] = q_scheme; }
 		__syncthreads();
 		const u32 flag = s_flag;
+		bool q_done = false;
 		if (flag)
 		{
 			const u32 nn = flag & 0xFFu, ord = flag >> 8;
 			u32 ab = 0; for (u32 t = nn; t > 1; t >>= 1) ++ab;
 			const u64 words = ((u64)1 << (ab * (ord + 1))) * nn / 2;
 			if (words > prm.table_words) { if (threadIdx.x == 0) s.err |= DEC_ERR_POOL; }
-			else table_fill(table, words);
+			else
+			{
+				table_fill(table, words);
+				__syncthreads();
+				if (nn <= 64 && !prm.serial_quality)
+				{	// the whole wave decodes the quality stream
+					s.bit = ((u64)s_par[3] << 32) | s_par[2];
+					const u8* tr = s_par[1] ? s_sym : nullptr;
+					const u32 resc = s_par[0];
+					switch (nn)
+					{
+					case 8:   qua_order_decode_wave<8>(s, (u16*)table, ord, resc, tr, lossy, d, S, rp, text); break;
+					case 16:  qua_order_decode_wave<16>(s, (u16*)table, ord, resc, tr, lossy, d, S, rp, text); break;
+					case 32:  qua_order_decode_wave<32>(s, (u16*)table, ord, resc, tr, lossy, d, S, rp, text); break;
+					default:  qua_order_decode_wave<64>(s, (u16*)table, ord, resc, tr, lossy, d, S, rp, text); break;
+					}
+					if (threadIdx.x == 0) S->q_scheme = s_par[4];
+					q_done = true;
+				}
+			}
 		}
 		__syncthreads();
-		if (threadIdx.x == 0 && !s.err)
+		if (threadIdx.x == 0 && !s.err && q_done) S->dna_pos = bs_pos(s);
+		if (threadIdx.x == 0 && !s.err && !q_done)
 		{
 			S->q_scheme = q_scheme;
 			if (q_rc)
-			{
+			{	// 128-symbol alphabets (two counters per lane would be needed), or the one-lane decoder was asked for
 				const u8* tr = q_translate ? s_sym : nullptr;
 				switch (qN)
 				{

@@ -5,6 +5,12 @@ Blocks are independent given the chunk boundaries, so rank r compresses a contig
 no peer traffic.  The only exchange is the one the archive needs: the per-block sizes (they *are* the footer
 table, reference src/DsrcFile.cpp:142) are all-gathered, then every rank's compressed stream moves to rank 0
 over its direct link (point-to-point send/recv, no ring, no reduction).  Rank-major order is archive order.
+
+What a shard needs from the shards before it is one number: the capacity of the reference's TagStats::fields vector after
+all earlier chunks, which is a fold over the first title of every chunk
+(dsrc_amd._lib.fields_capacity_fold).  Every rank folds its own chunks, the per-rank results are all-gathered and rank r
+seeds its first scheduler instance with the fold of ranks 0..r-1 (exchange_fields_capacity) -- with that the gathered
+stream is byte for byte the archive `dsrc c -t1` writes.
 """
 from __future__ import annotations
 
@@ -58,3 +64,40 @@ def gather_block_stream(block_sizes: List[int], payload: torch.Tensor, group=Non
         for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, payload[:total].contiguous(), 0, group)]):
             w.wait()
     return None
+
+
+def exchange_fields_capacity(chunk_first_fields: List[int], group=None, device=None) -> int:
+    """Seed for this rank's first scheduler instance.  chunk_first_fields: for every chunk of this rank, in order, the
+    number of fields in the title of its first record (dsrcgpu_title_fields).  The capacity after a chunk is
+    f(cap, n) = cap doubled (from 1) until it exceeds n - 1, so folding f over any run of chunks only needs the run's
+    largest n: one int64 per rank is all-gathered and rank r folds the entries of ranks 0..r-1."""
+    world = dist.get_world_size(group); rank = dist.get_rank(group)
+    mine = torch.tensor([max(chunk_first_fields) if chunk_first_fields else 0], dtype=torch.int64, device=device)
+    allv = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(allv, mine, group=group)
+    cap = 0
+    for r in range(rank):
+        cap = _capacity_after(cap, int(allv[r][0]))
+    return cap
+
+
+def _capacity_after(cap: int, n_fields: int) -> int:
+    for i in range(n_fields):
+        if i == cap:
+            cap = cap * 2 if cap else 1
+    return cap
+
+
+def archive_bytes(block_sizes: List[int], payloads: List[bytes], *, dna_order: int, quality_order: int, lossy: bool, crc: bool,
+                  tag_flags: int, quality_offset: int, plus_repetition: bool, color_space: bool) -> bytes:
+    """Rank 0: header + gathered blocks + footer = the .dsrc file (DsrcFileWriter, reference src/DsrcFile.cpp:112-170).
+    Header: AA 02 00 02, footer size (BE32), footer offset (BE64), records (0), block count (BE64), AA x 8.
+    Footer: CC, block sizes (host-endian uint32 array), dataset flags, quality offset, compression flags, orders, -f mask."""
+    import struct
+    body = b"".join(payloads)
+    assert len(body) == sum(block_sizes)
+    foot = b"\xCC" + struct.pack("<%dI" % len(block_sizes), *block_sizes)
+    foot += bytes([(2 if color_space else 0) | (1 if plus_repetition else 0), quality_offset,
+                   (1 if lossy else 0) | (2 if crc else 0), dna_order, quality_order]) + struct.pack(">Q", tag_flags)
+    head = b"\xAA\x02\x00\x02" + struct.pack(">IQQQ", len(foot), 40 + len(body), 0, len(block_sizes)) + b"\xAA" * 8
+    return head + body + foot

@@ -117,15 +117,23 @@ int dsrcgpu_decompress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d
 									uint64_t* text_offs, uint64_t* text_sizes, uint32_t* crc_ok);
 
 /* Queue form of DsrcCompressor::Process (src/DsrcWorker.cpp:39-70):
- *   fastqQueue.Pop(partId, chunk)            -> dsrcgpu_submit(partId, chunk)      (chunk bytes are copied)
+ *   fastqQueue.Pop(partId, chunk)            -> dsrcgpu_submit(partId, chunk)      (bytes are copied into page-locked staging)
  *   ... Store ... dsrcQueue.Push(partId, blk) -> dsrcgpu_collect(&partId, &blk, ...)
  *   dsrcPool.Release(blk)                    -> dsrcgpu_release(blk)
- * dsrcgpu_flush runs everything submitted so far; dsrcgpu_collect returns 1 and a block while results are
- * pending (in partId order of submission), 0 when drained. */
+ * Asynchronous: dsrcgpu_flush hands everything submitted since the last flush to the handle's scheduler thread as one
+ * batch and returns; up to two batches run / wait while a third is being filled (submit blocks when all three are
+ * busy, i.e. until the blocks of the oldest batch have been released).  Blocks come back in submission order:
+ * dsrcgpu_collect returns 1 and a block (a pointer into page-locked memory owned by the handle, valid until
+ * dsrcgpu_release), waits while a flushed batch is still running, and returns 0 when everything flushed has been
+ * collected; dsrcgpu_try_collect never waits (0 = nothing ready right now).  A batch that failed makes the next call
+ * return its error.  One submitter thread and one collector thread may use a handle concurrently; the batch calls above
+ * must not be mixed in while batches are in flight.  Block-to-block state follows submission order (`dsrc c -t1`). */
 int dsrcgpu_submit(dsrcgpu_handle* h, int64_t part_id, const uint8_t* fastq, uint64_t size);
 int dsrcgpu_flush(dsrcgpu_handle* h);
 int dsrcgpu_collect(dsrcgpu_handle* h, int64_t* part_id, uint8_t** block, uint64_t* block_size,
 					uint64_t raw_sizes[4], uint64_t comp_sizes[4]);
+int dsrcgpu_try_collect(dsrcgpu_handle* h, int64_t* part_id, uint8_t** block, uint64_t* block_size,
+						uint64_t raw_sizes[4], uint64_t comp_sizes[4]);
 int dsrcgpu_release(dsrcgpu_handle* h, uint8_t* block);
 
 /* Several handles may compress consecutive batches of ONE archive at the same time (one host thread each); this is
@@ -139,6 +147,18 @@ typedef struct dsrcgpu_chain dsrcgpu_chain;
 int dsrcgpu_chain_create(dsrcgpu_chain** out);
 void dsrcgpu_chain_destroy(dsrcgpu_chain* c);
 int dsrcgpu_set_chain(dsrcgpu_handle* h, dsrcgpu_chain* c, uint64_t seq);
+
+/* Sharding one archive over several devices or processes.  Chunk ranges are independent except for the one
+ * value above, which after a chunk is a pure function of the value before it and the number of fields in the title of
+ * the chunk's first record:  cap' = dsrcgpu_fields_capacity_after(cap, dsrcgpu_title_fields(title, len, flags)).
+ * So a shard that starts at chunk k needs only the fold of that function over the first titles of chunks 0..k-1 -- a
+ * host-side pass over one line per chunk (or an exclusive scan of one uint32 across ranks, dsrc_amd/dist.py) -- to write
+ * exactly the blocks `dsrc c -t1` writes: seed the first handle (or the chain) of the shard with it. */
+uint32_t dsrcgpu_title_fields(const uint8_t* title, uint32_t len, uint64_t tag_preserve_flags);
+uint32_t dsrcgpu_fields_capacity_after(uint32_t cap, uint32_t n_fields);
+int dsrcgpu_set_fields_capacity(dsrcgpu_handle* h, uint32_t cap);
+int dsrcgpu_get_fields_capacity(const dsrcgpu_handle* h, uint32_t* cap);
+int dsrcgpu_chain_seed(dsrcgpu_chain* c, uint32_t fields_capacity);      /* before batch 0 of the chain has run */
 
 /* Record-level API (reference: wrap::BlockCompressorExt::WriteNextRecord/Flush, src/BlockCompressorExt.cpp:20-46,65-127,
  * used by wrap::DsrcArchive, src/DsrcArchive.cpp:129-150,217-224).  The caller assembles each chunk as FASTQ text
@@ -164,6 +184,10 @@ int dsrcgpu_selftest(dsrcgpu_handle* h, uint32_t* mismatches);
 /* Timing of the last batch measured with HIP events on the scheduler's stream: total ms of the batch's
  * kernels, ms of the range-coder kernel (k_rc), number of k_rc launches. */
 int dsrcgpu_last_timing(const dsrcgpu_handle* h, float* batch_ms, float* rc_ms, uint32_t* rc_launches);
+
+/* ... and of the two data-parallel stages that bound the throughput of the order-context levels: summed HIP-event time
+ * of the k_sort launches (context sort) and of the k_replay_seams + k_replay launches (model replay) of the last batch. */
+int dsrcgpu_last_stage_timing(const dsrcgpu_handle* h, float* sort_ms, float* replay_ms);
 
 /* Counter-based synthetic Illumina-like FASTQ generated directly in HBM (bench input; same bytes as
  * dsrc_amd/synth.py illumina_fastq).  Writes records first..first+count-1, returns the byte count. */

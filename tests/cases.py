@@ -126,3 +126,20 @@ def rle_chunks():
             recs.append(b"@r.%d x\n" % i + seq + b"\n+\n" + bytes(q))
         out.append(b"\n".join(recs))
     return out
+
+
+def state_dependent_fastq(n_per_region: int = 9000):
+    """A file whose archive depends on the state DSRC carries from block to block (the capacity of TagStats::fields,
+    DESIGN.md section 1): regions of ~1 MB whose titles have 5, 9, 17, 9, 3 and 17 fields, all numeric fields coded
+    ValueVar + Huffman.  With -b1 every region becomes one or two blocks."""
+    rng = random.Random(2024)
+    out = []
+    first = 1
+    for nf in (5, 9, 17, 9, 3, 17):
+        for i in range(n_per_region):
+            title = b"@r.%d" % (first + i) + b"".join(b":%d" % ((7 * i + k) % 90 + 10) for k in range(nf - 2))
+            seq = bytes(rng.choice(b"ACGT") for _ in range(36))
+            qua = bytes(33 + rng.randint(20, 40) for _ in range(36))
+            out += [title, b"\n", seq, b"\n+\n", qua, b"\n"]
+        first += n_per_region
+    return b"".join(out)

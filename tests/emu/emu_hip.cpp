@@ -1,5 +1,6 @@
 // TEST INFRASTRUCTURE ONLY -- scheduler of the HIP emulator (see emu_hip.h).
 #include "emu_hip.h"
+#include <mutex>
 
 namespace emu
 {
@@ -32,8 +33,11 @@ static void trampoline()
 	swapcontext(&g_cur->ctx, &g_sched);
 }
 
+static std::mutex g_launch_mutex;      // one kernel at a time: host threads driving several handles take turns
+
 void launch(dim3 grid, dim3 block, const std::function<void()>& body)
 {
+	std::lock_guard<std::mutex> guard(g_launch_mutex);
 	const unsigned nt = block.x * block.y * block.z;
 	static std::vector<Thread> pool;
 	if (pool.size() < nt)

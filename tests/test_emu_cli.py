@@ -1,0 +1,65 @@
+"""The C++ host pipelines (dsrc_amd/csrc/host: DsrcCompressorGPU, DsrcDecompressorGPU behind the dsrc-amd CLI) on the CPU,
+linked against the HIP emulator build of the kernels (tests/emu/dsrc-amd-emu): archive identity with the reference's
+`dsrc c -t1` golden md5 on data whose blocks depend on block-to-block state -- with several scheduler instances spread
+over a device list -- and decompression back to the input.  Test harness only; the product links libdsrc_gpu.so."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+from dsrc_amd import synth
+from tests.cases import state_dependent_fastq
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_CLI = os.path.join(ROOT, "tests", "emu", "dsrc-amd-emu")
+G = json.load(open(os.path.join(ROOT, "tests", "golden", "state_golden.json")))
+
+
+@pytest.fixture(scope="module")
+def cli():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emu")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return EMU_CLI
+
+
+def md5(p):
+    return hashlib.md5(open(p, "rb").read()).hexdigest()
+
+
+def test_sharded_instances_write_the_t1_archive(cli, tmp_path):
+    data = state_dependent_fastq()
+    assert hashlib.sha256(data).hexdigest() == G["in_sha256"]
+    src = tmp_path / "state.fastq"; src.write_bytes(data)
+    a = G["archives"][0]
+    arc = tmp_path / "s.dsrc"; back = tmp_path / "back.fastq"
+    # two instances on each of two entries of the device list, one chunk per batch: every block on another instance
+    subprocess.check_call([cli, "c", *a["flags"], "-b1", "-n1", "-t2", "-g0,0", str(src), str(arc)])
+    assert (os.path.getsize(arc), md5(arc)) == (a["size"], a["md5"])
+    subprocess.check_call([cli, "d", "-n2", "-t2", "-g0,0", str(arc), str(back)])
+    assert back.read_bytes() == data
+
+
+@pytest.mark.parametrize("flags", [["-d1", "-q1", "-c"], ["-d2", "-q1", "-l"]])
+def test_round_trip_and_errors(cli, tmp_path, oracle, flags):
+    data = synth.illumina_fastq(500)
+    src = tmp_path / "a.fastq"; src.write_bytes(data)
+    arc = tmp_path / "a.dsrc"; back = tmp_path / "a.out"; ref_arc = tmp_path / "o.dsrc"
+    subprocess.check_call([cli, "c", *flags, str(src), str(arc)])
+    d = int(flags[0][2:]); q = int(flags[1][2:])
+    assert oracle.compress_file(str(src), str(ref_arc), d, q, "-l" in flags, "-c" in flags, 0, 8) == 0
+    assert md5(arc) == md5(ref_arc)
+    out = subprocess.run([cli, "d", "-s", str(arc)], capture_output=True, check=True).stdout
+    if "-l" not in flags:
+        assert out == data
+    else:
+        assert out.split(b"\n")[0::4] == data.split(b"\n")[0::4]
+    # a truncated archive and a non-archive are refused with the reference's messages, and no output is left behind
+    bad = tmp_path / "bad.dsrc"; bad.write_bytes(arc.read_bytes()[:100])
+    r = subprocess.run([cli, "d", str(bad), str(back)], capture_output=True)
+    assert r.returncode != 0 and b"Corrupted DSRC archive" in r.stderr and not back.exists()
+    bad.write_bytes(b"@not an archive\nACGT\n+\nIIII\n" * 4)
+    r = subprocess.run([cli, "d", str(bad), str(back)], capture_output=True)
+    assert r.returncode != 0 and b"Invalid archive" in r.stderr
+    r = subprocess.run([cli, "c", "-d7", str(src), str(arc)], capture_output=True)
+    assert r.returncode != 0 and b"invalid DNA compression mode" in r.stderr

@@ -11,6 +11,14 @@ from tests.cases import LEVELS, TINY, fuzz_fastq, fuzz_solid
 from tests.test_emu_kernels import emu  # noqa: F401  (fixture)
 
 
+@pytest.fixture(autouse=True)
+def one_lane_quality_decoder(request, monkeypatch):
+    """The wave-cooperative range decoder costs the emulator 64 context switches per symbol; most tests here use the
+    one-lane form of the same decoder (DSRC_GPU_DEC_SERIAL) and test_wave_decoder covers the cooperative one."""
+    if "wave" not in request.node.name:
+        monkeypatch.setenv("DSRC_GPU_DEC_SERIAL", "1")
+
+
 def handle(emu, cfg):
     return emu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset,
                       plus_repetition=cfg.plus_repetition, color_space=cfg.color_space, tag_flags=cfg.tag_flags)
@@ -125,3 +133,15 @@ def test_verify_after_compress(emu, oracle):
         h.compress_batch([bad])
     assert ei.value.code == -7 and "CRC32 checksums mismatch." in str(ei.value)
     h.close()
+
+
+@pytest.mark.parametrize("d,q,lossy", [(0, 2, False), (1, 1, False), (2, 1, True), (0, 2, True)])
+def test_wave_decoder(emu, oracle, d, q, lossy):
+    """qua_order_decode_wave (lane i = counter i; scan, ballot): 16-, 32- and 64-symbol alphabets, lossy 8, variable
+    lengths, and a context hot enough to rescale."""
+    import random
+    rng = random.Random(d * 10 + q)
+    few = b"\n".join(b"@h.%d\nACGT\n+\n%s" % (i, bytes(rng.choice(b"IIIIIIIH") for _ in range(4))) for i in range(2200))     # > 8k symbols in few contexts
+    wide = b"\n".join(b"@w.%d\n%s\n+\n%s" % (i, b"A" * (20 + i % 7), bytes(33 + rng.randrange(2, 62) for _ in range(20 + i % 7))) for i in range(60))
+    chunks = [synth.illumina_fastq(40)[:-1], few] + ([] if lossy else [wide])
+    check(emu, oracle, Config.from_levels(d, q, lossy), chunks)

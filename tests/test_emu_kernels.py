@@ -135,6 +135,79 @@ def test_chain_hands_state_between_handles(emu, oracle):
     assert alone != want[2]
 
 
+def test_queue_form_is_asynchronous_and_ordered(emu, oracle):
+    """submit / flush / collect / release: several batches flushed before anything is collected (the ring holds three), blocks
+    come back in submission order with the state carried across batches, try_collect never blocks, and a ring slot is
+    reused only after its blocks were released."""
+    import ctypes as C
+    chunks = [synth.illumina_fastq(30, first=1 + 30 * k)[:-1] for k in range(7)]
+    cfg = Config.from_levels(0, 1)
+    want = oracle.compress_blocks_state(cfg, chunks)
+    h = emu.Handle(cfg.dna_order, cfg.quality_order)
+    assert h.collect(wait=False) is None
+    for lo, hi in ((0, 2), (2, 3), (3, 5)):                     # three batches in flight
+        for i in range(lo, hi):
+            h.submit(100 + i, chunks[i])
+        h.flush()
+    got = []
+    while True:
+        r = h.collect()
+        if r is None:
+            break
+        got.append(r)
+    for i in (5, 6):                                            # the ring slots are free again: a fourth and fifth batch
+        h.submit(100 + i, chunks[i]); h.flush()
+    while True:
+        r = h.collect()
+        if r is None:
+            break
+        got.append(r)
+    h.close()
+    assert [g[0] for g in got] == [100 + i for i in range(7)]
+    assert [(g[1], g[2], g[3]) for g in got] == want
+
+
+def test_shard_seeding_gives_the_t1_blocks(emu, oracle):
+    """A handle that starts in the middle of an archive (another GPU / rank) is seeded with the fold of
+    dsrcgpu_fields_capacity_after over the first title of every chunk before its shard; its blocks are then those of one
+    handle fed everything in order.  Also with a field filter, where the field count is that of the rewritten title."""
+    import dataclasses
+    import random
+    rng = random.Random(12)
+
+    def fq(nf, n, first):
+        recs = []
+        for i in range(n):
+            title = f"@r.{first + i}" + "".join(f":{(7 * i + k) % 90 + 10}" for k in range(nf - 2))
+            seq = "".join(rng.choice("ACGT") for _ in range(30))
+            qua = "".join(chr(33 + rng.randint(20, 40)) for _ in range(30))
+            recs.append(f"{title}\n{seq}\n+\n{qua}")
+        return "\n".join(recs).encode()
+    chunks = [fq(5, 25, 1), fq(9, 25, 100), fq(9, 25, 200), fq(17, 25, 300), fq(3, 25, 400), fq(17, 25, 500)]
+    for flags in (0, 0b1111010):
+        cfg = dataclasses.replace(Config.from_levels(0, 0), tag_flags=flags)
+        want = [b for b, _, _ in oracle.compress_blocks_state(cfg, chunks)]
+        caps = [emu.fields_capacity_fold(chunks[:k], flags) for k in range(len(chunks) + 1)]
+        assert caps[-1] == oracle.last_fields_cap
+        got = []
+        for lo, hi in ((0, 2), (2, 3), (3, 6)):
+            h = emu.Handle(cfg.dna_order, cfg.quality_order, tag_flags=flags)
+            h.set_fields_capacity(caps[lo])
+            got += [r[0] for r in h.compress_batch(chunks[lo:hi])]
+            assert h.get_fields_capacity() == caps[hi]
+            h.close()
+        assert got == want, flags
+        if flags == 0:
+            h = emu.Handle(cfg.dna_order, cfg.quality_order)        # unseeded: the shard starts from an empty history
+            assert h.compress_batch(chunks[2:3])[0][0] != want[2]
+            h.close()
+            # a chain (several instances per device) that starts mid-archive
+            chain = emu.Chain(); chain.seed(caps[2])
+            h = emu.Handle(cfg.dna_order, cfg.quality_order); h.set_chain(chain, 0)
+            assert [r[0] for r in h.compress_batch(chunks[2:4])] == want[2:4]
+            h.close(); chain.close()
+
+
 def test_chain_survives_a_capacity_retry(emu, oracle):
     """A batch that comes back with DSRCGPU_E_CAPACITY has already taken its turn in the chain; announcing the same
     batch again and retrying with a larger buffer must neither wait for that turn a second time (it deadlocked) nor

@@ -187,3 +187,21 @@ def test_verify_pass_with_c(files):
     _run([CLI, "c", "-d3", "-q2", "-c", "-b1", "-n4", ill, a])
     _run([CLI, "c", "-d3", "-q2", "-c", "-x", "-b1", "-n4", ill, b])
     assert md5(a) == md5(b)
+
+
+def test_device_list_writes_the_t1_archive(tmp_path):
+    """-g<dev>,<dev>: scheduler instances spread over a device list (here the one GPU twice), one chunk per batch, on data
+    whose blocks depend on the block-to-block state: still the archive the reference writes with -t1 (golden md5)."""
+    import json
+    from tests.cases import state_dependent_fastq
+    if not os.path.exists(CLI):
+        pytest.skip("dsrc-amd not built")
+    G = json.load(open(os.path.join(ROOT, "tests", "golden", "state_golden.json")))
+    data = state_dependent_fastq()
+    src = tmp_path / "state.fastq"; src.write_bytes(data)
+    for a in G["archives"]:
+        arc = tmp_path / "s.dsrc"; back = tmp_path / "b.fastq"
+        _run([CLI, "c", *a["flags"], "-b1", "-n1", "-t3", "-g0,0", str(src), str(arc)])
+        assert (os.path.getsize(arc), md5(arc)) == (a["size"], a["md5"]), a
+        _run([CLI, "d", "-n1", "-t2", "-g0,0", str(arc), str(back)])
+        assert back.read_bytes() == data
