@@ -216,13 +216,49 @@ __device__ __forceinline__ u32 huff_sym(BitSrc& s, const u32* T)
 	return 0;
 }
 
+// floor(n / d) for the range decoder: n < 2^53 on every valid stream (buffer < range x total), so one f64 division is at
+// most one off and two integer checks make it exact; larger numerators (corrupt data) take the integer division
+__device__ __forceinline__ u32 div_u64_u32(u64 n, u32 d)
+{
+	if (n >> 52) return (u32)(n / d);
+	u64 q = (u64)((double)n / (double)d);
+	if (q * d > n) --q;
+	else if ((q + 1) * d <= n) ++q;
+	return (u32)q;
+}
+
 // ---- range decoder + adaptive rows: RangeDecoder (src/RangeCoder.h:90-142), TSymbolCoderRC<N>::DecodeSymbol
 // (src/SymbolCoderRC.h:50-91) -------------------------------------------------------------------------------------------
-struct RangeDec { u64 low, buffer; u32 range; };
+// The coder's byte source is a 16-byte look-ahead window over the block (w0 = the 8 bytes being consumed, w1 = the next 8,
+// requested when w0 is taken into use), so a renormalisation step costs a shift, not a dependent memory access.
+struct RangeDec { u64 low, buffer; u32 range; u64 w0, w1; u32 left; u64 next; };
+
+__device__ __forceinline__ u64 rd_window(const BitSrc& s, u64 byte_pos)          // 8 bytes at byte_pos, first byte in the top bits
+{
+	BitSrc t = s; t.bit = byte_pos * 8;
+	const u64 hi = bs_peek32(t);
+	t.bit += 32;
+	return (hi << 32) | (u64)bs_peek32(t);
+}
+__device__ __forceinline__ u32 rd_byte(RangeDec& d, BitSrc& s)
+{
+	if (d.left == 0) { d.w0 = d.w1; d.w1 = rd_window(s, d.next + 16); d.next += 8; d.left = 8; }     // next = first byte of w0
+	const u32 b = (u32)(d.w0 >> 56);
+	d.w0 <<= 8; --d.left;
+	return b;
+}
+// hands the stream position back to the bit source (bytes consumed so far)
+__device__ __forceinline__ void rd_finish(const RangeDec& d, BitSrc& s)
+{
+	s.bit = (d.next + 8 - d.left) * 8;
+	if (s.bit > (u64)s.size * 8) s.err |= DEC_ERR_TRUNC;
+}
 
 __device__ __forceinline__ void rd_start(RangeDec& d, BitSrc& s)
 {
-	d.buffer = ((u64)bs_word(s) << 32); d.buffer |= bs_word(s);
+	const u64 at = s.bit >> 3;                                  // byte aligned here
+	d.buffer = rd_window(s, at);
+	d.next = at + 8; d.w0 = rd_window(s, d.next); d.w1 = rd_window(s, d.next + 8); d.left = 8;
 	d.low = 0; d.range = 0xFFFFFFFFu;
 }
 
@@ -238,7 +274,7 @@ __device__ __forceinline__ u32 rd_symbol(RangeDec& d, BitSrc& s, u16* row)
 	}
 	d.range /= acc;
 	if (d.range == 0) { s.err |= DEC_ERR_FORMAT; d.range = 1; }
-	const u32 cul = (u32)(d.buffer / d.range);                    // Freq is uint32: the quotient is truncated
+	const u32 cul = div_u64_u32(d.buffer, d.range);               // Freq is uint32: the quotient is truncated
 	u32 idx = 0, hi = 0;
 	for (;;)
 	{
@@ -258,7 +294,7 @@ __device__ __forceinline__ u32 rd_symbol(RangeDec& d, BitSrc& s, u16* row)
 			const u32 lo = (u32)d.low;
 			d.range = (lo | 0x00FFFFFFu) - lo;
 		}
-		d.buffer = (d.buffer << 8) + bs_byte(s);
+		d.buffer = (d.buffer << 8) + rd_byte(d, s);
 		d.low <<= 8; d.range <<= 8;
 		if (d.range == 0) { s.err |= DEC_ERR_FORMAT; d.range = 0xFFFFFFFFu; break; }
 	}
@@ -600,18 +636,31 @@ __device__ void qua_order_decode(BitSrc& s, u16* tab, u32 ord, u32 rescale, cons
 		}
 		rp.kept[g] = (u16)(ql - ncount); rp.d_off[g] = d_total; d_total += ql - ncount;
 	}
+	rd_finish(rd, s);
 	S->d_total = d_total;
 }
 
-// floor(n / d) for the range decoder: n < 2^53 on every valid stream (buffer < range x total), so one f64 division is at
-// most one off and two integer checks make it exact; larger numerators (corrupt data) take the integer division
-__device__ __forceinline__ u32 div_u64_u32(u64 n, u32 d)
+// inclusive prefix sum over the wave with DPP row shifts / row broadcasts (gfx9: v_add with a dpp modifier, ~2 cycles a
+// step) instead of six ds_bpermute round trips through the LDS crossbar
+__device__ __forceinline__ u32 dec_wave_scan(u32 v)
 {
-	if (n >> 52) return (u32)(n / d);
-	u64 q = (u64)((double)n / (double)d);
-	if (q * d > n) --q;
-	else if ((q + 1) * d <= n) ++q;
-	return (u32)q;
+#ifdef DSRC_EMU_BUILD
+	return wave_incl_scan(v);
+#else
+	int x = (int)v;
+	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1
+	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);      // row_shr:2
+	x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);      // row_shr:4
+	x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);      // row_shr:8
+	x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+	x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+	return (u32)x;
+#endif
+}
+// value of lane `l` (wave-uniform) as a scalar: v_readlane with the lane number in an SGPR
+__device__ __forceinline__ u32 dec_readlane(u32 v, u32 l)
+{
+	return (u32)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)l));
 }
 
 // The same decoder with the WAVE on one stream (N <= 64): lane i holds counter i of the current row, so the row is one
@@ -646,14 +695,14 @@ __device__ void qua_order_decode_wave(BitSrc& s, u16* tab, u32 ord, u32 rescale,
 			const u64 h = ((hash & hash_mask) << abits) | pctx;
 			u16* row = tab + h * N;
 			u32 c = lane < N ? (u32)__hip_atomic_load(row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-			u32 incl = wave_incl_scan(c);
-			u32 acc = (u32)__shfl((int)incl, (int)(N - 1));
+			u32 incl = dec_wave_scan(c);
+			u32 acc = dec_readlane(incl, N - 1);
 			bool rescaled = false;
 			if (acc >= (1u << 16) - N * 2)
 			{	// TSymbolCoderRC::Rescale: the halved counters stay in the row
 				c -= c >> 1;
-				incl = wave_incl_scan(c);
-				acc = (u32)__shfl((int)incl, (int)(N - 1));
+				incl = dec_wave_scan(c);
+				acc = dec_readlane(incl, N - 1);
 				rescaled = true;
 			}
 			rd.range /= acc;
@@ -663,8 +712,8 @@ __device__ void qua_order_decode_wave(BitSrc& s, u16* tab, u32 ord, u32 rescale,
 			u32 idx;
 			if (m == 0) { s.err |= DEC_ERR_FORMAT; idx = N - 1; }     // the reference walks off the row here
 			else idx = (u32)__ffsll((long long)m) - 1u;
-			const u32 f = (u32)__shfl((int)c, (int)idx);
-			const u32 hi = (u32)__shfl((int)incl, (int)idx) - f;
+			const u32 f = dec_readlane(c, idx);
+			const u32 hi = dec_readlane(incl, idx) - f;
 			const u32 rr = hi * rd.range;                          // uint32 product
 			rd.buffer -= rr; rd.low += rr;
 			rd.range *= f;
@@ -675,7 +724,7 @@ __device__ void qua_order_decode_wave(BitSrc& s, u16* tab, u32 ord, u32 rescale,
 					const u32 lo = (u32)rd.low;
 					rd.range = (lo | 0x00FFFFFFu) - lo;
 				}
-				rd.buffer = (rd.buffer << 8) + bs_byte(s);
+				rd.buffer = (rd.buffer << 8) + rd_byte(rd, s);
 				rd.low <<= 8; rd.range <<= 8;
 				if (rd.range == 0) { s.err |= DEC_ERR_FORMAT; rd.range = 0xFFFFFFFFu; break; }
 			}
@@ -695,9 +744,60 @@ __device__ void qua_order_decode_wave(BitSrc& s, u16* tab, u32 ord, u32 rescale,
 		if (lane == 0) { rp.kept[g] = (u16)(ql - ncount); rp.d_off[g] = d_total; }
 		d_total += ql - ncount;
 	}
+	rd_finish(rd, s);
 	if (lane == 0) S->d_total = d_total;
 }
 
+// rd_symbol on a row held in registers (the caller stores it back): *rescaled tells whether every counter changed
+template <u32 N>
+__device__ __forceinline__ u32 rd_symbol_regs(RangeDec& d, BitSrc& s, u32 (&row)[N], bool* rescaled)
+{
+	u32 acc = 0;
+#pragma unroll
+	for (u32 i = 0; i < N; ++i) acc += row[i];
+	*rescaled = false;
+	if (acc >= (1u << 16) - N * 2)
+	{
+		acc = 0;
+#pragma unroll
+		for (u32 i = 0; i < N; ++i) { row[i] -= row[i] >> 1; acc += row[i]; }
+		*rescaled = true;
+	}
+	d.range /= acc;
+	if (d.range == 0) { s.err |= DEC_ERR_FORMAT; d.range = 1; }
+	const u32 cul = div_u64_u32(d.buffer, d.range);
+	u32 idx = N - 1, hi = 0, f = 0, lo = 0;
+	bool found = false;
+#pragma unroll
+	for (u32 i = 0; i < N; ++i)
+	{
+		hi += row[i];
+		if (!found && hi > cul) { found = true; idx = i; f = row[i]; lo = hi - row[i]; }
+	}
+	if (!found) { s.err |= DEC_ERR_FORMAT; f = row[N - 1]; lo = hi - f; }        // the reference walks off the row here
+	const u32 rr = lo * d.range;
+	d.buffer -= rr; d.low += rr;
+	d.range *= f;
+	while (d.range <= 0x00FFFFFFu)
+	{
+		if ((d.low ^ (d.low + d.range)) & 0xFF00000000000000ull)
+		{
+			const u32 l32 = (u32)d.low;
+			d.range = (l32 | 0x00FFFFFFu) - l32;
+		}
+		d.buffer = (d.buffer << 8) + rd_byte(d, s);
+		d.low <<= 8; d.range <<= 8;
+		if (d.range == 0) { s.err |= DEC_ERR_FORMAT; d.range = 0xFFFFFFFFu; break; }
+	}
+#pragma unroll
+	for (u32 i = 0; i < N; ++i) if (i == idx) row[i] += 2;
+	return idx;
+}
+
+// TDnaRCOrderModeler::Decode (src/DnaModelerRCO.h:62-79) on one lane.  The context of symbol t+1 is (context of t << bits | symbol
+// t): whatever symbol t turns out to be, its row is one of N CONSECUTIVE rows, 8 N^2 / 4 bytes of table that are known
+// before symbol t is decoded.  They are requested first, so the row read of the next symbol overlaps the arithmetic of this
+// one instead of following it; the current row lives in registers (it is the only row a store can have made stale).
 template <u32 N>
 __device__ void dna_order_decode(BitSrc& s, u16* tab, u32 ord, const DecDesc& d, DecState* S, RecPools rp, u8* dst)
 {
@@ -706,12 +806,42 @@ __device__ void dna_order_decode(BitSrc& s, u16* tab, u32 ord, const DecDesc& d,
 	u64 hash = 0;
 	RangeDec rd; rd_start(rd, s);
 	const u32 total = S->d_total;
+	u32 cur[N];
+#pragma unroll
+	for (u32 i = 0; i < N; ++i) cur[i] = tab[i];
 	for (u32 t = 0; t < total && !s.err; ++t)
 	{
-		const u32 c = rd_symbol<N>(rd, s, tab + hash * N);
+		const u64 nbase = (hash << abits) & mask;                 // first of the N candidate rows of symbol t+1
+		const u64* cp = (const u64*)(tab + nbase * N);             // N rows x N counters x 2 bytes, 8-byte aligned
+		u64 cand[N * N / 4];
+#pragma unroll
+		for (u32 i = 0; i < N * N / 4; ++i) cand[i] = cp[i];
+		bool rescaled;
+		const u32 c = rd_symbol_regs<N>(rd, s, cur, &rescaled);
 		dst[t] = (u8)c;
-		hash = ((hash << abits) | c) & mask;
+		u16* row = tab + hash * N;
+		if (rescaled) { for (u32 i = 0; i < N; ++i) row[i] = (u16)cur[i]; }
+		else row[c] = (u16)cur[c];
+		const u64 nh = nbase | c;
+		if (nh != hash)
+		{	// candidate row c = N / 4 consecutive 64-bit words
+			constexpr u32 W = N / 4;
+			u64 r[W];
+#pragma unroll
+			for (u32 w = 0; w < W; ++w) r[w] = cand[w];
+#pragma unroll
+			for (u32 k = 1; k < N; ++k)
+				if (c == k)
+				{
+#pragma unroll
+					for (u32 w = 0; w < W; ++w) r[w] = cand[k * W + w];
+				}
+#pragma unroll
+			for (u32 i = 0; i < N; ++i) cur[i] = (u32)(r[i / 4] >> (16 * (i & 3))) & 0xFFFFu;
+		}
+		hash = nh;
 	}
+	rd_finish(rd, s);
 }
 
 __global__ void __launch_bounds__(64) k_dec_streams(const u8* in, const DecDesc* desc, DecState* st, RecPools rp, u8* out, u32* pool,
@@ -931,9 +1061,33 @@ __global__ void __launch_bounds__(64) k_dec_streams(const u8* in, const DecDesc*
 				}
 			}
 			s_flag = f;
+			// the 2-bit packing has no serial dependency: its unpacking is handed to the whole wave
+			const bool b2 = !s.err && d_scheme == 0 && prm.dna_order == 0;
+			s_par[0] = b2 ? 1u : 0u; s_par[1] = S->d_total; s_par[2] = (u32)s.bit; s_par[3] = (u32)(s.bit >> 32);
 		}
 		__syncthreads();
 		const u32 dN = s_flag;
+		if (s_par[0])
+		{	// DnaModelerBasicB2::Decode (src/DnaModelerBasicB2.h:48-60): symbol t is bits 2t, 2t+1; a lane takes 16 symbols (32 bits)
+			BitSrc t = s; t.err = 0;
+			const u64 bit0 = ((u64)s_par[3] << 32) | s_par[2];
+			const u32 total = s_par[1];
+			u8* dst = d_stream + d.d_base;
+			for (u32 t0 = threadIdx.x * 16u; t0 < total; t0 += blockDim.x * 16u)
+			{
+				t.bit = bit0 + 2ull * t0;
+				const u32 w = bs_peek32(t);
+				const u32 cnt = total - t0 < 16u ? total - t0 : 16u;
+				if (cnt == 16u)
+				{	// sixteen bytes as two aligned 8-byte stores (d_base and t0 are multiples of 16)
+					u64 lo = 0, hi = 0;
+#pragma unroll
+					for (u32 k = 0; k < 8; ++k) { lo |= (u64)((w >> (30 - 2 * k)) & 3u) << (8 * k); hi |= (u64)((w >> (14 - 2 * k)) & 3u) << (8 * k); }
+					((u64*)(dst + t0))[0] = lo; ((u64*)(dst + t0))[1] = hi;
+				}
+				else for (u32 k = 0; k < cnt; ++k) dst[t0 + k] = (u8)((w >> (30 - 2 * k)) & 3u);
+			}
+		}
 		const u32 d_ord = dN == 8 ? (prm.dna_order < 7u ? prm.dna_order : 7u) : prm.dna_order;
 		if (dN)
 		{
@@ -949,8 +1103,8 @@ __global__ void __launch_bounds__(64) k_dec_streams(const u8* in, const DecDesc*
 			if (dN == 4) dna_order_decode<4>(s, (u16*)table, d_ord, d, S, rp, dst);
 			else if (dN == 8) dna_order_decode<8>(s, (u16*)table, d_ord, d, S, rp, dst);
 			else if (d_scheme == 0)
-			{	// DnaModelerBasicB2::Decode (src/DnaModelerBasicB2.h:48-60)
-				for (u32 t = 0; t < total; ++t) dst[t] = (u8)bs_bits(s, 2);
+			{	// unpacked above by the whole wave; the stream position moves on
+				bs_skip(s, total); bs_skip(s, total);
 				bs_align(s);
 			}
 			else

@@ -17,6 +17,11 @@ EMU_CLI = os.path.join(ROOT, "tests", "emu", "dsrc-amd-emu")
 G = json.load(open(os.path.join(ROOT, "tests", "golden", "state_golden.json")))
 
 
+@pytest.fixture(autouse=True)
+def one_lane_quality_decoder(monkeypatch):
+    monkeypatch.setenv("DSRC_GPU_DEC_SERIAL", "1")     # the wave-cooperative decoder is slow on the emulator (tests/test_emu_decode.py)
+
+
 @pytest.fixture(scope="module")
 def cli():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emu")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
