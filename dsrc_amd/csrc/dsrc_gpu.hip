@@ -1350,6 +1350,14 @@ uint32_t dsrcgpu_fields_capacity_after(uint32_t cap, uint32_t n_fields)
 	return cap;
 }
 
+int dsrcgpu_prepare(int device)
+{
+	// first touch of a device: the HIP runtime loads the code objects and creates the context (0.3-1 s); hosts call this
+	// on a side thread while they open files, so that dsrcgpu_create finds the device ready
+	if (hipSetDevice(device) != hipSuccess) return DSRCGPU_E_HIP;
+	return hipFree(nullptr) == hipSuccess ? DSRCGPU_OK : DSRCGPU_E_HIP;
+}
+
 int dsrcgpu_host_alloc(uint64_t bytes, void** out)
 {
 	if (!out) return DSRCGPU_E_ARG;

@@ -138,34 +138,51 @@ static void PutBE(std::vector<uchar>& v, uint64 x, int bytes) { for (int i = byt
 
 void ArchiveWriter::Start(const std::string& path)
 {
-	f = fopen(path.c_str(), "wb");
-	if (!f) throw DsrcException("Cannot open file to write:" + path);
+	fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+	if (fd < 0) throw DsrcException("Cannot open file to write:" + path);
 	name = path;
-	uchar zero[40]; memset(zero, 0, sizeof(zero));
-	Put(zero, 40);                                   // header is written last (src/DsrcFile.cpp:52-54)
+	pos = 40;                                        // the header is written last (src/DsrcFile.cpp:52-54)
 }
 
-void ArchiveWriter::Put(const void* p, uint64 n)
+void ArchiveWriter::WriteAt(uint64 off, const void* p, uint64 n) const
 {
-	if (n && fwrite(p, 1, n, f) != n) throw DsrcException("Error writing the archive (disk full?): " + name);
+	const uchar* b = (const uchar*)p;
+	while (n)
+	{
+		const ssize_t w = pwrite(fd, b, n > (1ull << 30) ? (1ull << 30) : n, (off_t)off);
+		if (w <= 0) throw DsrcException("Error writing the archive (disk full?): " + name);
+		b += w; off += (uint64)w; n -= (uint64)w;
+	}
 }
 
 void ArchiveWriter::Abandon()
 {
-	if (f) { fclose(f); f = nullptr; }
+	if (fd >= 0) { close(fd); fd = -1; }
 	if (!name.empty()) { unlink(name.c_str()); name.clear(); }
+}
+
+// the next n blocks of the archive: their sizes go into the footer table, the bytes may be written by the caller (any
+// thread, any time before Finish) at the returned file offset
+uint64 ArchiveWriter::Claim(uint32 n, const uint64_t* sizes, const uint64_t* raw, const uint64_t* comp)
+{
+	const uint64 at = pos;
+	for (uint32 i = 0; i < n; ++i)
+	{
+		blockSizes.push_back((uint32)sizes[i]); pos += sizes[i];
+		for (int k = 0; k < 4; ++k) { rawInfo.sizes[k] += raw[4 * i + k]; compInfo.sizes[k] += comp[4 * i + k]; }
+	}
+	return at;
 }
 
 void ArchiveWriter::WriteBlock(const uchar* data, uint64 size, const uint64 raw[4], const uint64 comp[4])
 {
-	Put(data, size);
-	blockSizes.push_back((uint32)size);
-	for (int i = 0; i < 4; ++i) { rawInfo.sizes[i] += raw[i]; compInfo.sizes[i] += comp[i]; }
+	const uint64_t sz = size, r[4] = {raw[0], raw[1], raw[2], raw[3]}, c[4] = {comp[0], comp[1], comp[2], comp[3]};
+	WriteAt(Claim(1, &sz, r, c), data, size);
 }
 
 void ArchiveWriter::Finish(const fq::FastqDatasetType& type, const CompressionSettings& s)
 {
-	const uint64 footerOffset = (uint64)ftello(f);
+	const uint64 footerOffset = pos;
 	std::vector<uchar> foot;
 	foot.push_back(0xCC);
 	const uchar* bs = (const uchar*)blockSizes.data();     // host-endian uint32 array, as the reference writes it
@@ -175,25 +192,25 @@ void ArchiveWriter::Finish(const fq::FastqDatasetType& type, const CompressionSe
 	foot.push_back((uchar)((s.lossy ? 1 : 0) | (s.calculateCrc32 ? 2 : 0)));
 	foot.push_back((uchar)s.dnaOrder); foot.push_back((uchar)s.qualityOrder);
 	PutBE(foot, s.tagPreserveFlags, 8);
-	Put(foot.data(), foot.size());
+	WriteAt(footerOffset, foot.data(), foot.size());
 	std::vector<uchar> head;
 	head.push_back(0xAA); head.push_back(2); head.push_back(0); head.push_back(2);
 	PutBE(head, foot.size(), 4); PutBE(head, footerOffset, 8); PutBE(head, 0, 8); PutBE(head, blockSizes.size(), 8);
 	for (int i = 0; i < 8; ++i) head.push_back(0xAA);
-	if (fseeko(f, 0, SEEK_SET) != 0) throw DsrcException("Error writing the archive: " + name);
-	Put(head.data(), head.size());
-	FILE* g = f; f = nullptr;
-	if (fclose(g) != 0) throw DsrcException("Error writing the archive (disk full?): " + name);
+	WriteAt(0, head.data(), head.size());
+	const int g = fd; fd = -1;
+	if (close(g) != 0) throw DsrcException("Error writing the archive (disk full?): " + name);
 	name.clear();
 }
 
-ArchiveWriter::~ArchiveWriter() { if (f) Abandon(); }           // an archive that was not finished is not left behind
+ArchiveWriter::~ArchiveWriter() { if (fd >= 0) Abandon(); }           // an archive that was not finished is not left behind
 
 // ---- operator -----------------------------------------------------------------------------------------------
 // File -> archive as a pipeline: the calling thread cuts chunk boundaries (two 8 KiB reads per chunk),
-// `instances` worker threads each own one GPU scheduler instance and, per batch, pread() their chunks straight into
-// page-locked memory, compress (host->device, kernels, device->host all on that instance's stream, overlapping the
-// other instances), and hand the blocks to the writer thread, which restores batch order.  The block-to-block state
+// reader threads pread() whole batches straight into page-locked memory, `instances` worker threads each own one GPU
+// scheduler instance, compress a batch (host->device, kernels, device->host all on that instance's stream, overlapping
+// the other instances) and write its blocks themselves with one positioned write: a batch claims its range of the archive
+// as soon as the batches before it have claimed theirs (that needs their sizes, not their bytes), so writes run in parallel.  The block-to-block state
 // travels through a dsrcgpu_chain, so the archive is the one a single instance -- and `dsrc c -t1` -- writes.
 namespace
 {
@@ -219,7 +236,6 @@ struct Job          // one batch
 	// filled by a reader thread
 	Pinned* in = nullptr; std::vector<uint64> at; uint64 inBytes = 0;
 	// results
-	Pinned* out = nullptr;
 	std::vector<uint64_t> offs, osz, raw, comp;
 };
 
@@ -229,8 +245,7 @@ struct Pipeline
 	std::deque<Job*> todo; bool noMore = false;          // cut, waiting for a reader
 	std::map<uint64, Job*> ready; uint64 nextStart = 0;  // read into page-locked memory, waiting for a scheduler instance (taken in order)
 	std::vector<Pinned*> freeIn;                         // input buffers not in use
-	std::map<uint64, Job*> done;
-	bool writerDone = false;                             // the writer thread no longer touches any output buffer
+	uint64 claimTurn = 0;                                // the batch whose turn it is to claim its range of the archive
 	std::string error;
 	bool Failed() { std::lock_guard<std::mutex> g(m); return !error.empty(); }
 	void Fail(const std::string& e) { std::lock_guard<std::mutex> g(m); if (error.empty()) error = e; cv.notify_all(); }
@@ -351,7 +366,6 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 	int fd = -1;
 	dsrcgpu_chain* chain = nullptr;
 	std::vector<std::thread> workers, readers;
-	std::thread writerThread;
 	Pipeline pl;
 	// everything the threads refer to outlives them (they are joined at the bottom, also on errors)
 	fq::FastqDatasetType type;
@@ -359,14 +373,21 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 	ArchiveWriter writer;
 	std::vector<std::unique_ptr<Pinned>> inBufs;
 	uint64 totalBatches = ~0ull;                     // known once the cutter is through (guarded by pl.m)
+	std::vector<std::thread> warm;                   // HIP start-up runs beside the file opening / first-chunk analysis
 	try
 	{
+		{
+			const std::vector<int> d0 = args.devices.empty() ? std::vector<int>(1, args.device) : args.devices;
+			for (int dev : d0) warm.emplace_back([dev]() { (void)dsrcgpu_prepare(dev); });
+		}
 		fd = open(args.inputFilename.c_str(), O_RDONLY);
 		struct stat sb;
 		if (fd < 0 || fstat(fd, &sb) != 0) throw DsrcException("Cannot open file to read:" + args.inputFilename);
 		if (!S_ISREG(sb.st_mode))
 		{	// pipes and devices go through the stream reader
 			close(fd); fd = -1;
+			for (auto& t : warm) t.join();
+			warm.clear();
 			FILE* f = fopen(args.inputFilename.c_str(), "rb");
 			if (!f) throw DsrcException("Cannot open file to read:" + args.inputFilename);
 			const bool ok = ProcessStream(args, f);
@@ -405,12 +426,11 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 		auto work = [&](uint32 idx)
 		{
 			dsrcgpu_handle* h = nullptr;
-			Pinned out[2];
-			std::vector<Job*> inFlight(2, nullptr);       // the job whose blocks still sit in out[k]
+			Pinned out;
 			try
 			{
 				h = CreateInstance(args, settings, type, devs[idx % devs.size()]);
-				for (uint32 turn = 0;; ++turn)
+				for (;;)
 				{
 					Job* job = nullptr;
 					{	// batches start in order: the chain makes batch s+1 wait for batch s early in its course
@@ -420,28 +440,20 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 						job = pl.ready[pl.nextStart]; pl.ready.erase(pl.nextStart); ++pl.nextStart;
 						pl.cv.notify_all();
 					}
+					std::unique_ptr<Job> owner(job);
 					const auto t0 = std::chrono::steady_clock::now();
 					const uint32 n = (uint32)job->sizes.size();
 					const uint64 inBytes = job->inBytes;
 					std::vector<const uint8_t*> ptrs(n);
 					for (uint32 i = 0; i < n; ++i) ptrs[i] = job->in->p + job->at[i];
-					const auto t1 = t0;
-					// the output buffer of two batches ago must have been written out
-					Pinned& ob = out[turn & 1];
-					{
-						std::unique_lock<std::mutex> g(pl.m);
-						pl.cv.wait(g, [&] { return !pl.error.empty() || inFlight[turn & 1] == nullptr || inFlight[turn & 1]->out == nullptr; });
-						if (!pl.error.empty()) { delete job; break; }
-					}
-					delete inFlight[turn & 1]; inFlight[turn & 1] = nullptr;
 					uint64 cap = inBytes * 2 / 5 + (uint64)n * (1u << 16);     // typical ratio 0.2-0.33; grown below if the data needs it
 					job->offs.resize(n); job->osz.resize(n); job->raw.resize(4 * n); job->comp.resize(4 * n);
 					int rc;
 					dsrcgpu_set_chain(h, chain, job->seq);     // once per batch: a retry below is the same turn of the chain
 					for (;;)
 					{
-						ob.Reserve(cap);
-						rc = dsrcgpu_compress_batch(h, n, ptrs.data(), job->sizes.data(), ob.p, ob.cap, job->offs.data(), job->osz.data(), job->raw.data(), job->comp.data());
+						out.Reserve(cap);
+						rc = dsrcgpu_compress_batch(h, n, ptrs.data(), job->sizes.data(), out.p, out.cap, job->offs.data(), job->osz.data(), job->raw.data(), job->comp.data());
 						if (rc != DSRCGPU_E_CAPACITY || cap >= inBytes + (uint64)n * (1u << 16)) break;
 						cap = inBytes + (uint64)n * (1u << 16);        // incompressible input: room for the worst case, once
 					}
@@ -450,35 +462,37 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 						pl.freeIn.push_back(job->in); job->in = nullptr;
 						pl.cv.notify_all();
 					}
-					if (rc != DSRCGPU_OK) { const std::string e = dsrcgpu_last_error(h); delete job; throw DsrcException(e); }
+					if (rc != DSRCGPU_OK) throw DsrcException(dsrcgpu_last_error(h));
+					const auto t1 = std::chrono::steady_clock::now();
+					// the archive position of this batch is known once the batches before it have claimed theirs (sizes only:
+					// nobody waits for anybody's bytes); the blocks lie back to back in `out` and go out in one positioned write
+					uint64 fileOff = 0, total = 0;
+					{
+						std::unique_lock<std::mutex> g(pl.m);
+						pl.cv.wait(g, [&] { return !pl.error.empty() || pl.claimTurn == job->seq; });
+						if (!pl.error.empty()) break;
+						fileOff = writer.Claim(n, job->osz.data(), job->raw.data(), job->comp.data());
+						++pl.claimTurn;
+						pl.cv.notify_all();
+					}
+					for (uint32 i = 0; i < n; ++i) total += job->osz[i];
+					writer.WriteAt(fileOff, out.p + job->offs[0], total);
 					if (trace)
 					{
 						const auto t2 = std::chrono::steady_clock::now();
 						auto ms = [&](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-						fprintf(stderr, "[dsrc-amd] batch %llu (%u chunks, %.2f GB): start %.0f ms, compress %.0f ms\n", (unsigned long long)job->seq, n, inBytes / 1e9, ms(tStart, t0), ms(t1, t2));
-					}
-					job->out = &ob; inFlight[turn & 1] = job;
-					{
-						std::lock_guard<std::mutex> g(pl.m);
-						pl.done[job->seq] = job;
-						pl.cv.notify_all();
+						fprintf(stderr, "[dsrc-amd] batch %llu (%u chunks, %.2f GB): start %.0f ms, compress %.0f ms, write %.0f ms\n", (unsigned long long)job->seq, n, inBytes / 1e9, ms(tStart, t0), ms(t0, t1), ms(t1, t2));
 					}
 				}
 			}
 			catch (const std::exception& e) { pl.Fail(e.what()); }
-			{	// the writer may still be copying out of out[]: it is done with them when it has released them or has exited
-				std::unique_lock<std::mutex> g(pl.m);
-				pl.cv.wait(g, [&] { return pl.writerDone || ((!inFlight[0] || !inFlight[0]->out) && (!inFlight[1] || !inFlight[1]->out)); });
-				for (Job*& j : inFlight)
-					if (j) { for (auto it = pl.done.begin(); it != pl.done.end();) { if (it->second == j) it = pl.done.erase(it); else ++it; } delete j; j = nullptr; }
-			}
 			if (h) dsrcgpu_destroy(h);
 		};
 		for (uint32 i = 0; i < instances; ++i) workers.emplace_back(work, i);
 
 		// ---- readers: file -> page-locked memory, ahead of the scheduler instances -----------------------------------
-		const uint32 nReaders = std::min<uint32>(2, instances);
-		for (uint32 i = 0; i < instances + 1; ++i) { inBufs.emplace_back(new Pinned()); pl.freeIn.push_back(inBufs.back().get()); }
+		const uint32 nReaders = std::min<uint32>(8, 2 * instances);     // pread = copies out of the page cache: they scale with threads
+		for (uint32 i = 0; i < instances + 2; ++i) { inBufs.emplace_back(new Pinned()); pl.freeIn.push_back(inBufs.back().get()); }
 		auto readLoop = [&]()
 		{
 			try
@@ -518,34 +532,6 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 		};
 		for (uint32 i = 0; i < nReaders; ++i) readers.emplace_back(readLoop);
 
-		// ---- writer: batches in order ---------------------------------------------------------------------------
-		writerThread = std::thread([&]()
-		{
-			try
-			{
-				for (uint64 next = 0;; ++next)
-				{
-					Job* job = nullptr;
-					{
-						std::unique_lock<std::mutex> g(pl.m);
-						pl.cv.wait(g, [&] { return !pl.error.empty() || pl.done.count(next) || next >= totalBatches; });
-						if (!pl.error.empty() || next >= totalBatches) return;
-						job = pl.done[next]; pl.done.erase(next);
-					}
-					const uint32 n = (uint32)job->sizes.size();
-					for (uint32 i = 0; i < n; ++i) writer.WriteBlock(job->out->p + job->offs[i], job->osz[i], (const uint64*)&job->raw[4 * i], (const uint64*)&job->comp[4 * i]);
-					{
-						std::lock_guard<std::mutex> g(pl.m);
-						job->out = nullptr;                    // the worker may reuse the buffer (and frees the job)
-						pl.cv.notify_all();
-					}
-				}
-			}
-			catch (const std::exception& e) { pl.Fail(e.what()); }
-			std::lock_guard<std::mutex> g(pl.m);
-			pl.writerDone = true; pl.cv.notify_all();
-		});
-
 		// ---- cutter (this thread) -------------------------------------------------------------------------------
 		uint64 seq = 0;
 		bool more = true;
@@ -575,8 +561,6 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 		}
 		auto stamp = [&](const char* what) { if (trace) fprintf(stderr, "[dsrc-amd] %s at %.0f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tStart).count()); };
 		stamp("cutter done");
-		writerThread.join();
-		stamp("writer done");
 		for (auto& t : workers) t.join();
 		for (auto& t : readers) t.join();
 		workers.clear(); readers.clear();
@@ -593,7 +577,7 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 		std::lock_guard<std::mutex> g(pl.m);
 		pl.noMore = true; pl.cv.notify_all();
 	}
-	if (writerThread.joinable()) writerThread.join();
+	for (auto& t : warm) if (t.joinable()) t.join();
 	for (auto& t : workers) if (t.joinable()) t.join();
 	for (auto& t : readers) if (t.joinable()) t.join();
 	for (Job* j : pl.todo) delete j;

@@ -152,15 +152,19 @@ class ArchiveWriter
 public:
 	void Start(const std::string& path);
 	void WriteBlock(const uchar* data, uint64 size, const uint64 raw[4], const uint64 comp[4]);
+	// for writers that run in parallel: Claim (one caller at a time, in archive order) reserves the file range of the next
+	// n blocks and records their sizes; WriteAt (any thread) fills it
+	uint64 Claim(uint32 n, const uint64_t* sizes, const uint64_t* raw, const uint64_t* comp);
+	void WriteAt(uint64 off, const void* p, uint64 n) const;
 	void Finish(const fq::FastqDatasetType& type, const CompressionSettings& settings);
 	const fq::StreamsInfo& Raw() const { return rawInfo; }
 	const fq::StreamsInfo& Comp() const { return compInfo; }
 	void Abandon();                  // close and remove the unfinished archive
 	~ArchiveWriter();
 private:
-	void Put(const void* p, uint64 n);
 	std::string name;
-	FILE* f = nullptr;
+	int fd = -1;
+	uint64 pos = 0;
 	std::vector<uint32> blockSizes;
 	fq::StreamsInfo rawInfo, compInfo;
 };

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <unistd.h>
 
 #include "dsrc_host.h"
 
@@ -101,5 +102,10 @@ int main(int argc, const char* argv[])
 	if (!ok) std::cerr << op->GetError();
 	else if (verbose) std::cerr << op->GetLog();
 	delete op;
-	return ok ? 0 : -1;
+	if (ok)
+	{	// everything is written and closed: leave without the HIP runtime's tear-down (0.3-0.5 s of unmapping at exit)
+		std::cerr.flush(); fflush(nullptr);
+		_exit(0);
+	}
+	return -1;
 }

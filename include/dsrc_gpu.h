@@ -171,6 +171,10 @@ int dsrcgpu_chain_seed(dsrcgpu_chain* c, uint32_t fields_capacity);      /* befo
  * Not combinable with tag_preserve_flags or calculate_crc32 (the reference's archive API drops both). */
 int dsrcgpu_set_record_layout(dsrcgpu_handle* h, uint32_t n, const uint32_t* chunk_sizes);
 
+/* Optional: brings up the HIP runtime and the device context (the first HIP call of a process costs 0.3-1 s); call it on a
+ * side thread while the host opens its files. */
+int dsrcgpu_prepare(int device);
+
 /* Page-locked host memory for chunk / block buffers: host<->device copies from it run at PCIe speed and
  * asynchronously to the other handles' kernels (the entry points accept any host pointer; pageable ones are slower). */
 int dsrcgpu_host_alloc(uint64_t bytes, void** out);

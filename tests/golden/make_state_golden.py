@@ -23,4 +23,13 @@ chunks=[data[s:s+n] for s,n in cuts]
 a=[b for b,_,_ in o.compress_blocks_state(cfg,chunks)]
 fresh=[o.compress_block(cfg,c)[0] for c in chunks]
 print('blocks differing when state is not carried:', sum(x!=y for x,y in zip(a,fresh)), 'of', len(a))
+# a smaller variant (regions of ~0.5 MB, three 1 MiB chunks) for the emulator-backed CPU test
+small=state_dependent_fastq(4500)
+open('/tmp/state_s.fastq','wb').write(small)
+subprocess.check_call([REF_BIN,'c','-d0','-q0','-b1','-t1','/tmp/state_s.fastq','/tmp/state_s.dsrc'])
+b=open('/tmp/state_s.dsrc','rb').read()
+cs=[small[s:s+n] for s,n in o.cut_chunks(small,1<<20)]
+a=[x for x,_,_ in o.compress_blocks_state(cfg,cs)]; fresh=[o.compress_block(cfg,c)[0] for c in cs]
+print('small:',len(small),len(cs),'chunks;',sum(x!=y for x,y in zip(a,fresh)),'state-dependent')
+res['small']={'n_per_region':4500,'in_sha256':hashlib.sha256(small).hexdigest(),'flags':['-d0','-q0'],'buf_mb':1,'size':len(b),'md5':hashlib.md5(b).hexdigest()}
 json.dump(res,open('/root/repo/tests/golden/state_golden.json','w'),indent=1)

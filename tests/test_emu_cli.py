@@ -33,16 +33,15 @@ def md5(p):
 
 
 def test_sharded_instances_write_the_t1_archive(cli, tmp_path):
-    data = state_dependent_fastq()
-    assert hashlib.sha256(data).hexdigest() == G["in_sha256"]
+    a = G["small"]                       # three 1 MiB chunks whose blocks depend on the carried state
+    data = state_dependent_fastq(a["n_per_region"])
+    assert hashlib.sha256(data).hexdigest() == a["in_sha256"]
     src = tmp_path / "state.fastq"; src.write_bytes(data)
-    a = G["archives"][0]
     arc = tmp_path / "s.dsrc"; back = tmp_path / "back.fastq"
     # two instances on each of two entries of the device list, one chunk per batch: every block on another instance
     subprocess.check_call([cli, "c", *a["flags"], "-b1", "-n1", "-t2", "-g0,0", str(src), str(arc)])
     assert (os.path.getsize(arc), md5(arc)) == (a["size"], a["md5"])
-    subprocess.check_call([cli, "d", "-n2", "-t2", "-g0,0", str(arc), str(back)])
-    assert back.read_bytes() == data
+    # (decompression of this archive over a device list: tests/test_gpu_host_cli.py; on the emulator a small one below)
 
 
 @pytest.mark.parametrize("flags", [["-d1", "-q1", "-c"], ["-d2", "-q1", "-l"]])
@@ -54,7 +53,7 @@ def test_round_trip_and_errors(cli, tmp_path, oracle, flags):
     d = int(flags[0][2:]); q = int(flags[1][2:])
     assert oracle.compress_file(str(src), str(ref_arc), d, q, "-l" in flags, "-c" in flags, 0, 8) == 0
     assert md5(arc) == md5(ref_arc)
-    out = subprocess.run([cli, "d", "-s", str(arc)], capture_output=True, check=True).stdout
+    out = subprocess.run([cli, "d", "-s", "-t2", "-g0,0", "-n1", str(arc)], capture_output=True, check=True).stdout
     if "-l" not in flags:
         assert out == data
     else:

@@ -58,7 +58,24 @@ def main():
         same = md5(ours) == md5(theirs)
         print("archives identical:", same)
         assert same
-    for p in (src, ours, theirs):
+    # the way back: archive -> FASTQ through the GPU decompressor, next to the reference's `dsrc d`
+    back = os.path.join(d, "e2e_back.fastq")
+    druns = [("dsrc-amd d -t%d" % inst, [CLI, "d", f"-t{inst}", ours, back])]
+    if not os.environ.get("E2E_NO_REF") and os.path.exists(REF):
+        druns.append(("reference d -t60", [REF, "d", "-t60", ours, back]))
+    for name, cmd in druns:
+        if os.path.exists(back):
+            os.remove(back)
+        t = time.time(); subprocess.check_call(cmd); dt = time.time() - t
+        print(f"{name:30s}: {size / 1e9:.2f} GB in {dt:6.2f} s = {size / dt / 1e6:8.1f} MB/s")
+        assert os.path.getsize(back) == size
+        with open(src, "rb") as fa, open(back, "rb") as fb:          # spot comparison: 64 MiB pieces across the file
+            for k in range(16):
+                o = (size - (64 << 20)) * k // 15
+                fa.seek(o); fb.seek(o)
+                assert fa.read(64 << 20) == fb.read(64 << 20), f"decoded text differs near byte {o}"
+    print("decoded text identical to the input (size + 16 x 64 MiB spot checks)")
+    for p in (src, ours, theirs, back):
         if os.path.exists(p):
             os.remove(p)
 
