@@ -215,8 +215,13 @@ class Handle:
                                                        C.c_uint64(out_cap), o_offs, o_sizes, raw, comp))
         return list(o_offs), list(o_sizes), list(raw), list(comp)
 
-    def submit(self, part_id: int, data: bytes):
-        self._chk(self.L.dsrcgpu_submit(self.h, C.c_int64(part_id), data, C.c_uint64(len(data))))
+    def submit(self, part_id: int, data: bytes) -> bool:
+        """False = all batches of the ring are in flight (DSRCGPU_E_BUSY): collect blocks, then submit again."""
+        rc = self.L.dsrcgpu_submit(self.h, C.c_int64(part_id), data, C.c_uint64(len(data)))
+        if rc == -8:
+            return False
+        self._chk(rc)
+        return True
 
     def flush(self):
         self._chk(self.L.dsrcgpu_flush(self.h))

@@ -1228,9 +1228,9 @@ int dsrcgpu_submit(dsrcgpu_handle* h, int64_t part_id, const uint8_t* fastq, uin
 	if (h->q_rc) return fail(h, h->q_rc, "%s", h->q_err.c_str());
 	QBatch* b = &h->qb[h->q_fill];
 	if (b->state != QBatch::Filling)
-	{	// a ring slot is free again once every block of the batch it held has been released
-		h->q_cv.wait(g, [&] { return h->qb[h->q_fill].state == QBatch::Free || h->q_rc; });
-		if (h->q_rc) return fail(h, h->q_rc, "%s", h->q_err.c_str());
+	{	// a ring slot is free again once every block of the batch it held has been collected and released.  A caller that
+		// submits and collects on ONE thread would wait for itself here, so a full ring is reported, not waited for
+		if (b->state != QBatch::Free) return DSRCGPU_E_BUSY;
 		b->state = QBatch::Filling; b->ids.clear(); b->in_off.clear(); b->sizes.clear(); b->in_used = 0;
 	}
 	const u64 at = (b->in_used + 255) & ~(u64)255;

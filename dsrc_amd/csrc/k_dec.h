@@ -147,7 +147,7 @@ __device__ __forceinline__ u32 huff_peek(const BitSrc& s, u32 pos, u32* n_int)
 }
 
 // parses the tree at the (aligned) read position into the pool and returns its pool index
-__device__ u32 huff_load(BitSrc& s, NodePool& np)
+__device__ __forceinline__ u32 huff_load(BitSrc& s, NodePool& np)
 {
 	bs_align(s);
 	const u32 begin = bs_pos(s);
@@ -601,7 +601,7 @@ __device__ __forceinline__ bool q_special(u32 q, u32 lossy) { return lossy ? q =
 // TQualityOrderModeler::Decode with T*QualityEncoder::Decode + TQualityModelExt::DecodeSymbol
 // (src/QualityOrderModeler.h:49-65, src/QualityEncoder.h:77-143,248-263,306-326)
 template <u32 N>
-__device__ void qua_order_decode(BitSrc& s, u16* tab, u32 ord, u32 rescale, const u8* translate, u32 lossy,
+__device__ __forceinline__ void qua_order_decode(BitSrc& s, u16* tab, u32 ord, u32 rescale, const u8* translate, u32 lossy,
 								 const DecDesc& d, DecState* S, RecPools rp, u8* text)
 {
 	const u32 abits = dec_int_log2(N);
@@ -669,7 +669,7 @@ __device__ __forceinline__ u32 dec_readlane(u32 v, u32 l)
 // one lane needs for a 32-counter row.  Counter traffic goes through workgroup-scope atomics (plain loads / stores that
 // are coherent within the CU): lane j reads counters that lane j' wrote a few symbols earlier.
 template <u32 N>
-__device__ void qua_order_decode_wave(BitSrc& s, u16* tab, u32 ord, u32 rescale, const u8* translate, u32 lossy,
+__device__ __forceinline__ void qua_order_decode_wave(BitSrc& s, u16* tab, u32 ord, u32 rescale, const u8* translate, u32 lossy,
 									  const DecDesc& d, DecState* S, RecPools rp, u8* text)
 {
 	const u32 lane = lane_id();
@@ -799,7 +799,7 @@ __device__ __forceinline__ u32 rd_symbol_regs(RangeDec& d, BitSrc& s, u32 (&row)
 // before symbol t is decoded.  They are requested first, so the row read of the next symbol overlaps the arithmetic of this
 // one instead of following it; the current row lives in registers (it is the only row a store can have made stale).
 template <u32 N>
-__device__ void dna_order_decode(BitSrc& s, u16* tab, u32 ord, const DecDesc& d, DecState* S, RecPools rp, u8* dst)
+__device__ __forceinline__ void dna_order_decode(BitSrc& s, u16* tab, u32 ord, const DecDesc& d, DecState* S, RecPools rp, u8* dst)
 {
 	const u32 abits = dec_int_log2(N);
 	const u64 mask = ((u64)1 << (abits * ord)) - 1;

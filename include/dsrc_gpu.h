@@ -59,7 +59,8 @@ enum
 	DSRCGPU_E_CAPACITY    = -4,   /* caller's output buffer too small */
 	DSRCGPU_E_INPUT       = -5,   /* a chunk could not be coded (no records, invalid bases, reference-UB input ...) */
 	DSRCGPU_E_STATE       = -6,
-	DSRCGPU_E_CRC         = -7    /* verify_after_compress: a block did not decode back to the checksums stored in it */
+	DSRCGPU_E_CRC         = -7,   /* verify_after_compress: a block did not decode back to the checksums stored in it */
+	DSRCGPU_E_BUSY        = -8    /* dsrcgpu_submit: all batches of the ring are in flight -- collect and release blocks, then submit again */
 };
 
 /* Replaces: BlockCompressor::BlockCompressor (src/BlockCompressor.cpp:53-94) x worker threads.
@@ -121,8 +122,10 @@ int dsrcgpu_decompress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d
  *   ... Store ... dsrcQueue.Push(partId, blk) -> dsrcgpu_collect(&partId, &blk, ...)
  *   dsrcPool.Release(blk)                    -> dsrcgpu_release(blk)
  * Asynchronous: dsrcgpu_flush hands everything submitted since the last flush to the handle's scheduler thread as one
- * batch and returns; up to two batches run / wait while a third is being filled (submit blocks when all three are
- * busy, i.e. until the blocks of the oldest batch have been released).  Blocks come back in submission order:
+ * batch and returns; up to two batches run / wait while a third is being filled.  When all three are busy
+ * dsrcgpu_submit returns DSRCGPU_E_BUSY without copying anything (it does not wait: the caller may be the thread that has
+ * to collect): take blocks with dsrcgpu_collect, release them, submit again -- a slot is free once every block of the
+ * oldest batch has been released.  Blocks come back in submission order:
  * dsrcgpu_collect returns 1 and a block (a pointer into page-locked memory owned by the handle, valid until
  * dsrcgpu_release), waits while a flushed batch is still running, and returns 0 when everything flushed has been
  * collected; dsrcgpu_try_collect never waits (0 = nothing ready right now).  A batch that failed makes the next call

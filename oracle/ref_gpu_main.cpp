@@ -61,11 +61,12 @@ public:
 private:
 	uint32 batchBlocks, producersExpected;
 
-	// blocks that are ready go to the reference's writer queue; `wait`: also the ones still being compressed
-	bool Drain(dsrcgpu_handle* h, bool wait)
+	// blocks that are ready go to the reference's writer queue; `wait`: also the ones still being compressed; `one`: a single block
+	bool Drain(dsrcgpu_handle* h, bool wait, bool one = false)
 	{
-		for (;;)
+		for (bool first = true;; first = false)
 		{
+			if (one && !first) return true;
 			int64_t id; uint8_t* blk; uint64_t size, raw[4], cmp[4];
 			const int rc = wait ? dsrcgpu_collect(h, &id, &blk, &size, raw, cmp) : dsrcgpu_try_collect(h, &id, &blk, &size, raw, cmp);
 			if (rc == 0) return true;
@@ -91,7 +92,11 @@ private:
 			more = fastqQueue.Pop(partId, chunk);          // the queue the CPU workers pop from
 			if (more)
 			{
-				if (dsrcgpu_submit(h, partId, chunk->data.Pointer(), chunk->size) != DSRCGPU_OK) { errorHandler.SetError(dsrcgpu_last_error(h)); break; }
+				int rc;
+				// ring full: this thread is also the collector -- hand finished blocks to the writer until a slot is free
+				while ((rc = dsrcgpu_submit(h, partId, chunk->data.Pointer(), chunk->size)) == DSRCGPU_E_BUSY)
+					if (!Drain(h, true, true)) break;
+				if (rc != DSRCGPU_OK) { if (!errorHandler.IsError()) errorHandler.SetError(dsrcgpu_last_error(h)); break; }
 				fastqPool.Release(chunk); chunk = NULL; ++pending;
 			}
 			if (pending == batchBlocks || (!more && pending))

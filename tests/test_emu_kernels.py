@@ -147,8 +147,9 @@ def test_queue_form_is_asynchronous_and_ordered(emu, oracle):
     assert h.collect(wait=False) is None
     for lo, hi in ((0, 2), (2, 3), (3, 5)):                     # three batches in flight
         for i in range(lo, hi):
-            h.submit(100 + i, chunks[i])
+            assert h.submit(100 + i, chunks[i])
         h.flush()
+    assert h.submit(105, chunks[5]) is False                    # ring full: reported, not waited for (the caller is the collector)
     got = []
     while True:
         r = h.collect()
@@ -156,7 +157,7 @@ def test_queue_form_is_asynchronous_and_ordered(emu, oracle):
             break
         got.append(r)
     for i in (5, 6):                                            # the ring slots are free again: a fourth and fifth batch
-        h.submit(100 + i, chunks[i]); h.flush()
+        assert h.submit(100 + i, chunks[i]); h.flush()
     while True:
         r = h.collect()
         if r is None:
