@@ -106,6 +106,7 @@ struct dsrcgpu_handle
 	// per-stage HIP-event timing of the last batch: pairs of events around every k_sort launch and every replay group
 	std::vector<hipEvent_t> stage_ev; std::vector<u32> stage_kind; u32 stage_used = 0;       // kind: 0 sort, 1 replay
 	float sort_ms = 0.f, replay_ms = 0.f, decode_stream_ms = 0.f;
+	u64 dec_table_budget = 0;        // dsrcgpu_set_table_budget: HBM a decoding pass may take for model tables (0 = automatic)
 };
 
 namespace
@@ -809,6 +810,7 @@ u64 dec_table_words(const dsrcgpu_settings& set)
 u64 dec_table_budget(const dsrcgpu_handle* h, size_t other)
 {
 	if (const char* env = getenv("DSRC_GPU_DEC_TABLE_MB")) return (u64)atol(env) << 20;
+	if (h->dec_table_budget) return h->dec_table_budget;
 	size_t free_b = 0, total_b = 0;
 	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (u64)8192 << 20;
 	const u64 avail = (u64)free_b + h->arena.cap;             // the arena is re-allocated when it has to grow
@@ -886,6 +888,7 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 
 	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(DecDesc) * B, hipMemcpyHostToDevice, s));
 	hipLaunchKernelGGL(k_dec_tags, dim3(B), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), AP<u8>(h, o_fld), prm); KCHK();
+	if (prm.quality_order == 0) { hipLaunchKernelGGL(k_dec_qhuff, dim3(B), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), prm); KCHK(); }
 	hipLaunchKernelGGL(k_dec_streams, dim3(slots), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), AP<u8>(h, o_d), AP<u32>(h, o_tab), prm); KCHK();
 	{
 		const u32 gx = std::max(1u, std::min(64u, (max_recs + 4 * WAVES - 1) / (4 * WAVES)));
@@ -1348,6 +1351,17 @@ uint32_t dsrcgpu_fields_capacity_after(uint32_t cap, uint32_t n_fields)
 {
 	for (uint32_t i = 0; i < n_fields; ++i) if (i == cap) cap = cap ? cap * 2 : 1;
 	return cap;
+}
+
+int dsrcgpu_set_table_budget(dsrcgpu_handle* h, uint64_t bytes) { if (!h) return DSRCGPU_E_ARG; h->dec_table_budget = bytes; return DSRCGPU_OK; }
+
+int dsrcgpu_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes)
+{
+	size_t f = 0, t = 0;
+	if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) return DSRCGPU_E_HIP;
+	if (free_bytes) *free_bytes = f;
+	if (total_bytes) *total_bytes = t;
+	return DSRCGPU_OK;
 }
 
 int dsrcgpu_prepare(int device)

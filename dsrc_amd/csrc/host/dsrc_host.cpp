@@ -246,6 +246,7 @@ struct Pipeline
 	std::map<uint64, Job*> ready; uint64 nextStart = 0;  // read into page-locked memory, waiting for a scheduler instance (taken in order)
 	std::vector<Pinned*> freeIn;                         // input buffers not in use
 	uint64 claimTurn = 0;                                // the batch whose turn it is to claim its range of the archive
+	uint64 written = 0;                                  // batches whose blocks are in the archive file
 	std::string error;
 	bool Failed() { std::lock_guard<std::mutex> g(m); return !error.empty(); }
 	void Fail(const std::string& e) { std::lock_guard<std::mutex> g(m); if (error.empty()) error = e; cv.notify_all(); }
@@ -373,6 +374,7 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 	ArchiveWriter writer;
 	std::vector<std::unique_ptr<Pinned>> inBufs;
 	uint64 totalBatches = ~0ull;                     // known once the cutter is through (guarded by pl.m)
+	const auto tStart = std::chrono::steady_clock::now();
 	std::vector<std::thread> warm;                   // HIP start-up runs beside the file opening / first-chunk analysis
 	try
 	{
@@ -421,7 +423,6 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 		writer.Start(args.outputFilename);
 
 		const bool trace = getenv("DSRC_HOST_TRACE") != nullptr;
-		const auto tStart = std::chrono::steady_clock::now();
 		// ---- workers ------------------------------------------------------------------------------------------
 		auto work = [&](uint32 idx)
 		{
@@ -430,6 +431,7 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 			try
 			{
 				h = CreateInstance(args, settings, type, devs[idx % devs.size()]);
+				if (trace) fprintf(stderr, "[dsrc-amd] instance %u ready at %.0f ms\n", idx, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tStart).count());
 				for (;;)
 				{
 					Job* job = nullptr;
@@ -477,6 +479,10 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 					}
 					for (uint32 i = 0; i < n; ++i) total += job->osz[i];
 					writer.WriteAt(fileOff, out.p + job->offs[0], total);
+					{
+						std::lock_guard<std::mutex> g(pl.m);
+						++pl.written; pl.cv.notify_all();
+					}
 					if (trace)
 					{
 						const auto t2 = std::chrono::steady_clock::now();
@@ -523,6 +529,7 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 						}
 					}
 					job->in = buf;
+					if (trace && job->seq < 8) fprintf(stderr, "[dsrc-amd] batch %llu read at %.0f ms\n", (unsigned long long)job->seq, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tStart).count());
 					std::lock_guard<std::mutex> g(pl.m);
 					pl.ready[job->seq] = job;
 					pl.cv.notify_all();
@@ -540,6 +547,8 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 		while (more && !pl.Failed())
 		{
 			Job* job = new Job(); job->seq = seq;
+			// (smaller first batches to fill the pipeline sooner were measured SLOWER: arenas and page-locked buffers sized by
+			// a small first batch are re-allocated when the full-size batches arrive, 1.3-1.8 s per instance)
 			while (job->sizes.size() < batch)
 			{
 				if (!havePending) { if (!cutter.Next(start, size)) { more = false; break; } }
@@ -561,15 +570,25 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 		}
 		auto stamp = [&](const char* what) { if (trace) fprintf(stderr, "[dsrc-amd] %s at %.0f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tStart).count()); };
 		stamp("cutter done");
-		for (auto& t : workers) t.join();
-		for (auto& t : readers) t.join();
-		workers.clear(); readers.clear();
-		stamp("instances released");
+		{	// every block is in the file once all batches have been written; the instances may still be tearing down
+			std::unique_lock<std::mutex> g(pl.m);
+			pl.cv.wait(g, [&] { return !pl.error.empty() || pl.written == totalBatches; });
+		}
 		if (!pl.error.empty()) throw DsrcException(pl.error);
 		writer.Finish(type, settings);
 		LogSizes(writer);
+		stamp("archive closed");
+		if (args.exitWhenDone)
+		{	// a command-line process has nothing left to do: skip unmapping ~100 GB of arenas and page-locked buffers
+			if (args.verboseLog) fputs(GetLog().c_str(), stderr);
+			fflush(nullptr);
+			_exit(0);
+		}
+		for (auto& t : workers) t.join();
+		for (auto& t : readers) t.join();
+		workers.clear(); readers.clear();
 		inBufs.clear();
-		stamp("archive closed, buffers released");
+		stamp("instances and buffers released");
 	}
 	catch (const DsrcException& e) { AddError(e.what()); pl.Fail(e.what()); }
 	catch (const std::exception& e) { AddError(e.what()); pl.Fail(e.what()); }
@@ -673,20 +692,32 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 		else { out = fopen(args.outputFilename.c_str(), "wb"); if (!out) throw DsrcException("Cannot open file to write:" + args.outputFilename); }
 
 		const uint64 nBlocks = rd.BlockCount();
+		// A decoding pass is a chain per block: it takes about as long for 1000 blocks as for 10, so
+		// passes are LARGE -- up to 1024 blocks, 3 GiB of archive -- and few handles run at a time: with an order model
+		// every block in flight holds a model table of up to 64 MiB, two handles per device share the HBM for them.
+		const std::vector<int> devs = args.devices.empty() ? std::vector<int>(1, args.device) : args.devices;
+		const bool tables = rd.Settings().dnaOrder > 0 || rd.Settings().qualityOrder > 0;
+		const uint32 perDev = std::min<uint32>(std::max(1u, args.threadNum), tables ? 2u : 4u);
+		const uint32 wanted = perDev * (uint32)devs.size();
 		std::vector<std::pair<uint64, uint64> > batches;
 		{
-			const uint64 budget = 192ull << 20;                 // compressed bytes per scheduler pass (about 0.75 GB of text)
+			const uint64 maxBlocks = args.batchBlocks ? args.batchBlocks : std::max<uint64>(1, std::min<uint64>(1024, (nBlocks + wanted - 1) / wanted));
+			const uint64 budget = 3072ull << 20;
 			uint64 lo = 0, bytes = 0;
 			for (uint64 i = 0; i < nBlocks; ++i)
 			{
 				bytes += rd.BlockSizes()[i];
-				const uint64 cnt = i + 1 - lo;
-				if ((args.batchBlocks && cnt >= args.batchBlocks) || (!args.batchBlocks && bytes >= budget)) { batches.emplace_back(lo, i + 1); lo = i + 1; bytes = 0; }
+				if (i + 1 - lo >= maxBlocks || bytes >= budget) { batches.emplace_back(lo, i + 1); lo = i + 1; bytes = 0; }
 			}
 			if (lo < nBlocks) batches.emplace_back(lo, nBlocks);
 		}
-		const std::vector<int> devs = args.devices.empty() ? std::vector<int>(1, args.device) : args.devices;
-		const uint32 instances = (uint32)std::max<uint64>(1, std::min<uint64>((uint64)std::min<uint32>(std::max(1u, args.threadNum), 8u) * devs.size(), batches.size()));
+		const uint32 instances = (uint32)std::max<uint64>(1, std::min<uint64>(wanted, batches.size()));
+		uint64 tableShare = 0;
+		if (tables)
+		{
+			uint64_t freeB = 0, totalB = 0;
+			if (dsrcgpu_device_memory(devs[0], &freeB, &totalB) == DSRCGPU_OK) tableShare = freeB / 100 * 60 / std::max<uint32>(1, (instances + (uint32)devs.size() - 1) / (uint32)devs.size());
+		}
 		uint64 next = 0, writeTurn = 0;
 
 		auto work = [&](uint32 idx)
@@ -695,6 +726,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 			try
 			{
 				h = CreateDecodeInstance(devs[idx % devs.size()], rd.Settings(), rd.Type());
+				if (tableShare) dsrcgpu_set_table_budget(h, tableShare);
 				Pinned in, text;
 				for (;;)
 				{

@@ -84,6 +84,8 @@ struct InputParameters          // src/Common.h:149-193, plus the GPU knobs at t
 	int device = 0;
 	std::vector<int> devices;      // more than one: scheduler instances are spread over these GPUs of the node (threadNum instances EACH); one archive
 	uint32 batchBlocks = 0;        // chunks per scheduler pass; 0 = as many as fit ~1.5 GiB of input
+	bool exitWhenDone = false;     // command line only: leave the process (_exit) as soon as the output file is complete
+	bool verboseLog = false;       // with exitWhenDone: print the log before leaving
 };
 
 class IDsrcOperator

@@ -97,6 +97,7 @@ int main(int argc, const char* argv[])
 	if (p.threadNum == 0 || p.threadNum > 64) { std::cerr << "Error: invalid thread number specified [1-64]\n"; return -1; }
 	if (!(p.fastqBufferSizeMB >= 1 && p.fastqBufferSizeMB <= 1024)) { std::cerr << "Error: invalid fastq buffer size specified [1-1024] \n"; return -1; }
 
+	p.exitWhenDone = !p.useFastqStdIo; p.verboseLog = verbose;      // a file-to-file run ends when the output is complete
 	comp::IDsrcOperator* op = compress ? (comp::IDsrcOperator*)new comp::DsrcCompressorGPU() : (comp::IDsrcOperator*)new comp::DsrcDecompressorGPU();
 	const bool ok = op->Process(p);
 	if (!ok) std::cerr << op->GetError();

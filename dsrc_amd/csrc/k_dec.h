@@ -844,6 +844,215 @@ __device__ __forceinline__ void dna_order_decode(BitSrc& s, u16* tab, u32 ord, c
 	rd_finish(rd, s);
 }
 
+// ---- stage 3a: quality stream of the -q0 levels (position Huffman, truncated, RLE): wave per block, lane 0 walks -----------
+// The trees of a block (one per read position, ~40 internal nodes each) are parsed into the HBM pool by lane 0, copied
+// into LDS by the wave when they fit (DEC_LDS_NODES words), and the symbol loop then costs one LDS read per code bit and a
+// register shift for the bit stream (64-bit window, refilled 32 bits at a time) instead of two dependent global loads.
+#define DEC_LDS_NODES 11776u          // 46 KB: three workgroups per CU
+
+struct BitWin { u64 w; u32 n; u64 next; };      // w: unread bits at the top; n of them valid; next: byte position of the next refill
+
+__device__ __forceinline__ void bw_init(BitWin& b, const BitSrc& s)
+{
+	b.next = s.bit >> 3; b.w = 0; b.n = 0;
+	const u32 skip = (u32)s.bit & 7u;
+	BitSrc t = s; t.bit = b.next * 8;
+	b.w = (u64)bs_peek32(t) << 32; t.bit += 32; b.w |= (u64)bs_peek32(t);
+	b.next += 8; b.n = 64;
+	b.w <<= skip; b.n -= skip;
+}
+__device__ __forceinline__ void bw_refill(BitWin& b, const BitSrc& s)          // keeps at least 32 valid bits
+{
+	if (b.n < 32)
+	{
+		BitSrc t = s; t.bit = b.next * 8;
+		b.w |= (u64)bs_peek32(t) << (32 - b.n);
+		b.next += 4; b.n += 32;
+	}
+}
+__device__ __forceinline__ u32 bw_bits(BitWin& b, const BitSrc& s, u32 n)       // n <= 32
+{
+	if (n == 0) return 0;
+	bw_refill(b, s);
+	const u32 v = (u32)(b.w >> (64 - n));
+	b.w <<= n; b.n -= n;
+	return v;
+}
+__device__ __forceinline__ void bw_finish(const BitWin& b, BitSrc& s)
+{
+	s.bit = b.next * 8 - b.n;
+	if (s.bit > (u64)s.size * 8) s.err |= DEC_ERR_TRUNC;
+}
+template <typename PT>
+__device__ __forceinline__ u32 bw_huff(BitWin& b, const BitSrc& s, PT T, u32* err)
+{
+	u32 node = 0;
+	for (u32 round = 0; round < 2; ++round)
+	{
+		bw_refill(b, s);
+		u64 w = b.w;
+		for (u32 k = 1; k <= 32; ++k)
+		{
+			const u32 t = T[node];
+			const u32 child = (w >> 63) ? (t >> 16) : (t & 0xFFFFu);
+			w <<= 1;
+			if (child & 0x8000u) { b.w = w; b.n -= k; return child & 0x7FFFu; }
+			node = child;
+		}
+		b.w = w; b.n -= 32;
+	}
+	*err |= DEC_ERR_FORMAT;
+	return 0;
+}
+
+// Plain / Truncated::DecodeRecords (src/QualityPositionModeler.cpp:189-220,291-337) over trees at `W` (HBM pool or its LDS copy)
+template <typename PT>
+__device__ __forceinline__ void qpos_records(BitSrc& s, PT W, u32 dir, u32 maxl, u32 n, const u8* sym, bool truncated, u32 lossy,
+											 const DecDesc& d, DecState* S, RecPools rp, u8* text)
+{
+	BitWin b; bw_init(b, s);
+	const u32 max_bits = dec_bit_length(maxl);
+	const u32 variable = truncated ? bw_bits(b, s, 1) : 0u;
+	const u32 hash_sym = lossy ? 1u : 2u;                    // HashSymbolQuantized / HashSymbolNormal
+	u32 d_total = 0, err = 0;
+	const u32 n_recs = S->n_recs;
+	for (u32 k = 0; k < n_recs && !err; ++k)
+	{
+		const u64 g = (u64)d.rec_base + k;
+		const u32 ql = rp.len[g];
+		u8* q = text + rp.qual_off[g];
+		u32 th = ql, ncount = 0;
+		if (truncated && bw_bits(b, s, 1)) th = bw_bits(b, s, variable ? dec_bit_length(ql) : max_bits);
+		if (th > ql || th > maxl) { err |= DEC_ERR_FORMAT; break; }
+		for (u32 j = 0; j < th; ++j)
+		{
+			const u32 x = bw_huff(b, s, W + W[dir + j], &err);
+			const u32 qv = x < n ? sym[x] : 255u;
+			q[j] = (u8)qv; ncount += q_special(qv, lossy) ? 1u : 0u;
+		}
+		for (u32 j = th; j < ql; ++j) q[j] = (u8)hash_sym;
+		rp.kept[g] = (u16)(ql - ncount); rp.d_off[g] = d_total; d_total += ql - ncount;
+	}
+	S->d_total = d_total;
+	bw_finish(b, s);
+	s.err |= err;
+	bs_align(s);
+}
+
+__global__ void __launch_bounds__(64) k_dec_qhuff(const u8* in, const DecDesc* desc, DecState* st, RecPools rp, u8* out, u32* pool, DecParams prm)
+{
+	__shared__ u32 s_nodes[DEC_LDS_NODES];
+	__shared__ u8 s_sym[256];
+	__shared__ u32 s_par[8];
+	const u32 b = blockIdx.x;
+	DecState* S = &st[b];
+	if (S->err) return;                                   // wave-uniform
+	const DecDesc d = desc[b];
+	u8* text = out + d.out_off;
+	BitSrc s; s.p = in + d.in_off; s.size = d.in_size; s.err = 0; s.bit = (u64)S->qua_pos * 8;
+	NodePool np; np.w = pool + d.qnode_off; np.cap = d.qnode_cap; np.top = 0;
+	const u32 lossy = prm.lossy;
+	u32 q_scheme = 0, dir = 0, maxl = 0, n = 0;
+	if (threadIdx.x == 0)
+	{
+		// scheme byte (IQualityModelerProxy::Decode, src/QualityModelerProxy.h:59-69)
+		q_scheme = bs_byte(s);
+		if (q_scheme > 2) s.err |= DEC_ERR_FORMAT;
+		S->q_scheme = q_scheme;
+		if (!s.err && q_scheme <= 1)
+		{	// IQualityPositionModeler::Decode: statistics, symbols, one tree per position (src/QualityPositionModeler.cpp:39-103)
+			bs_align(s);
+			maxl = bs_word(s);
+			for (u32 i = 0; i < 256; ++i) if (bs_bit(s)) s_sym[n++] = (u8)i;
+			if (maxl > 65535u) s.err |= DEC_ERR_FORMAT;
+			dir = pool_take(np, maxl ? maxl : 1u, &s.err);
+			for (u32 i = 0; i < maxl && !s.err; ++i) { const u32 t = huff_load(s, np); np.w[dir + i] = t; }
+		}
+		s_par[0] = (!s.err && q_scheme <= 1) ? 1u : 0u; s_par[1] = np.top; s_par[2] = dir; s_par[3] = maxl; s_par[4] = n;
+	}
+	__syncthreads();
+	const bool pos_scheme = s_par[0] != 0;
+	const bool in_lds = pos_scheme && s_par[1] <= DEC_LDS_NODES;
+	if (in_lds) for (u32 i = threadIdx.x; i < s_par[1]; i += blockDim.x) s_nodes[i] = np.w[i];
+	__syncthreads();
+	if (threadIdx.x != 0) return;
+	if (pos_scheme)
+	{
+		if (in_lds) qpos_records(s, (const LDS_AS u32*)s_nodes, dir, maxl, n, s_sym, q_scheme == 1, lossy, d, S, rp, text);
+		else qpos_records(s, (const u32*)np.w, dir, maxl, n, s_sym, q_scheme == 1, lossy, d, S, rp, text);
+	}
+	else if (!s.err)
+	{
+		// QualityRLEModeler::Decode (src/QualityRLEModeler.cpp:48-113,380-486); the runs are expanded as they are decoded
+		const u32 run_len = bs_word(s);
+		u8* ls = (u8*)(np.w + pool_take(np, 64, &s.err));       // 256 length symbols
+		u32 qn = 0, ln = 0;
+		for (u32 i = 0; i < 256; ++i) { s_sym[i] = 255; ls[i] = 255; }
+		for (u32 i = 0; i < 256; ++i) if (bs_bit(s)) s_sym[qn++] = (u8)i;
+		for (u32 i = 0; i < 256; ++i) if (bs_bit(s)) ls[ln++] = (u8)i;
+		bs_align(s);
+		if (qn == 0 || ln == 0 || run_len == 0) s.err |= DEC_ERR_FORMAT;
+		u32 qdir = 0, ldir = 0, l_begin = 0, l_end = 0;
+		if (qn > 1 && !s.err)
+		{
+			qdir = pool_take(np, qn, &s.err); ldir = pool_take(np, qn, &s.err);
+			for (u32 i = 0; i < qn && !s.err; ++i) { const u32 a = huff_load(s, np); np.w[qdir + i] = a; const u32 c = huff_load(s, np); np.w[ldir + i] = c; }
+			bs_align(s);
+		}
+		else if (!s.err)
+		{
+			bs_align(s);
+			if (ln > 1)
+			{
+				l_begin = ls[bs_byte(s) & 255u];
+				l_end = ls[0]; if (l_end == l_begin) l_end = ls[1];
+			}
+			else { l_begin = ls[0]; l_end = l_begin; }
+		}
+		u32 cur_len = 0, idx = 0, cur_q = 0, prev = 0, d_total = 0;
+		for (u32 k = 0; k < S->n_recs && !s.err; ++k)
+		{
+			const u64 g = (u64)d.rec_base + k;
+			const u32 ql = rp.len[g];
+			u8* q = text + rp.qual_off[g];
+			u32 ncount = 0;
+			for (u32 j = 0; j < ql; ++j)
+			{
+				if (cur_len == 0)
+				{
+					if (idx >= run_len) { s.err |= DEC_ERR_FORMAT; break; }
+					if (qn > 1)
+					{
+						u32 x = huff_sym(s, np.w + np.w[qdir + prev]);
+						if (x >= qn) { s.err |= DEC_ERR_FORMAT; break; }
+						cur_q = s_sym[x]; prev = x;
+						x = huff_sym(s, np.w + np.w[ldir + prev]);
+						if (x >= ln) { s.err |= DEC_ERR_FORMAT; break; }
+						cur_len = (u32)ls[x] + 1;
+					}
+					else { cur_q = s_sym[0]; cur_len = (idx + 1 == run_len ? l_end : l_begin) + 1; }
+					idx++;
+				}
+				q[j] = (u8)cur_q; --cur_len;
+				ncount += q_special(cur_q, lossy) ? 1u : 0u;
+			}
+			rp.kept[g] = (u16)(ql - ncount); rp.d_off[g] = d_total; d_total += ql - ncount;
+		}
+		// runs the records did not consume are still read by the reference (DecodeRuns comes first)
+		for (; idx < run_len && qn > 1 && !s.err; ++idx)
+		{
+			u32 x = huff_sym(s, np.w + np.w[qdir + prev]);
+			if (x >= qn) { s.err |= DEC_ERR_FORMAT; break; }
+			prev = x;
+			x = huff_sym(s, np.w + np.w[ldir + prev]);
+		}
+		S->d_total = d_total;
+		bs_align(s);
+	}
+	S->dna_pos = bs_pos(s);
+	S->err |= s.err;
+}
+
 __global__ void __launch_bounds__(64) k_dec_streams(const u8* in, const DecDesc* desc, DecState* st, RecPools rp, u8* out, u32* pool,
 													 u8* d_stream, u32* tables, DecParams prm)
 {
@@ -865,7 +1074,9 @@ __global__ void __launch_bounds__(64) k_dec_streams(const u8* in, const DecDesc*
 		// scheme byte (IQualityModelerProxy::Decode, src/QualityModelerProxy.h:59-69); the lossy order proxy has none (:156-159)
 		u32 q_scheme = 0, qN = 8, q_ord = qo, q_rescale = 8;
 		bool q_rc = false, q_translate = false;
-		if (threadIdx.x == 0)
+		const bool q_elsewhere = qo == 0;              // Huffman / RLE schemes: k_dec_qhuff has run, the DNA stream starts at dna_pos
+		if (threadIdx.x == 0 && q_elsewhere) s.bit = (u64)S->dna_pos * 8;
+		if (threadIdx.x == 0 && !q_elsewhere)
 		{
 			if (qo > 0 && lossy) q_rc = true;
 			else
@@ -890,6 +1101,7 @@ __global__ void __launch_bounds__(64) k_dec_streams(const u8* in, const DecDesc*
 			}
 			s_flag = (q_rc && !s.err) ? (qN | (q_ord << 8)) : 0u;
 		}
+		if (threadIdx.x == 0 && q_elsewhere) s_flag = 0;
 		if (threadIdx.x == 0) { s_par[0] = q_rescale; s_par[1] = q_translate ? 1u : 0u; s_par[2] = (u32)s.bit; s_par[3] = (u32)(s.bit >> 32); s_par[4] = q_scheme; }
 		__syncthreads();
 		const u32 flag = s_flag;
@@ -923,7 +1135,7 @@ __global__ void __launch_bounds__(64) k_dec_streams(const u8* in, const DecDesc*
 		}
 		__syncthreads();
 		if (threadIdx.x == 0 && !s.err && q_done) S->dna_pos = bs_pos(s);
-		if (threadIdx.x == 0 && !s.err && !q_done)
+		if (threadIdx.x == 0 && !s.err && !q_done && !q_elsewhere)
 		{
 			S->q_scheme = q_scheme;
 			if (q_rc)
@@ -938,109 +1150,7 @@ __global__ void __launch_bounds__(64) k_dec_streams(const u8* in, const DecDesc*
 				default:  qua_order_decode<128>(s, (u16*)table, q_ord, q_rescale, tr, lossy, d, S, rp, text); break;
 				}
 			}
-			else if (q_scheme <= 1)
-			{
-				// IQualityPositionModeler::Decode + Plain/Truncated::DecodeRecords (src/QualityPositionModeler.cpp:39-103,189-220,291-337)
-				const bool truncated = q_scheme == 1;
-				bs_align(s);
-				const u32 maxl = bs_word(s);
-				u32 n = 0;
-				for (u32 i = 0; i < 256; ++i) if (bs_bit(s)) s_sym[n++] = (u8)i;
-				if (maxl > 65535u) s.err |= DEC_ERR_FORMAT;
-				const u32 dir = pool_take(np, maxl ? maxl : 1u, &s.err);
-				for (u32 i = 0; i < maxl && !s.err; ++i) { const u32 t = huff_load(s, np); np.w[dir + i] = t; }
-				const u32 max_bits = dec_bit_length(maxl);
-				const u32 variable = truncated ? bs_bit(s) : 0u;
-				const u32 hash_sym = lossy ? 1u : 2u;                    // HashSymbolQuantized / HashSymbolNormal
-				u32 d_total = 0;
-				for (u32 k = 0; k < S->n_recs && !s.err; ++k)
-				{
-					const u64 g = (u64)d.rec_base + k;
-					const u32 ql = rp.len[g];
-					u8* q = text + rp.qual_off[g];
-					u32 th = ql, ncount = 0;
-					if (truncated && bs_bit(s)) th = bs_bits(s, variable ? dec_bit_length(ql) : max_bits);
-					if (th > ql || th > maxl) { s.err |= DEC_ERR_FORMAT; break; }
-					for (u32 j = 0; j < th; ++j)
-					{
-						const u32 x = huff_sym(s, np.w + np.w[dir + j]);
-						const u32 qv = x < n ? s_sym[x] : 255u;
-						q[j] = (u8)qv; ncount += q_special(qv, lossy) ? 1u : 0u;
-					}
-					for (u32 j = th; j < ql; ++j) q[j] = (u8)hash_sym;
-					rp.kept[g] = (u16)(ql - ncount); rp.d_off[g] = d_total; d_total += ql - ncount;
-				}
-				S->d_total = d_total;
-				bs_align(s);
-			}
-			else
-			{
-				// QualityRLEModeler::Decode (src/QualityRLEModeler.cpp:48-113,380-486); the runs are expanded as they are decoded
-				const u32 run_len = bs_word(s);
-				u8* ls = (u8*)(np.w + pool_take(np, 64, &s.err));       // 256 length symbols
-				u32 qn = 0, ln = 0;
-				for (u32 i = 0; i < 256; ++i) { s_sym[i] = 255; ls[i] = 255; }
-				for (u32 i = 0; i < 256; ++i) if (bs_bit(s)) s_sym[qn++] = (u8)i;
-				for (u32 i = 0; i < 256; ++i) if (bs_bit(s)) ls[ln++] = (u8)i;
-				bs_align(s);
-				if (qn == 0 || ln == 0 || run_len == 0) s.err |= DEC_ERR_FORMAT;
-				u32 qdir = 0, ldir = 0, l_begin = 0, l_end = 0;
-				if (qn > 1 && !s.err)
-				{
-					qdir = pool_take(np, qn, &s.err); ldir = pool_take(np, qn, &s.err);
-					for (u32 i = 0; i < qn && !s.err; ++i) { const u32 a = huff_load(s, np); np.w[qdir + i] = a; const u32 c = huff_load(s, np); np.w[ldir + i] = c; }
-					bs_align(s);
-				}
-				else if (!s.err)
-				{
-					bs_align(s);
-					if (ln > 1)
-					{
-						l_begin = ls[bs_byte(s) & 255u];
-						l_end = ls[0]; if (l_end == l_begin) l_end = ls[1];
-					}
-					else { l_begin = ls[0]; l_end = l_begin; }
-				}
-				u32 cur_len = 0, idx = 0, cur_q = 0, prev = 0, d_total = 0;
-				for (u32 k = 0; k < S->n_recs && !s.err; ++k)
-				{
-					const u64 g = (u64)d.rec_base + k;
-					const u32 ql = rp.len[g];
-					u8* q = text + rp.qual_off[g];
-					u32 ncount = 0;
-					for (u32 j = 0; j < ql; ++j)
-					{
-						if (cur_len == 0)
-						{
-							if (idx >= run_len) { s.err |= DEC_ERR_FORMAT; break; }
-							if (qn > 1)
-							{
-								u32 x = huff_sym(s, np.w + np.w[qdir + prev]);
-								if (x >= qn) { s.err |= DEC_ERR_FORMAT; break; }
-								cur_q = s_sym[x]; prev = x;
-								x = huff_sym(s, np.w + np.w[ldir + prev]);
-								if (x >= ln) { s.err |= DEC_ERR_FORMAT; break; }
-								cur_len = (u32)ls[x] + 1;
-							}
-							else { cur_q = s_sym[0]; cur_len = (idx + 1 == run_len ? l_end : l_begin) + 1; }
-							idx++;
-						}
-						q[j] = (u8)cur_q; --cur_len;
-						ncount += q_special(cur_q, lossy) ? 1u : 0u;
-					}
-					rp.kept[g] = (u16)(ql - ncount); rp.d_off[g] = d_total; d_total += ql - ncount;
-				}
-				// runs the records did not consume are still read by the reference (DecodeRuns comes first)
-				for (; idx < run_len && qn > 1 && !s.err; ++idx)
-				{
-					u32 x = huff_sym(s, np.w + np.w[qdir + prev]);
-					if (x >= qn) { s.err |= DEC_ERR_FORMAT; break; }
-					prev = x;
-					x = huff_sym(s, np.w + np.w[ldir + prev]);
-				}
-				S->d_total = d_total;
-				bs_align(s);
-			}
+			else s.err |= DEC_ERR_FORMAT;          // quality_order == 0 is decoded by k_dec_qhuff
 			S->dna_pos = bs_pos(s);
 		}
 

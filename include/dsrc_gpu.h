@@ -174,6 +174,12 @@ int dsrcgpu_chain_seed(dsrcgpu_chain* c, uint32_t fields_capacity);      /* befo
  * Not combinable with tag_preserve_flags or calculate_crc32 (the reference's archive API drops both). */
 int dsrcgpu_set_record_layout(dsrcgpu_handle* h, uint32_t n, const uint32_t* chunk_sizes);
 
+/* Decoding the order-context levels keeps one adaptive model table per block in flight (up to 64 MiB at -q2, DESIGN.md
+ * section 11); by default a pass takes 70 % of the HBM that is free when it starts.  Hosts that run several decoding
+ * handles on one device give each its share: dsrcgpu_set_table_budget(h, bytes) (0 = automatic again). */
+int dsrcgpu_set_table_budget(dsrcgpu_handle* h, uint64_t bytes);
+int dsrcgpu_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
+
 /* Optional: brings up the HIP runtime and the device context (the first HIP call of a process costs 0.3-1 s); call it on a
  * side thread while the host opens its files. */
 int dsrcgpu_prepare(int device);
