@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--qua", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=int(os.environ.get("DSRC_BENCH_CPU_BLOCKS", "480")), help="8 MiB chunks of the CPU baseline sample (480 = 4 GB)")
-    ap.add_argument("--decode-blocks", type=int, default=int(os.environ.get("DSRC_BENCH_DECODE_BLOCKS", "1200")),
+    ap.add_argument("--decode-blocks", type=int, default=int(os.environ.get("DSRC_BENCH_DECODE_BLOCKS", "2400")),
                     help="blocks of the secondary decompression measurement (0 = skip)")
     ap.add_argument("--check", type=int, default=2, help="blocks of the first sub-batch to verify against the oracle")
     args = ap.parse_args()

@@ -655,8 +655,11 @@ void ArchiveReader::ReadBlock(uint64 i, uchar* dst) const
 // Text bytes to reserve for consecutive blocks.  A block written from a FASTQ file declares its own chunk size (+1 for the
 // last newline, src/BlockCompressor.cpp:279-281); one written by the record-level API declares a running total over the
 // archive (BlockCompressor::Reset does not clear it, src/BlockCompressorExt.cpp:126), i.e. its own size is the difference
-// to the block before.  `exact` = false asks for the always-sufficient figure (used when the first try did not fit).
-void TextCaps(const std::vector<uint32>& words, uint32 wordBefore, bool haveBefore, bool exact, std::vector<uint64_t>& caps)
+// to the block before.  The difference is taken for the size only where it is plausible -- smaller than the word itself and
+// not smaller than the block's compressed size (consecutive chunks of a file archive differ by a few KB, a block of text
+// is larger than its compressed form).  `exact` = false asks for the always-sufficient figure (used when the first try
+// did not fit).
+void TextCaps(const std::vector<uint32>& words, const std::vector<uint64_t>& blockSizes, uint32 wordBefore, bool haveBefore, bool exact, std::vector<uint64_t>& caps)
 {
 	caps.resize(words.size());
 	uint32 prev = wordBefore; bool have = haveBefore;
@@ -664,7 +667,7 @@ void TextCaps(const std::vector<uint32>& words, uint32 wordBefore, bool haveBefo
 	{
 		const uint64 own = (uint64)words[i] + 1;
 		const uint64 diff = (uint64)(uint32)(words[i] - prev) + 1;
-		caps[i] = (exact && have && diff > 1 && diff < own) ? diff : own;
+		caps[i] = (exact && have && diff < own && diff >= blockSizes[i]) ? diff : own;
 		prev = words[i]; have = true;
 	}
 }
@@ -758,7 +761,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 					int rc = DSRCGPU_OK;
 					for (int attempt = 0; attempt < 2; ++attempt)
 					{
-						TextCaps(words, before, haveBefore, attempt == 0, caps);
+						TextCaps(words, sizes, before, haveBefore, attempt == 0, caps);
 						uint64 cap = 0; for (uint64 c : caps) cap += c;
 						text.Reserve(cap + 64);
 						rc = dsrcgpu_decompress_batch(h, n, ptrs.data(), sizes.data(), caps.data(), text.p, text.cap, offs.data(), tsz.data(), nullptr);
@@ -1030,7 +1033,7 @@ bool DsrcArchive::FeedBatch()
 	int rc = DSRCGPU_OK;
 	for (int attempt = 0; attempt < 2; ++attempt)
 	{
-		comp::TextCaps(words, impl->lastWord, impl->haveLastWord, attempt == 0, caps);
+		comp::TextCaps(words, sizes, impl->lastWord, impl->haveLastWord, attempt == 0, caps);
 		uint64 cap = 0; for (uint64 c : caps) cap += c;
 		impl->text.resize(cap + 64);
 		rc = dsrcgpu_decompress_batch(impl->h, n, ptrs.data(), sizes.data(), caps.data(), impl->text.data(), impl->text.size(), offs.data(), tsz.data(), nullptr);

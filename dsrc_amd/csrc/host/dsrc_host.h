@@ -195,7 +195,7 @@ private:
 
 // helpers shared with the record-level API
 uint64 GetBE(const uchar* p, int bytes);
-void TextCaps(const std::vector<uint32>& words, uint32 wordBefore, bool haveBefore, bool exact, std::vector<uint64_t>& caps);
+void TextCaps(const std::vector<uint32>& words, const std::vector<uint64_t>& blockSizes, uint32 wordBefore, bool haveBefore, bool exact, std::vector<uint64_t>& caps);
 dsrcgpu_handle* CreateDecodeInstance(int device, const CompressionSettings& settings, const fq::FastqDatasetType& type);
 
 } // namespace comp
