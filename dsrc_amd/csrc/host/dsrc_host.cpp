@@ -235,6 +235,7 @@ struct Job          // one batch
 	std::vector<uint64> fileOff; std::vector<uint64_t> sizes;          // chunk i = file[fileOff[i], +sizes[i])
 	// filled by a reader thread
 	Pinned* in = nullptr; std::vector<uint64> at; uint64 inBytes = 0;
+	uint32 nextPart = 0, chunksLeft = 0;                               // reading in parts (guarded by Pipeline::m)
 	// results
 	std::vector<uint64_t> offs, osz, raw, comp;
 };
@@ -243,6 +244,7 @@ struct Pipeline
 {
 	std::mutex m; std::condition_variable cv;
 	std::deque<Job*> todo; bool noMore = false;          // cut, waiting for a reader
+	std::vector<Job*> reading;                           // being read into their buffer, part by part
 	std::map<uint64, Job*> ready; uint64 nextStart = 0;  // read into page-locked memory, waiting for a scheduler instance (taken in order)
 	std::vector<Pinned*> freeIn;                         // input buffers not in use
 	uint64 claimTurn = 0;                                // the batch whose turn it is to claim its range of the archive
@@ -497,7 +499,10 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 		for (uint32 i = 0; i < instances; ++i) workers.emplace_back(work, i);
 
 		// ---- readers: file -> page-locked memory, ahead of the scheduler instances -----------------------------------
-		const uint32 nReaders = std::min<uint32>(8, 2 * instances);     // pread = copies out of the page cache: they scale with threads
+		// A batch is read by SEVERAL threads (parts of 16 chunks): one thread copies out of the page cache at ~2 GB/s, so a
+		// 1.6 GB batch read by one thread takes 0.9 s and (instances + 2) buffers in flight cap the pipeline at ~10 GB/s.
+		const uint32 nReaders = std::min<uint32>(16, 4 * instances);
+		const uint32 partChunks = 16;
 		for (uint32 i = 0; i < instances + 2; ++i) { inBufs.emplace_back(new Pinned()); pl.freeIn.push_back(inBufs.back().get()); }
 		auto readLoop = [&]()
 		{
@@ -505,33 +510,54 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 			{
 				for (;;)
 				{
-					Job* job = nullptr; Pinned* buf = nullptr;
+					Job* job = nullptr; uint32 lo = 0, hi = 0;
 					{
 						std::unique_lock<std::mutex> g(pl.m);
-						pl.cv.wait(g, [&] { return !pl.error.empty() || (!pl.todo.empty() && !pl.freeIn.empty()) || (pl.noMore && pl.todo.empty()); });
-						if (!pl.error.empty() || pl.todo.empty()) return;
-						job = pl.todo.front(); pl.todo.pop_front();
-						buf = pl.freeIn.back(); pl.freeIn.pop_back();
-						pl.cv.notify_all();
+						for (;;)
+						{
+							if (!pl.error.empty()) return;
+							// a part of a batch that is being read ...
+							for (Job* j : pl.reading) if (j->nextPart < j->sizes.size()) { job = j; break; }
+							if (job) { lo = job->nextPart; hi = std::min<uint32>((uint32)job->sizes.size(), lo + partChunks); job->nextPart = hi; break; }
+							// ... or the next batch, once a buffer is free for it (its page-locked memory is sized here)
+							if (!pl.todo.empty() && !pl.freeIn.empty())
+							{
+								Job* j = pl.todo.front(); pl.todo.pop_front();
+								Pinned* buf = pl.freeIn.back(); pl.freeIn.pop_back();
+								const uint32 n = (uint32)j->sizes.size();
+								j->at.resize(n); j->inBytes = 0;
+								for (uint32 i = 0; i < n; ++i) { j->at[i] = j->inBytes; j->inBytes += (j->sizes[i] + 4096) & ~(uint64)4095; }
+								j->in = buf; j->nextPart = n; j->chunksLeft = n;          // parts are handed out once the buffer exists
+								pl.reading.push_back(j);
+								g.unlock();
+								buf->Reserve(j->inBytes);
+								g.lock();
+								j->nextPart = 0;
+								pl.cv.notify_all();
+								continue;
+							}
+							if (pl.noMore && pl.todo.empty() && pl.reading.empty()) return;
+							pl.cv.wait(g);
+						}
 					}
-					const uint32 n = (uint32)job->sizes.size();
-					job->at.resize(n); job->inBytes = 0;
-					for (uint32 i = 0; i < n; ++i) { job->at[i] = job->inBytes; job->inBytes += (job->sizes[i] + 4096) & ~(uint64)4095; }
-					buf->Reserve(job->inBytes);
-					for (uint32 i = 0; i < n; ++i)
+					for (uint32 i = lo; i < hi; ++i)
 					{
 						uint64 got = 0;
 						while (got < job->sizes[i])
 						{
-							const ssize_t r = pread(fd, buf->p + job->at[i] + got, job->sizes[i] - got, (off_t)(job->fileOff[i] + got));
+							const ssize_t r = pread(fd, job->in->p + job->at[i] + got, job->sizes[i] - got, (off_t)(job->fileOff[i] + got));
 							if (r <= 0) throw DsrcException("read error");
 							got += (uint64)r;
 						}
 					}
-					job->in = buf;
-					if (trace && job->seq < 8) fprintf(stderr, "[dsrc-amd] batch %llu read at %.0f ms\n", (unsigned long long)job->seq, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tStart).count());
 					std::lock_guard<std::mutex> g(pl.m);
-					pl.ready[job->seq] = job;
+					job->chunksLeft -= hi - lo;
+					if (job->chunksLeft == 0)
+					{
+						pl.reading.erase(std::find(pl.reading.begin(), pl.reading.end(), job));
+						if (trace && job->seq < 8) fprintf(stderr, "[dsrc-amd] batch %llu read at %.0f ms\n", (unsigned long long)job->seq, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tStart).count());
+						pl.ready[job->seq] = job;
+					}
 					pl.cv.notify_all();
 				}
 			}
@@ -600,6 +626,7 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 	for (auto& t : workers) if (t.joinable()) t.join();
 	for (auto& t : readers) if (t.joinable()) t.join();
 	for (Job* j : pl.todo) delete j;
+	for (Job* j : pl.reading) delete j;
 	for (auto& kv : pl.ready) delete kv.second;
 	if (chain) dsrcgpu_chain_destroy(chain);
 	if (fd >= 0) close(fd);
