@@ -216,17 +216,23 @@ namespace
 {
 struct Pinned
 {
-	uchar* p = nullptr; uint64 cap = 0;
+	uchar* p = nullptr; uint64 cap = 0; bool pageable = false;
 	void Reserve(uint64 n)
 	{
 		if (n <= cap) return;
-		if (p) dsrcgpu_host_free(p);
-		p = nullptr; cap = 0;
+		Release();
+		// Plain (pageable) memory by default: page-locking costs ~0.23 s per 1.6 GB and the runtime serialises it with every
+		// other HIP call of the process, so locking the ~13 GB of batch buffers held the first passes back by 1.5-2 s
+		// (measured: 38.5 GB file 6.7 s -> 4.8 s); the copies are staged by the runtime, inside the worker's own thread.
+		// DSRC_HOST_PINNED=1 brings the page-locked buffers back.
+		static const bool usePageable = getenv("DSRC_HOST_PINNED") == nullptr;
 		void* q = nullptr;
-		if (dsrcgpu_host_alloc(n, &q) != DSRCGPU_OK) throw DsrcException("cannot allocate page-locked host memory");
+		if (usePageable) { if (posix_memalign(&q, 2u << 20, n) != 0) throw DsrcException("out of memory"); pageable = true; }
+		else if (dsrcgpu_host_alloc(n, &q) != DSRCGPU_OK) throw DsrcException("cannot allocate page-locked host memory");
 		p = (uchar*)q; cap = n;
 	}
-	~Pinned() { if (p) dsrcgpu_host_free(p); }
+	void Release() { if (p) { if (pageable) free(p); else dsrcgpu_host_free(p); } p = nullptr; cap = 0; pageable = false; }
+	~Pinned() { Release(); }
 };
 
 struct Job          // one batch

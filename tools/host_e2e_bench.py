@@ -43,14 +43,22 @@ def main():
     h.close()
     size = os.path.getsize(src)
     res = {}
-    extra = sys.argv[3:]          # e.g. -n384, or several instance counts as "-t6"
-    runs = [("dsrc-amd -t%d %s" % (inst, " ".join(extra)), [CLI, "c", "-d3", "-q2", f"-t{inst}", *extra, src, ours])]
-    runs.append((runs[0][0] + " (2nd run)", runs[0][1]))
+    # extra switches, e.g. -n384; several variants separated by "/" (each is run twice): -n96 / -n96 -t6 / -n64 -t8
+    variants = [v.split() for v in " ".join(sys.argv[3:]).split("/")] if len(sys.argv) > 3 else [[]]
+    runs = []
+    for extra in variants:
+        name = "dsrc-amd -t%d %s" % (inst, " ".join(extra))
+        cmd = [CLI, "c", "-d3", "-q2", f"-t{inst}", *extra, src, ours]
+        runs += [(name, cmd), (name + " (2nd run)", cmd)]
     if not os.environ.get("E2E_NO_REF"):
         runs.append(("reference -t60", [REF, "c", "-d3", "-q2", "-t60", src, theirs]))
     for name, cmd in runs:
         if not os.path.exists(cmd[0]):
             continue
+        if os.environ.get("E2E_GAP"):          # separate the runs: remove the previous archive, let the driver reclaim the previous process's memory
+            if cmd[0] == CLI and os.path.exists(ours):
+                os.remove(ours)
+            time.sleep(float(os.environ["E2E_GAP"]))
         t = time.time(); subprocess.check_call(cmd); dt = time.time() - t
         res[name] = size / dt / 1e6
         print(f"{name:30s}: {size / 1e9:.2f} GB in {dt:6.2f} s = {size / dt / 1e6:8.1f} MB/s")
