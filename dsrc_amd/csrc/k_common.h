@@ -68,7 +68,7 @@ __device__ __forceinline__ u32 wave_sum(u32 v)
 // exclusive scan over the workgroup (must be called by every thread); *total = sum of all v
 __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* total)
 {
-	__shared__ u32 s_w[WAVES];
+	__shared__ u32 s_w[16];          // up to 1024 threads whatever DSRC_WG is (k_sort may use a larger workgroup than the other kernels)
 	const u32 inc = wave_incl_scan(v);
 	if (lane_id() == 63) s_w[wave_id()] = inc;
 	__syncthreads();
