@@ -17,6 +17,9 @@
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#ifndef DSRC_REPLAY_WHATIF
+#define DSRC_REPLAY_WHATIF 0     // experiments only: a k_replay PROBE mode for the whole run (wrong output)
+#endif
 #include <string>
 #include <thread>
 #include <vector>
@@ -106,6 +109,7 @@ struct dsrcgpu_handle
 	// per-stage HIP-event timing of the last batch: pairs of events around every k_sort launch and every replay group
 	std::vector<hipEvent_t> stage_ev; std::vector<u32> stage_kind; u32 stage_used = 0;       // kind: 0 sort, 1 replay
 	float sort_ms = 0.f, replay_ms = 0.f, decode_stream_ms = 0.f;
+	bool sort_atomic = false;        // k_sort ranks with LDS atomics (device passed k_lds_order_test), else with ballots
 	u64 dec_table_budget = 0;        // dsrcgpu_set_table_budget: HBM a decoding pass may take for model tables (0 = automatic)
 };
 
@@ -654,12 +658,29 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	if (NJ)
 	{
 		const u32 nq = (u32)qjobs.size(), nd = (u32)djobs.size();
+		const bool sort_atomic = h->sort_atomic;
 		hipLaunchKernelGGL(k_rc_headers, dim3((NJ + 63) / 64), dim3(64), 0, s, d_jobs, NJ, d_state, wpool); KCHK();
 		for (size_t sl = 0; sl + 1 < slice_lo.size(); ++sl)
 		{
 			const u32 s_lo = slice_lo[sl], s_hi = slice_lo[sl + 1];
 			stage_mark(0);
-			hipLaunchKernelGGL(k_sort, dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state); KCHK();
+#ifdef DSRC_SORT_PROBE
+			{	// timing experiments (not a product path): what each phase of k_sort costs, first slice of the first batches
+				static int shots = 0;
+				if (sl == 0 && shots < 2)
+				{
+					++shots;
+					hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+#define PROBE_RUN(M) { hipEventRecord(e0, s); if (sort_atomic) hipLaunchKernelGGL((k_sort<M, true>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state); else hipLaunchKernelGGL((k_sort<M, false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state); \
+					hipEventRecord(e1, s); hipEventSynchronize(e1); float ms = 0; hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[probe] k_sort<%u> %u streams: %.2f ms\n", (unsigned)M, s_hi - s_lo, ms); }
+					PROBE_RUN(0) PROBE_RUN(0) PROBE_RUN(128) PROBE_RUN(129) PROBE_RUN(130) PROBE_RUN(132) PROBE_RUN(134) PROBE_RUN(136) PROBE_RUN(144) PROBE_RUN(160) PROBE_RUN(192) PROBE_RUN(255)
+					hipEventDestroy(e0); hipEventDestroy(e1);
+				}
+			}
+#endif
+			if (sort_atomic) hipLaunchKernelGGL((k_sort<0, true>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state);
+			else hipLaunchKernelGGL((k_sort<0, false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state);
+			KCHK();
 			stage_mark(0); stage_mark(1);
 			for (u32 lo = s_lo; lo < s_hi;)
 			{
@@ -667,18 +688,37 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 				while (hi < s_hi && jobs[hi].n_alpha == jobs[lo].n_alpha) ++hi;
 				const u32 cnt = hi - lo;
 				u32 mxn = 1; for (u32 i = lo; i < hi; ++i) mxn = std::max(mxn, jobs[i].n);
-				// REPLAY_WG/64 waves per part.  Many waves per chain = few chains in flight: the scattered 12-byte records of
-				// a chain then merge in the memory-side cache (measured: 32 parts 164 ms, 512 parts 71 ms per 512 DNA chains)
-				static const u32 max_parts = getenv("DSRC_GPU_REPLAY_PARTS") ? (u32)atoi(getenv("DSRC_GPU_REPLAY_PARTS")) : 512u;   // tuning knob
+				// REPLAY_WG/64 waves per part.  Many waves per chain = few chains in flight: the scattered 12-byte records of a
+				// chain have to meet in the memory-side cache before their line is evicted, and with several scheduler instances
+				// streaming through that cache the time a chain is open counts (one instance, 512 DNA chains: 32 parts 164 ms,
+				// 512 parts 71 ms; five instances: 256 parts 21.4, 512 23.3, 1024 24.3, 2048 24.7, 3200 23.2 GB/s)
+				static const u32 max_parts = getenv("DSRC_GPU_REPLAY_PARTS") ? (u32)atoi(getenv("DSRC_GPU_REPLAY_PARTS")) : 2048u;   // tuning knob
 				const u32 parts = std::max(1u, std::min(max_parts, mxn / 1024u));
+				const dim3 rgrid(parts * cnt);                           // replay_slot
+#ifdef DSRC_SORT_PROBE
+				{
+					static int shots = 0;
+					if ((jobs[lo].n_alpha == 32 || jobs[lo].n_alpha == 4) && lo == s_lo && shots < 4 && (sl == 0 || sl + 2 == slice_lo.size()))
+					{
+						++shots;
+						hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+#define RPROBE_RUN(NN, M) { hipEventRecord(e0, s); hipLaunchKernelGGL((k_replay<NN, M>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0), parts, cnt); \
+						hipEventRecord(e1, s); hipEventSynchronize(e1); float ms = 0; hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[probe] k_replay<%d,%d> %u streams x %u parts: %.2f ms\n", NN, M, cnt, parts, ms); }
+						hipLaunchKernelGGL(k_replay_seams<32>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt);
+						if (jobs[lo].n_alpha == 32) { RPROBE_RUN(32, 0) RPROBE_RUN(32, 0) RPROBE_RUN(32, 1) RPROBE_RUN(32, 2) RPROBE_RUN(32, 8) RPROBE_RUN(32, 16) RPROBE_RUN(32, 32) }
+						else { RPROBE_RUN(4, 0) RPROBE_RUN(4, 0) RPROBE_RUN(4, 1) RPROBE_RUN(4, 2) RPROBE_RUN(4, 8) RPROBE_RUN(4, 16) RPROBE_RUN(4, 32) }
+						hipEventDestroy(e0); hipEventDestroy(e1);
+					}
+				}
+#endif
 				switch (jobs[lo].n_alpha)
 				{
-				case 4:   hipLaunchKernelGGL(k_replay_seams<4>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool)); hipLaunchKernelGGL(k_replay<4>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
-				case 8:   hipLaunchKernelGGL(k_replay_seams<8>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool)); hipLaunchKernelGGL(k_replay<8>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
-				case 16:  hipLaunchKernelGGL(k_replay_seams<16>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool)); hipLaunchKernelGGL(k_replay<16>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
-				case 32:  hipLaunchKernelGGL(k_replay_seams<32>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool)); hipLaunchKernelGGL(k_replay<32>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
-				case 64:  hipLaunchKernelGGL(k_replay_seams<64>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool)); hipLaunchKernelGGL(k_replay<64>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
-				default:  hipLaunchKernelGGL(k_replay_seams<128>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool)); hipLaunchKernelGGL(k_replay<128>, dim3(parts, cnt), dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0)); break;
+				case 4:   hipLaunchKernelGGL(k_replay_seams<4>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<4, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0), parts, cnt); break;
+				case 8:   hipLaunchKernelGGL(k_replay_seams<8>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<8, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0), parts, cnt); break;
+				case 16:  hipLaunchKernelGGL(k_replay_seams<16>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<16, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0), parts, cnt); break;
+				case 32:  hipLaunchKernelGGL(k_replay_seams<32>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<32, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0), parts, cnt); break;
+				case 64:  hipLaunchKernelGGL(k_replay_seams<64>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<64, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0), parts, cnt); break;
+				default:  hipLaunchKernelGGL(k_replay_seams<128>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<128, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0), parts, cnt); break;
 				}
 				KCHK();
 				lo = hi;
@@ -1021,6 +1061,30 @@ int dsrcgpu_create(const dsrcgpu_settings* settings, const dsrcgpu_dataset* data
 		for (u32 k = 1; k < 32; ++k) { p = mul(p, p); tab[256 + k] = p; }
 		HIPCHK(hipMalloc((void**)&h->d_crc_tab, sizeof(tab)));
 		HIPCHK(hipMemcpy(h->d_crc_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
+	}
+	{	// which ranking variant of k_sort this device gets (once per device and process): the LDS-atomic one needs the lanes of
+		// one LDS atomic instruction applied in lane order, which is measured here, not assumed.  DSRC_GPU_SORT_BALLOT=1 keeps
+		// the ballot variant (tests compare the two).
+		static std::mutex mu; static int known[64];               // 0 unknown, 1 ordered, 2 not
+		std::lock_guard<std::mutex> lk(mu);
+		int& k = known[device & 63];
+		if (k == 0)
+		{
+			u32* d_bad = nullptr; u32 bad = 1;
+			HIPCHK(hipMalloc((void**)&d_bad, 4));
+			HIPCHK(hipMemsetAsync(d_bad, 0, 4, h->stream));
+			#ifdef DSRC_EMU_BUILD
+			hipLaunchKernelGGL(k_lds_order_test, dim3(1), dim3(256), 0, h->stream, d_bad, 20u); KCHK();       // the CPU emulator runs lanes in order anyway
+#else
+			hipLaunchKernelGGL(k_lds_order_test, dim3(256), dim3(256), 0, h->stream, d_bad, 4096u); KCHK();   // 4 M wave patterns, < 1 ms
+#endif
+			HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, h->stream));
+			HIPCHK(hipStreamSynchronize(h->stream));
+			HIPCHK(hipFree(d_bad));
+			k = bad ? 2 : 1;
+			if (bad && getenv("DSRC_GPU_DEBUG")) fprintf(stderr, "[dsrc_gpu] LDS atomics are not applied in lane order on device %d: k_sort ranks with ballots\n", device);
+		}
+		h->sort_atomic = k == 1 && !getenv("DSRC_GPU_SORT_BALLOT");
 	}
 	if (arena_bytes) { rc = ensure_arena(h, (size_t)arena_bytes); if (rc) return rc; }
 	return DSRCGPU_OK;

@@ -640,23 +640,7 @@ __device__ __forceinline__ void qua_order_decode(BitSrc& s, u16* tab, u32 ord, u
 	S->d_total = d_total;
 }
 
-// inclusive prefix sum over the wave with DPP row shifts / row broadcasts (gfx9: v_add with a dpp modifier, ~2 cycles a
-// step) instead of six ds_bpermute round trips through the LDS crossbar
-__device__ __forceinline__ u32 dec_wave_scan(u32 v)
-{
-#ifdef DSRC_EMU_BUILD
-	return wave_incl_scan(v);
-#else
-	int x = (int)v;
-	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);      // row_shr:1
-	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);      // row_shr:2
-	x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);      // row_shr:4
-	x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);      // row_shr:8
-	x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
-	x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
-	return (u32)x;
-#endif
-}
+__device__ __forceinline__ u32 dec_wave_scan(u32 v) { return wave_incl_scan_dpp(v); }
 // value of lane `l` (wave-uniform) as a scalar: v_readlane with the lane number in an SGPR
 __device__ __forceinline__ u32 dec_readlane(u32 v, u32 l)
 {

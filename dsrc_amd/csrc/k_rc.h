@@ -176,8 +176,10 @@ __device__ __forceinline__ u32 ctx_digit0(const CtxJob& j, const u8* s, const u8
 // run of 64*SORT_ITEMS elements of the tile and walks it 64 at a time: equal-digit lanes are found with one
 // ballot per digit bit, the wave's private counter row in LDS gives the running rank, and a per-digit
 // scan over the waves turns the rows into global offsets once per tile.
-#define SORT_MAX_BINS 512
-#define SORT_DIGIT_BITS 9
+#ifndef SORT_DIGIT_BITS
+#define SORT_DIGIT_BITS 10     // 20-bit quality contexts (32 symbols, order 3) in two passes instead of three: k_sort 73.5 -> 64.7 ms per 512 blocks
+#endif
+#define SORT_MAX_BINS (1 << SORT_DIGIT_BITS)
 #ifndef SORT_ITEMS
 #define SORT_ITEMS 8
 #endif
@@ -185,24 +187,35 @@ __device__ __forceinline__ u32 ctx_digit0(const CtxJob& j, const u8* s, const u8
 #define SORT_WG WG
 #endif
 #define SORT_WAVES (SORT_WG / 64)
-__global__ void __launch_bounds__(SORT_WG) k_sort(const CtxJob* jobs, u64* pool, const u8* d_stream, const u8* q_stream, const u8* qp_stream, BlkState* st)
+#ifndef SORT_OCC
+#define SORT_OCC 4          // waves per SIMD the register allocation aims at
+#endif
+// PROBE != 0: timing experiments only (tools/variant_bench.sh, -DDSRC_SORT_PROBE), the output is not a sort.  Every probe writes
+// tile position p to dst[tile + p]; 1 no digit-0 histogram, 2 no ranking, 4 no per-tile scan, 8 nothing leaves the registers,
+// 16 no global store, 32 elements made up instead of loaded / computed, 64 no next-digit histogram
+template <u32 PROBE, bool ATOMIC>
+__global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SORT_OCC, SORT_OCC))) k_sort(const CtxJob* jobs, u64* pool, const u8* d_stream, const u8* q_stream, const u8* qp_stream, BlkState* st)
 {
-	__shared__ u32 s_base[SORT_MAX_BINS];
+	__shared__ u32 s_base[SORT_MAX_BINS];                 // where the next element of a digit goes (index into dst)
 	__shared__ u32 s_next[SORT_MAX_BINS];
-	__shared__ u16 s_cnt[SORT_WAVES][SORT_MAX_BINS];      // per tile a wave ranks 64*SORT_ITEMS elements: 16 bits are plenty, and with
-	                                                 // 56 KB in all a k_sort workgroup fits on a CU next to a k_rc wave's 104 KB
-	__shared__ u32 s_off[SORT_WAVES][SORT_MAX_BINS];
+	__shared__ u32 s_delta[SORT_MAX_BINS];                // tile position p of an element with digit d -> dst index s_delta[d] + p
+	__shared__ u16 s_cnt[SORT_WAVES][SORT_MAX_BINS];      // per tile a wave ranks 64*SORT_ITEMS elements: 16 bits are plenty
+	__shared__ u16 s_off[SORT_WAVES][SORT_MAX_BINS];      // tile position of a wave's first element of a digit
+	__shared__ u64 s_tile[SORT_WG * SORT_ITEMS];          // the tile in digit order.  102 KB in all: one workgroup per CU, next to a k_rc workgroup's 53 KB
+	__shared__ u32 s_ws[SORT_WAVES];
 	__shared__ u8 s_rank[256];
 	const CtxJob j = jobs[blockIdx.x];
 	const u32 n = j.n, bins = 1u << j.dbits;
-	const u32 wv = wave_id(), nw = blockDim.x >> 6, lane = lane_id();
-	const u32 tile_elems = blockDim.x * SORT_ITEMS;
+	const u32 wv = wave_id(), lane = lane_id();
+	constexpr u32 nw = SORT_WAVES;                           // always launched with SORT_WG threads
+	constexpr u32 tile_elems = SORT_WG * SORT_ITEMS;
 	const u8* sym_src = (j.is_dna ? d_stream : q_stream) + j.src_off;
 	const u8* qp = qp_stream + j.src_off;
 
 	for (u32 i = threadIdx.x; i < 256; i += blockDim.x) s_rank[i] = (!j.is_dna && j.translate) ? st[j.blk].q_sym[i] : (u8)i;
 	for (u32 i = threadIdx.x; i < bins; i += blockDim.x) s_base[i] = 0;
 	__syncthreads();
+	if (!(PROBE & 1))
 	{	// histogram of digit 0
 		bool bad = false;
 		u32 i_from = 0;
@@ -289,14 +302,29 @@ __global__ void __launch_bounds__(SORT_WG) k_sort(const CtxJob* jobs, u64* pool,
 			{
 				const u32 i = wbase + k * 64 + lane;
 				el[k] = 0;
-				if (i < n) el[k] = pass ? src[i] : (j.is_dna ? ctx_elem_dna(j, sym_src, i, &bad) : ctx_elem_qua(j, sym_src, qp, s_rank, i));
+				if (PROBE & 32) el[k] = ((u64)(i * 2654435761u) << 32) | i;
+				else if (i < n) el[k] = pass ? src[i] : (j.is_dna ? ctx_elem_dna(j, sym_src, i, &bad) : ctx_elem_qua(j, sym_src, qp, s_rank, i));
 			}
 #pragma unroll
 			for (u32 k = 0; k < SORT_ITEMS; ++k)
 			{
+				if (PROBE & 2) { rk[k] = 0; continue; }
 				const u32 i = wbase + k * 64 + lane;
 				const bool valid = i < n;
 				const u32 d = (u32)(el[k] >> shift) & (bins - 1);
+				if (ATOMIC)
+				{	// one LDS atomic per element on the wave's packed counter pair: the LDS serialises the lanes of one instruction
+					// that meet in a word in ascending lane order (k_lds_order_test checks exactly that on the device before this
+					// variant is ever launched), and a wave's instructions in program order -- which is the stable order
+					const u32 sh = (d & 1u) * 16u;
+					u32 old = 0;
+					if (valid) old = atomicAdd(&((u32*)s_cnt[wv])[d >> 1], 1u << sh);
+					rk[k] = (old >> sh) & 0xFFFFu;
+#ifdef DSRC_EMU_BUILD
+					(void)__ballot(true);                                     // the emulator runs lanes one after the other: keep them in step per k
+#endif
+					continue;
+				}
 				u64 peers = __ballot(valid);
 #pragma unroll
 				for (u32 b = 0; b < SORT_DIGIT_BITS; ++b)                   // digit bits above dbits are zero for every lane: no effect
@@ -311,31 +339,55 @@ __global__ void __launch_bounds__(SORT_WG) k_sort(const CtxJob* jobs, u64* pool,
 				if (valid && r == 0 && sync) s_cnt[wv][d] = (u16)(before + (u32)__popcll(peers));
 			}
 			__syncthreads();
-			for (u32 dd = threadIdx.x; dd < bins; dd += blockDim.x)
+			// the tile's digit counts -> tile positions (exclusive scan over digits, then over the waves of a digit)
+			for (u32 d0 = 0, carry = 0; d0 < bins && !(PROBE & 4); d0 += SORT_WG)              // one round with 1024 threads
 			{
-				u32 run = s_base[dd];
-				for (u32 w = 0; w < nw; ++w)
+				const u32 dd = d0 + threadIdx.x;
+				u32 c[SORT_WAVES], tot = 0;
+#pragma unroll
+				for (u32 w = 0; w < SORT_WAVES; ++w) { c[w] = dd < bins ? s_cnt[w][dd] : 0u; tot += c[w]; }
+				const u32 inc = wave_incl_scan_dpp(tot);
+				if (lane == 63) s_ws[wv] = inc;
+				__syncthreads();
+				u32 run = carry + inc - tot;
+				const u32 nws = (bins - d0 + 63) / 64 < SORT_WAVES ? (bins - d0 + 63) / 64 : SORT_WAVES;   // waves that hold digits
+				for (u32 i = 0; i < nws; ++i) { const u32 x = s_ws[i]; run += i < wv ? x : 0u; carry += x; }
+				if (dd < bins)
 				{
-					const u32 c = s_cnt[w][dd];
-					s_cnt[w][dd] = 0;
-					s_off[w][dd] = run;
-					run += c;
+					const u32 g = s_base[dd];
+					s_delta[dd] = g - run; s_base[dd] = g + tot;
+#pragma unroll
+					for (u32 w = 0; w < SORT_WAVES; ++w) { s_off[w][dd] = (u16)run; run += c[w]; s_cnt[w][dd] = 0; }
 				}
-				s_base[dd] = run;
+				if (d0 + SORT_WG < bins) __syncthreads();
 			}
 			__syncthreads();
 #pragma unroll
 			for (u32 k = 0; k < SORT_ITEMS; ++k)
 			{
 				const u32 i = wbase + k * 64 + lane;
-				if (i < n)
-				{
-					dst[s_off[wv][(u32)(el[k] >> shift) & (bins - 1)] + rk[k]] = el[k];
-					if (more) atomicAdd(&s_next[(u32)(el[k] >> (shift + j.dbits)) & (bins - 1)], 1u);
-				}
+				if (PROBE) { if (i < n && !(PROBE & 8)) s_tile[(wv * SORT_ITEMS + k) * 64 + lane + (rk[k] & 1u)] = el[k]; }
+				else if (i < n) s_tile[(u32)s_off[wv][(u32)(el[k] >> shift) & (bins - 1)] + rk[k]] = el[k];
 			}
 			__syncthreads();
+			// out in tile order: the elements of a digit are neighbours here and in dst, so a wave's store covers a few
+			// contiguous runs instead of 64 separate 8-byte targets
+			const u32 tile_n = n - tile < tile_elems ? n - tile : tile_elems;
+#pragma unroll
+			for (u32 k = 0; k < SORT_ITEMS; ++k)
+			{
+				const u32 p = k * SORT_WG + threadIdx.x;
+				if (p < tile_n && !(PROBE & 8))
+				{
+					const u64 e = s_tile[p];
+					if (!PROBE) dst[s_delta[(u32)(e >> shift) & (bins - 1)] + p] = e;
+					else if (!(PROBE & 16)) dst[tile + p + (s_delta[(u32)(e >> shift) & (bins - 1)] & 0u)] = e;
+					if (more && !(PROBE & 64)) atomicAdd(&s_next[(u32)(e >> (shift + j.dbits)) & (bins - 1)], 1u);
+				}
+			}
+			// no barrier here: the next tile touches s_delta / s_tile only behind its own first two barriers
 		}
+		__syncthreads();                                    // the last tile's s_next updates
 		for (u32 i = threadIdx.x; i < bins; i += blockDim.x) s_base[i] = s_next[i];
 		__syncthreads();
 	}
@@ -354,6 +406,36 @@ __device__ __forceinline__ u64 recip48(u32 d)
 	const u32 lo = (u32)(p - (double)hi * 0x1p32);             // the subtraction is exact (p < 2^47 keeps >= 6 fraction bits); the cast truncates
 	const u64 q = ((u64)hi << 32) | lo;
 	return q + ((d & (d - 1u)) ? 1ull : 0ull);
+}
+
+// Is the order in which the LDS applies the lanes of ONE ds_add_rtn instruction to one word the lane order?  k_sort<.., true>
+// relies on it.  Every wave tries `rounds` digit patterns (1 .. 512 distinct digits, full and ragged execution masks) and compares
+// what the atomics return with the rank computed from ballots.  *bad != 0: the host keeps the ballot variant.
+__global__ void __launch_bounds__(256) k_lds_order_test(u32* bad, u32 rounds)
+{
+	__shared__ u32 s_c[4][SORT_MAX_BINS / 2];
+	const u32 wv = wave_id(), lane = lane_id();
+	u32 wrong = 0;
+	for (u32 round = 0; round < rounds; ++round)
+	{
+		for (u32 i = lane; i < SORT_MAX_BINS / 2; i += 64) s_c[wv][i] = 0;
+		wave_fence();
+		const u32 mask = (2u << (round % SORT_DIGIT_BITS)) - 1u;        // 2 .. SORT_MAX_BINS bins
+		u32 x = (blockIdx.x * 4 + wv) * 0x9E3779B9u + round * 0x85EBCA6Bu + lane * 0xC2B2AE35u;
+		x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+		const u32 d = (round & 64) ? (x & mask & ~1u) | (lane & 1u) : x & mask;     // also patterns where neighbours share a word
+		const bool valid = (round & 128) ? ((x >> 20) & 3u) != 0 : true;
+		u64 peers = __ballot(valid);
+#pragma unroll
+		for (u32 b = 0; b < SORT_DIGIT_BITS; ++b) { const u64 m = __ballot((d >> b) & 1u); peers &= ((d >> b) & 1u) ? m : ~m; }
+		const u32 expect = (u32)__popcll(peers & lanemask_lt());
+		const u32 sh = (d & 1u) * 16u;
+		u32 old = 0;
+		if (valid) old = atomicAdd(&s_c[wv][d >> 1], 1u << sh);
+		if (valid && ((old >> sh) & 0xFFFFu) != expect) wrong = 1;
+		wave_fence();
+	}
+	if (wrong) atomicOr(bad, 1u);
 }
 
 // device self-test (dsrcgpu_selftest): recip48 against the integer division for every divisor, and rc_div against
@@ -412,12 +494,25 @@ template <int N> __device__ __forceinline__ void replay_prefix(const ReplayRow<N
 	*total = ta + tb;
 }
 
-// Ranges: the sorted array of a stream is cut into gridDim.x * REPLAY_WG/64 ranges of `per` elements (a multiple of 64,
+// Ranges: the sorted array of a stream is cut into parts * REPLAY_WG/64 ranges of `per` elements (a multiple of 64,
 // at least 256); wave w replays exactly range w.  A segment that crosses a range boundary needs the row state at the
 // boundary: k_replay_seams computes it with a cheap walk (counts only: no ranks, no records) by the wave whose range holds
 // the segment's head, and leaves it in the sort buffer that is no longer needed (REPLAY_SEAM_WORDS u32 per boundary, which
 // always fits: per >= 256 elements of 8 bytes per boundary).  So a context that holds most of a stream's symbols is
 // replayed by all the stream's waves, not by one.
+// Which (part, stream) a k_replay / k_replay_seams workgroup works on: all parts of a stream are neighbours in the grid, so
+// that few streams are in flight at a time and their scattered record lines stay in the memory-side cache (512 parts: 71 ms,
+// 32 parts: 164 ms per 512 DNA streams).  Measured and rejected: one stream per XCD (workgroup id -> stream 8 * (id / 8 / parts)
+// + id % 8, eight streams in flight): 7.8 / 10.0 instead of 6.7 / 6.7 ms per 128 quality / DNA streams.  Where the time goes
+// (one instance, 128 streams): records not stored 2.6 ms, stored in sorted order 2.7 ms, scattered into a 192 KB window
+// 3.2 ms, scattered by t 6.7 ms -- the scatter to stream order is two thirds of k_replay.
+__device__ __forceinline__ bool replay_slot(u32 parts, u32 cnt, u32* part, u32* stream)
+{
+	*stream = blockIdx.x / parts;
+	*part = blockIdx.x % parts;
+	return *stream < cnt;
+}
+
 #define REPLAY_SEAM_WORDS 260u
 __device__ __forceinline__ u32 replay_per(u32 n, u32 n_ranges)
 {
@@ -426,17 +521,19 @@ __device__ __forceinline__ u32 replay_per(u32 n, u32 n_ranges)
 }
 
 template <int N>
-__global__ void __launch_bounds__(REPLAY_WG) k_replay_seams(const CtxJob* jobs, u64* pool)
+__global__ void __launch_bounds__(REPLAY_WG) k_replay_seams(const CtxJob* jobs, u64* pool, u32 parts, u32 n_streams)
 {
+	u32 part, stream;
+	if (!replay_slot(parts, n_streams, &part, &stream)) return;
 	constexpr int BITS = N <= 4 ? 2 : N <= 8 ? 3 : N <= 16 ? 4 : N <= 32 ? 5 : N <= 64 ? 6 : 7;
-	const CtxJob j = jobs[blockIdx.y];
+	const CtxJob j = jobs[stream];
 	const u64* src = pool + (j.sorted_in_b ? j.elems_b : j.elems);
 	u32* seams = (u32*)(pool + (j.sorted_in_b ? j.elems : j.elems_b));
 	const u32 n = j.n;
 	const u32 lane = lane_id();
 	const u32 limit = (1u << 16) - 2u * N;
-	const u32 per = replay_per(n, gridDim.x * (REPLAY_WG / 64));
-	const u64 r_lo64 = (u64)(blockIdx.x * (REPLAY_WG / 64) + wave_id()) * per;
+	const u32 per = replay_per(n, parts * (REPLAY_WG / 64));
+	const u64 r_lo64 = (u64)(part * (REPLAY_WG / 64) + wave_id()) * per;
 	if (r_lo64 + per >= n) return;                          // no boundary after this range
 	const u32 r_lo = (u32)r_lo64, hi = r_lo + per;
 	if ((src[hi] >> ELEM_CTX_SHIFT) != (src[hi - 1] >> ELEM_CTX_SHIFT)) return;      // nothing crosses my upper boundary
@@ -504,19 +601,22 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay_seams(const CtxJob* jobs, 
 	}
 }
 
-template <int N>
-__global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const u64* pool, RcRec* rec_pool)
+// PROBE != 0: timing experiments only (-DDSRC_SORT_PROBE): 1 no record store, 2 records stored in sorted order (no scatter), 4 no reciprocal
+template <int N, int PROBE = 0>
+__global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const u64* pool, RcRec* rec_pool, u32 parts, u32 n_streams)
 {
+	u32 part, stream;
+	if (!replay_slot(parts, n_streams, &part, &stream)) return;
 	constexpr int BITS = N <= 4 ? 2 : N <= 8 ? 3 : N <= 16 ? 4 : N <= 32 ? 5 : N <= 64 ? 6 : 7;
 	__shared__ u32 s_tail[REPLAY_WG / 64][128];
-	const CtxJob j = jobs[blockIdx.y];
+	const CtxJob j = jobs[stream];
 	const u64* src = pool + (j.sorted_in_b ? j.elems_b : j.elems);
 	RcRec* recs = rec_pool + j.trip;
 	const u32 n = j.n;
 	const u32 lane = lane_id();
 	const u32 limit = (1u << 16) - 2u * N;                   // MaxAccumulatedValue (src/SymbolCoderRC.h:67)
-	const u32 per = replay_per(n, gridDim.x * (REPLAY_WG / 64));
-	const u64 r_lo = (u64)(blockIdx.x * (REPLAY_WG / 64) + wave_id()) * per;
+	const u32 per = replay_per(n, parts * (REPLAY_WG / 64));
+	const u64 r_lo = (u64)(part * (REPLAY_WG / 64) + wave_id()) * per;
 	if (r_lo >= n) return;
 	const u32 hi = (u32)(r_lo + per < n ? r_lo + per : n);
 	u32 pos = (u32)r_lo;
@@ -611,9 +711,17 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 		if (active)
 		{	// what k_rc needs per symbol: the 48-bit reciprocal of `total` (rc_div), freq, cum -- one 12-byte record
 			RcRec rr;
-			const u64 m = recip48(tot);
+			const u64 m = (PROBE & 4) ? (u64)tot : recip48(tot);
 			rr.m_lo = (u32)m; rr.mf = ((u32)(m >> 32) << 16) | f; rr.cum = cum;
-			recs[(u32)el] = rr;
+			if (PROBE & 8) recs[(u32)el & 0xFFFFFu] = rr;            // scatter inside 12 MB
+			else if (PROBE & 16) recs[(u32)el & 0x3FFFu] = rr;      // scatter inside 192 KB
+			else if (PROBE & 32) { typedef u32 __attribute__((vector_size(16))) V4; const V4 r4 = {rr.m_lo, rr.mf, rr.cum, 0u}; ((V4*)recs)[((u32)el * 3u) >> 2] = r4; }   // 16-byte aligned stores, same footprint
+			else if (!(PROBE & 3))
+			{
+				recs[(u32)el] = rr;          // (a non-temporal store here: 169 instead of 55 ms per 512 blocks -- the lines do merge in the caches)
+			}
+			else if (PROBE & 2) recs[idx] = rr;
+			else if (rr.m_lo == 0xFFFFFFFFu && rr.cum == 0xFFFFFFFFu) recs[idx] = rr;      // keeps the computation alive, never true
 		}
 
 		// carry the segment that is open at the end of the window
