@@ -495,7 +495,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	const u32 NJ = (u32)jobs.size();
 	std::vector<RcChain> chains(NJ);
 	{
-		// records of one chain are contiguous: k_replay scatters inside one chain's 12 B x n array (a few chains in
+		// records of one chain are contiguous: k_replay scatters inside one chain's 8 B x n array (a few chains in
 		// flight stay within the memory-side cache) and k_rc streams it through LDS.  The 64 chains of a k_rc wave
 		// are one pitch apart (a multiple of 4 records: rows stay 16-byte aligned); k_rc's DMA may read RC_OVERREAD
 		// records past the longest chain of its wave.
@@ -507,14 +507,14 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			const u32 hi = std::min(NJ, g + RC_LANES);
 			u32 mx = 0; for (u32 i = g; i < hi; ++i) mx = std::max(mx, jobs[i].n);
 			const u32 pitch = (mx + 3) / 4 * 4 + 4;
-			if ((u64)pitch * sizeof(RcRec) >= (1ull << 32))      // k_rc: 32-bit byte offsets inside one stream's array
+			if ((u64)pitch * sizeof(RcPack) >= (1ull << 32))      // k_rc: 32-bit byte offsets inside one stream's array
 				return fail(h, DSRCGPU_E_ARG, "chunk too large for the range-coder stage (a stream of %u symbols exceeds 4 GiB of records); use a smaller buffer size", mx);
 			for (u32 i = g; i < hi; ++i) { cbase[i] = trip_words + (size_t)(i - g) * pitch; cpitch[i] = pitch; }
 			trip_words += (size_t)pitch * (hi - g);
 			if (hi == NJ) trip_words += pitch + RC_OVERREAD;               // over-read slack behind the last array
 		}
-		const size_t o_trip = A.alloc(trip_words * sizeof(RcRec) + 256);
-		const size_t trip0 = (o_trip + 47) / 48 * 4;
+		const size_t o_trip = A.alloc(trip_words * sizeof(RcPack) + 256);
+		const size_t trip0 = (o_trip + 15) / 16 * 2;                 // in records, 16-byte aligned
 		for (u32 i = 0; i < NJ; ++i)
 		{
 			CtxJob& j = jobs[i];
@@ -688,7 +688,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 				while (hi < s_hi && jobs[hi].n_alpha == jobs[lo].n_alpha) ++hi;
 				const u32 cnt = hi - lo;
 				u32 mxn = 1; for (u32 i = lo; i < hi; ++i) mxn = std::max(mxn, jobs[i].n);
-				// REPLAY_WG/64 waves per part.  Many waves per chain = few chains in flight: the scattered 12-byte records of a
+				// REPLAY_WG/64 waves per part.  Many waves per chain = few chains in flight: the scattered 8-byte records of a
 				// chain have to meet in the memory-side cache before their line is evicted, and with several scheduler instances
 				// streaming through that cache the time a chain is open counts (one instance, 512 DNA chains: 32 parts 164 ms,
 				// 512 parts 71 ms; five instances: 256 parts 21.4, 512 23.3, 1024 24.3, 2048 24.7, 3200 23.2 GB/s)
@@ -702,7 +702,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 					{
 						++shots;
 						hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-#define RPROBE_RUN(NN, M) { hipEventRecord(e0, s); hipLaunchKernelGGL((k_replay<NN, M>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0), parts, cnt); \
+#define RPROBE_RUN(NN, M) { hipEventRecord(e0, s); hipLaunchKernelGGL((k_replay<NN, M>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt); \
 						hipEventRecord(e1, s); hipEventSynchronize(e1); float ms = 0; hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[probe] k_replay<%d,%d> %u streams x %u parts: %.2f ms\n", NN, M, cnt, parts, ms); }
 						hipLaunchKernelGGL(k_replay_seams<32>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt);
 						if (jobs[lo].n_alpha == 32) { RPROBE_RUN(32, 0) RPROBE_RUN(32, 0) RPROBE_RUN(32, 1) RPROBE_RUN(32, 2) RPROBE_RUN(32, 8) RPROBE_RUN(32, 16) RPROBE_RUN(32, 32) }
@@ -713,12 +713,12 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 #endif
 				switch (jobs[lo].n_alpha)
 				{
-				case 4:   hipLaunchKernelGGL(k_replay_seams<4>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<4, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0), parts, cnt); break;
-				case 8:   hipLaunchKernelGGL(k_replay_seams<8>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<8, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0), parts, cnt); break;
-				case 16:  hipLaunchKernelGGL(k_replay_seams<16>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<16, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0), parts, cnt); break;
-				case 32:  hipLaunchKernelGGL(k_replay_seams<32>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<32, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0), parts, cnt); break;
-				case 64:  hipLaunchKernelGGL(k_replay_seams<64>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<64, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0), parts, cnt); break;
-				default:  hipLaunchKernelGGL(k_replay_seams<128>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<128, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcRec>(h, 0), parts, cnt); break;
+				case 4:   hipLaunchKernelGGL(k_replay_seams<4>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<4, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt); break;
+				case 8:   hipLaunchKernelGGL(k_replay_seams<8>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<8, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt); break;
+				case 16:  hipLaunchKernelGGL(k_replay_seams<16>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<16, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt); break;
+				case 32:  hipLaunchKernelGGL(k_replay_seams<32>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<32, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt); break;
+				case 64:  hipLaunchKernelGGL(k_replay_seams<64>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<64, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt); break;
+				default:  hipLaunchKernelGGL(k_replay_seams<128>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<128, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt); break;
 				}
 				KCHK();
 				lo = hi;
@@ -730,8 +730,8 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		HIPCHK(hipEventRecord(h->ev[4], s));
 		HIPCHK(hipStreamWaitEvent(h->rc_stream, h->ev[4], 0));
 		HIPCHK(hipEventRecord(h->ev[2], h->rc_stream));
-		hipLaunchKernelGGL(k_rc, dim3((NJ + RC_LANES - 1) / RC_LANES), dim3(128), 0, h->rc_stream, d_chains, NJ, AP<RcRec>(h, 0), AP<RcFin>(h, o_fin), d_state); KCHK();
-		hipLaunchKernelGGL(k_rc_emit, dim3(NJ), dim3(RC_EMIT_WG), 0, h->rc_stream, d_chains, AP<RcRec>(h, 0), AP<RcFin>(h, o_fin), wpool, d_state); KCHK();
+		hipLaunchKernelGGL(k_rc, dim3((NJ + RC_LANES - 1) / RC_LANES), dim3(64 * (1 + RC_LOADERS)), 0, h->rc_stream, d_chains, NJ, AP<RcPack>(h, 0), AP<RcFin>(h, o_fin), d_state); KCHK();
+		hipLaunchKernelGGL(k_rc_emit, dim3(NJ), dim3(RC_EMIT_WG), 0, h->rc_stream, d_chains, AP<RcPack>(h, 0), AP<RcFin>(h, o_fin), wpool, d_state); KCHK();
 		HIPCHK(hipEventRecord(h->ev[3], h->rc_stream));
 		HIPCHK(hipStreamWaitEvent(s, h->ev[3], 0));
 		h->rc_launches = 1;

@@ -22,14 +22,16 @@
 #define ELEM_CTX_SHIFT 40
 
 // what the range coder consumes per symbol (written by k_replay in stream order, one contiguous array per chain)
-struct RcRec { u32 m_lo, mf, cum; };     // 12 bytes; m = ceil(2^48/total): m_lo = m & 0xFFFFFFFF, mf = (m >> 32) << 16 | freq
+struct RcRec { u32 m_lo, mf, cum; };     // what the coder works on (LDS rows): m = ceil(2^48/total): m_lo = m & 0xFFFFFFFF, mf = (m >> 32) << 16 | freq
+typedef u64 RcPack;                      // what k_replay scatters to stream order, 8 aligned bytes: freq | cum << 16 | total << 32 (total <= 2^16).
+                                         // k_rc's loader waves turn it into an RcRec on the way into LDS (the reciprocal is off the coder's chain)
 
 struct CtxJob     // one (block, stream)
 {
 	u64 src_off;        // byte offset of the symbol stream (q_stream / d_stream)
 	u64 elems;          // u64 index of sort buffer A
 	u64 elems_b;        // u64 index of sort buffer B
-	u64 trip;           // RcRec index of this chain's first record
+	u64 trip;           // RcPack index of this chain's first record
 	u32 n;              // symbols
 	u32 blk;
 	u32 alpha_bits;     // log2(alphabet)
@@ -464,8 +466,8 @@ __global__ void __launch_bounds__(256) k_selftest(u32* bad)
 //     cum   = cumbase[s] + 2 * #{earlier lanes of my segment with a smaller symbol}
 //     total = T0 + 2 * (symbols coded so far in the epoch)
 // which are popcounts of per-symbol ballots masked to the lane's segment.  (The records are scattered into
-// the chain's own 12 B x n array: with few chains in flight that array stays in the memory-side cache, so the
-// 12-byte pieces merge into full lines before they reach HBM -- the launch uses many waves per chain.)  Only the segment that
+// the chain's own 8 B x n array: with few chains in flight that array stays in the memory-side cache, so the
+// 8-byte pieces merge into full lines before they reach HBM -- the launch uses many waves per chain.)  Only the segment that
 // is still open at the end of a window carries state (lane v keeps base[v] / cnt[v]); a window is
 // cut short where that segment hits its rescale point.  A wave replays exactly its slice of the array (see
 // k_replay_seams for segments that cross slices), so any number of waves can work on one stream.
@@ -603,7 +605,7 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay_seams(const CtxJob* jobs, 
 
 // PROBE != 0: timing experiments only (-DDSRC_SORT_PROBE): 1 no record store, 2 records stored in sorted order (no scatter), 4 no reciprocal
 template <int N, int PROBE = 0>
-__global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const u64* pool, RcRec* rec_pool, u32 parts, u32 n_streams)
+__global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const u64* pool, RcPack* rec_pool, u32 parts, u32 n_streams)
 {
 	u32 part, stream;
 	if (!replay_slot(parts, n_streams, &part, &stream)) return;
@@ -611,7 +613,7 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 	__shared__ u32 s_tail[REPLAY_WG / 64][128];
 	const CtxJob j = jobs[stream];
 	const u64* src = pool + (j.sorted_in_b ? j.elems_b : j.elems);
-	RcRec* recs = rec_pool + j.trip;
+	RcPack* recs = rec_pool + j.trip;
 	const u32 n = j.n;
 	const u32 lane = lane_id();
 	const u32 limit = (1u << 16) - 2u * N;                   // MaxAccumulatedValue (src/SymbolCoderRC.h:67)
@@ -709,19 +711,14 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 			else { f = 1 + 2 * same; cum = sym + 2 * less; tot = N + 2 * in_seg; }
 		}
 		if (active)
-		{	// what k_rc needs per symbol: the 48-bit reciprocal of `total` (rc_div), freq, cum -- one 12-byte record
-			RcRec rr;
-			const u64 m = (PROBE & 4) ? (u64)tot : recip48(tot);
-			rr.m_lo = (u32)m; rr.mf = ((u32)(m >> 32) << 16) | f; rr.cum = cum;
-			if (PROBE & 8) recs[(u32)el & 0xFFFFFu] = rr;            // scatter inside 12 MB
-			else if (PROBE & 16) recs[(u32)el & 0x3FFFu] = rr;      // scatter inside 192 KB
-			else if (PROBE & 32) { typedef u32 __attribute__((vector_size(16))) V4; const V4 r4 = {rr.m_lo, rr.mf, rr.cum, 0u}; ((V4*)recs)[((u32)el * 3u) >> 2] = r4; }   // 16-byte aligned stores, same footprint
-			else if (!(PROBE & 3))
-			{
-				recs[(u32)el] = rr;          // (a non-temporal store here: 169 instead of 55 ms per 512 blocks -- the lines do merge in the caches)
-			}
+		{	// what k_rc needs per symbol: freq, cum, total -- one aligned 8-byte record (one 32-byte sector per store; the 12-byte
+			// record with the reciprocal took 1.25, and a stream's array was half as large again)
+			const RcPack rr = (u64)f | ((u64)cum << 16) | ((u64)tot << 32);
+			if (PROBE & 8) recs[(u32)el & 0xFFFFFu] = rr;            // scatter inside 8 MB
+			else if (PROBE & 16) recs[(u32)el & 0x3FFFu] = rr;      // scatter inside 128 KB
+			else if (!(PROBE & 3)) recs[(u32)el] = rr;          // (a non-temporal store here: 169 instead of 55 ms per 512 blocks -- the lines do merge in the caches)
 			else if (PROBE & 2) recs[idx] = rr;
-			else if (rr.m_lo == 0xFFFFFFFFu && rr.cum == 0xFFFFFFFFu) recs[idx] = rr;      // keeps the computation alive, never true
+			else if (rr == ~0ull) recs[idx] = rr;                  // keeps the computation alive, never true
 		}
 
 		// carry the segment that is open at the end of the window
@@ -773,7 +770,7 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 //     group is replayed from a snapshot with the reference's loop, verbatim.
 struct RcChain
 {
-	u64 trip;          // RcRec index of the chain's first record (a multiple of 4: rows are 16-byte aligned)
+	u64 trip;          // RcPack index of the chain's first record (a multiple of 2: 16-byte aligned)
 	u64 out_words;     // u32 index of the staging stream
 	u32 n;
 	u32 out_byte0, out_cap;
@@ -793,7 +790,10 @@ struct RcFin { u32 n; u8 b[60]; };
 #endif                                 // CU with two k_sort workgroups, and it issues half as many DMA requests per symbol
 #define RC_CHUNK 64                    // symbols per chain per LDS chunk (768 B = 48 lanes x 16 B)
 #define RC_ROW_U4 49                   // LDS row pitch in 16-byte units: 48 of data + 1 so that a 16-lane ds_read_b128 pass covers all 64 banks
-#define RC_OVERREAD (3 * RC_CHUNK)     // records the DMA may touch past the longest chain of a wave (arena slack)
+#define RC_OVERREAD (5 * RC_CHUNK)     // records the loaders may touch past the longest chain of a wave (arena slack)
+#ifndef RC_LOADERS
+#define RC_LOADERS 2                   // loader waves per workgroup (each feeds RC_LANES / RC_LOADERS rows)
+#endif
 #define RC_XB 64                       // per-lane byte buffer of the exact path (LDS)
 
 typedef u32 __attribute__((vector_size(16))) U4;   // one 16-byte LDS / global access
@@ -891,20 +891,41 @@ __device__ __forceinline__ void rc_load_group(RcRegs& g, const LDS_AS U4* row, u
 	for (u32 i = 0; i < 3 * RC_GROUP / 4; ++i) g.q[i] = row[grp * (3 * RC_GROUP / 4) + i];
 }
 
-// LDS-DMA requests for chains [J0, J1) of the wave: lanes 0..47 fetch the 48 x 16 bytes (= 64 records) of chain j
-// that start at byte `chunk_off` (wave-uniform) of its array into row j.  The arrays of a wave's chains are `pitch`
-// bytes apart: a request is a scalar pointer (advanced by scalar adds) + the lane's fixed offset 16 * lane.
-template <int J0, int J1>
-__device__ __forceinline__ void rc_dma(LDS_AS U4* buf, const u8* base, u32 pitch, u32 chunk_off, u32 n_live)
+__device__ __forceinline__ RcRec rc_unpack(RcPack v)
 {
-	if (lane_id() < 3 * RC_CHUNK / 4)
-	{
-		const u8* sp = base + chunk_off + (u64)J0 * pitch;
+	const u64 m = recip48((u32)(v >> 32));
+	RcRec e; e.m_lo = (u32)m; e.mf = ((u32)(m >> 32) << 16) | ((u32)v & 0xFFFFu); e.cum = ((u32)v >> 16) & 0xFFFFu;
+	return e;
+}
+
+// Loader wave `lw` of RC_LOADERS feeds rows lw, lw + RC_LOADERS, ...: lane l fetches record l of the row's 64-record chunk
+// (512 contiguous bytes per row and instruction) that starts at byte `chunk_off` of the chain's array; the arrays of a
+// workgroup's chains are `pitch` bytes apart.  The fetch of chunk k+2 is in flight while chunk k+1 is converted.
+#define RC_ROWS_PER_LOADER (RC_LANES / RC_LOADERS)
+__device__ __forceinline__ void rc_fetch(RcPack* r, const u8* base, u32 pitch, u32 chunk_off, u32 lw, u32 n_live)
+{
+	const u8* sp = base + chunk_off + (u64)lw * pitch + lane_id() * 8u;
 #pragma unroll
-		for (int j = J0; j < J1; ++j)
+	for (u32 k = 0; k < RC_ROWS_PER_LOADER; ++k)
+	{
+		r[k] = lw + k * RC_LOADERS < n_live ? *(const RcPack*)sp : 0ull;       // n_live: constant RC_LANES in full workgroups
+		sp += (u64)RC_LOADERS * pitch;
+	}
+}
+
+// ... and turns them into the coder's 12-byte records (reciprocal of the total) in the rows of `buf`;
+// a 3-dword stride over the lanes touches every LDS bank once
+__device__ __forceinline__ void rc_convert(LDS_AS U4* buf, const RcPack* r, u32 lw, u32 n_live)
+{
+#pragma unroll
+	for (u32 k = 0; k < RC_ROWS_PER_LOADER; ++k)
+	{
+		const u32 j = lw + k * RC_LOADERS;
+		if (j < n_live)
 		{
-			if ((u32)j < n_live) lds_dma16(sp, lane_id() * 16u, buf + j * RC_ROW_U4);      // n_live: constant RC_LANES in full waves
-			sp += pitch;
+			const RcRec e = rc_unpack(r[k]);
+			LDS_AS u32* d = (LDS_AS u32*)(buf + j * RC_ROW_U4) + 3u * lane_id();
+			d[0] = e.m_lo; d[1] = e.mf; d[2] = e.cum;
 		}
 	}
 }
@@ -923,20 +944,20 @@ __device__ __forceinline__ void rc_chunk(RcState& s, u32* codes, RcRegs& r0, RcR
 	if (t0 + 4 * RC_GROUP <= n) rc_group(s, c + 3 * RC_GROUP, r1, row, 3, xb, err, fx);
 }
 
-// A workgroup is two waves.  Wave 0 codes (one lane = one chain, RC_LANES chains); wave 1 only issues the LDS-DMA
-// requests, one chunk ahead, so that the coder's instruction stream is the arithmetic and nothing else (the requests
-// were 1/5 of its issue slots).  They meet at one barrier per 64-symbol chunk: the loader arrives when the chunk
-// after the current one has landed, the coder when it has finished the current one -- after the barrier the loader
-// may overwrite the buffer the coder has just left.
+// A workgroup is 1 + RC_LOADERS waves.  Wave 0 codes (one lane = one chain, RC_LANES chains); the others fetch the 8-byte
+// records k_replay left, two chunks ahead, and write the coder's records into the LDS rows one chunk ahead, so that the
+// coder's instruction stream is the arithmetic and nothing else.  They meet at one barrier per 64-symbol chunk: a loader
+// arrives when its rows of the chunk after the current one are written, the coder when it has finished the current one --
+// after the barrier the loaders may overwrite the buffer the coder has just left.
 // FULL: every lane below RC_LANES has a chain; the last workgroup of a launch may be partial and then must not request
 // rows it does not have (one launch, two instantiations of the body: a wave only ever fetches the code of its own).
 template <bool FULL>
-__device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains, RcRec* rec_pool, RcFin* fin, BlkState* st, LDS_AS U4* buf_a, LDS_AS U4* buf_b, u8* s_xb)
+__device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains, RcPack* rec_pool, RcFin* fin, BlkState* st, LDS_AS U4* buf_a, LDS_AS U4* buf_b, u8* s_xb)
 {
 	__builtin_amdgcn_s_setprio(3);                                             // the serial waves win issue arbitration against co-resident data-parallel waves
 	const u32 first_chain = blockIdx.x * RC_LANES;
 	const u32 lane = lane_id(), id = first_chain + lane;
-	const bool loader = wave_id() == 1;
+	const bool loader = wave_id() >= 1;
 	const bool have = lane < RC_LANES && (FULL || id < n_chains);
 	const RcChain c = chains[have ? id : n_chains - 1];                        // idle lanes shadow a real chain's values and code nothing
 	const u32 n_live = FULL ? (u32)RC_LANES : n_chains - first_chain;
@@ -947,26 +968,29 @@ __device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains
 	if (loader)
 	{
 		if (!wave_full) return;
-		// the arrays of a wave's chains are c.pitch records apart (wave-uniform; idle lanes shadow the last chain's values)
+		// the arrays of a workgroup's chains are c.pitch records apart (wave-uniform; idle lanes shadow the last chain's values)
 		const u8* base = uniform_ptr(rec_pool + __shfl(c.trip, 0));
-		const u32 pitch = (u32)__builtin_amdgcn_readfirstlane((int)(c.pitch * (u32)sizeof(RcRec)));
-		rc_dma<0, RC_LANES>(buf_a, base, pitch, 0, n_live);
-		lds_dma_wait();
+		const u32 pitch = (u32)__builtin_amdgcn_readfirstlane((int)(c.pitch * (u32)sizeof(RcPack)));
+		const u32 lw = wave_id() - 1u, CB = RC_CHUNK * (u32)sizeof(RcPack);
+		RcPack ra[RC_ROWS_PER_LOADER], rb[RC_ROWS_PER_LOADER];
+		rc_fetch(ra, base, pitch, 0, lw, n_live);
+		rc_fetch(rb, base, pitch, CB, lw, n_live);
+		rc_convert(buf_a, ra, lw, n_live);
 		__syncthreads();                                                       // chunk 0 is there
 		for (u32 t0 = 0; t0 < wave_full; t0 += 2 * RC_CHUNK)
 		{
-			rc_dma<0, RC_LANES>(buf_b, base, pitch, (t0 + RC_CHUNK) * (u32)sizeof(RcRec), n_live);
-			lds_dma_wait();
+			rc_fetch(ra, base, pitch, (t0 + 2 * RC_CHUNK) * (u32)sizeof(RcPack), lw, n_live);
+			rc_convert(buf_b, rb, lw, n_live);
 			__syncthreads();                                                   // coder is through buf_a, chunk t0+64 is in buf_b
-			rc_dma<0, RC_LANES>(buf_a, base, pitch, (t0 + 2 * RC_CHUNK) * (u32)sizeof(RcRec), n_live);
-			lds_dma_wait();
+			rc_fetch(rb, base, pitch, (t0 + 3 * RC_CHUNK) * (u32)sizeof(RcPack), lw, n_live);
+			rc_convert(buf_a, ra, lw, n_live);
 			__syncthreads();                                                   // coder is through buf_b, chunk t0+128 is in buf_a
 		}
 		return;
 	}
 
-	RcRec* p = rec_pool + c.trip;
-	u32* codes = (u32*)p;                                                      // code t overwrites bytes 4t..4t+3 of the chain's own array
+	RcPack* p = rec_pool + c.trip;
+	u32* codes = (u32*)p;                                                      // code t overwrites bytes 4t..4t+3 of the chain's own array (behind every record still to be read)
 	u8* xb = s_xb + lane * RC_XB;
 	u32* err = &st[c.blk].err;
 	RcState s;
@@ -992,7 +1016,7 @@ __device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains
 	if (!have) return;
 	// the last n mod 16 symbols and RangeEncoder::End
 	u32 nb = 0;
-	for (u32 t = n_full; t < n; ++t) { const RcRec e = p[t]; rc_step_exact(s, e, xb, nb); }
+	for (u32 t = n_full; t < n; ++t) { const RcRec e = rc_unpack(p[t]); rc_step_exact(s, e, xb, nb); }
 	if (nb + 8 > sizeof(fin->b)) { atomicOr(err, (u32)DSRC_ERR_OUT_OVERFLOW); nb = 0; }
 	RcFin* F = &fin[id];
 	for (u32 k = 0; k < nb; ++k) F->b[k] = xb[k];
@@ -1000,7 +1024,7 @@ __device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains
 	F->n = nb + 8;
 }
 
-__global__ void __launch_bounds__(128) k_rc(const RcChain* chains, u32 n_chains, RcRec* rec_pool, RcFin* fin, BlkState* st)
+__global__ void __launch_bounds__(64 * (1 + RC_LOADERS)) k_rc(const RcChain* chains, u32 n_chains, RcPack* rec_pool, RcFin* fin, BlkState* st)
 {
 	__shared__ U4 s_a[RC_LANES * RC_ROW_U4];
 	__shared__ U4 s_b[RC_LANES * RC_ROW_U4];
@@ -1014,7 +1038,7 @@ __global__ void __launch_bounds__(128) k_rc(const RcChain* chains, u32 n_chains,
 // each code its position, the bytes are stored; then the tail left in RcFin.  Sets the stream size.
 #define RC_EMIT_WG 256
 #define RC_EMIT_ITEMS 8
-__global__ void __launch_bounds__(RC_EMIT_WG) k_rc_emit(const RcChain* chains, const RcRec* rec_pool, const RcFin* fin, u32* word_pool, BlkState* st)
+__global__ void __launch_bounds__(RC_EMIT_WG) k_rc_emit(const RcChain* chains, const RcPack* rec_pool, const RcFin* fin, u32* word_pool, BlkState* st)
 {
 	__shared__ u32 s_w[RC_EMIT_WG / 64];
 	const RcChain c = chains[blockIdx.x];
