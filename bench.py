@@ -32,8 +32,8 @@ sys.path.insert(0, ROOT)
 BUF = 8 << 20                     # -b8 (reference default, src/Common.h:156)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 RECS_PER_BLOCK = 22300
-PMC_RC_BYTES_PER_BLOCK = (20.0005e6 * 2 + 13.3255e6) * 1024 / 512   # measured, see roofline.traffic below
-PMC_SORT_BYTES_PER_BLOCK = 113e9 / 512                            # k_sort: 100-126 GB per 512-block batch (same profile)
+PMC_RC_BYTES_PER_BLOCK = (13.3515e6 * 2 + 13.3427e6) * 1024 / 512   # measured, see roofline.traffic below
+PMC_SORT_BYTES_PER_BLOCK = (16.6858e6 * 2 + 65.8718e6) * 1024 / 512  # k_sort, eight launches of a 512-block batch (same profile)
 MAX_RESIDENT = 3                  # distinct input shards kept in HBM per scheduler instance (2 when N > 1: rank 0 also holds the gathered streams)
 
 
@@ -403,11 +403,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          # L2<->fabric bytes of one k_rc launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), 512-block launch:
-                         # FETCH 20.0005e6 KiB x 2 (gfx950 counts 16 B/lane streaming reads at half) + WRITE 13.3255e6 KiB = 106.7 MB per block,
-                         # i.e. exactly the 12-byte records read once + the 4-byte codes written once (profiles/r01_pmc_b512_p1_d3q2.txt)
+                         # FETCH 13.3515e6 KiB x 2 (gfx950 counts 16 B/lane streaming reads at half) + WRITE 13.3427e6 KiB = 80.1 MB per block,
+                         # i.e. exactly the 8-byte records read once + the 4-byte codes written once (profiles/r02_pmc_b512_p1_d3q2.txt)
                          "traffic": int(PMC_RC_BYTES_PER_BLOCK * sub_blocks), "kernel": "k_rc (range-coder arithmetic, one lane per stream; followed by k_rc_emit)",
                          "kernel_ms": round(rc_ms, 2), "launch_bytes": int(alg), "batch_ms": round(batch_ms, 2),
-                         "note": "algorithmic bytes = chunk bytes in + block bytes out of one sub-batch launch (SURVEY 8d); kernel_ms = k_rc + k_rc_emit from HIP events on the range-coder stream, measured while other scheduler instances share the GPU (alone: 141 ms)"},
+                         "note": "algorithmic bytes = chunk bytes in + block bytes out of one sub-batch launch (SURVEY 8d); kernel_ms = k_rc + k_rc_emit from HIP events on the range-coder stream, measured while other scheduler instances share the GPU (alone: 132 ms)"},
         }
         sort_ms = sum(x[3] for x in tm) / max(1, len(tm)); replay_ms = sum(x[4] for x in tm) / max(1, len(tm))
         if sort_ms > 0:
@@ -418,7 +418,7 @@ def main():
                 "achieved": round(alg / (sort_ms / 1e3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(alg / (sort_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5), "kernel_ms": round(sort_ms, 2), "replay_ms": round(replay_ms, 2),
                 "launch_bytes": int(alg), "traffic": int(PMC_SORT_BYTES_PER_BLOCK * sub_blocks),
-                "note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE of the k_sort launches of a 512-block batch / 512 (profiles/r01_pmc_b512_p1_d3q2.txt); "
+                "note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE of the k_sort launches of a 512-block batch / 512 (profiles/r02_pmc_b512_p1_d3q2.txt); "
                         "replay_ms = k_replay_seams + k_replay of the same sub-batch"}
         decode_line = None
         if args.decode_blocks > 0 and world == 1:
