@@ -153,7 +153,7 @@ size_t estimate_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
 	size_t tot = 0, mx = 0;
 	for (u32 i = 0; i < n; ++i) { tot += (size_t)sizes[i] + 4096; mx = std::max(mx, (size_t)sizes[i]); }
 	const size_t sort_slice = std::min(tot * 14, ((size_t)7168 << 20) + mx * 16);       // see slice_lo in run_batch
-	return tot * 10 + (rc ? sort_slice : 0) + (size_t)n * (1u << 20) + (16u << 20);      // measured: 9.5 x input + slice at -d3 -q2 (8-byte records)
+	return tot * 21 / 2 + (rc ? sort_slice : 0) + (size_t)n * (1u << 20) + (16u << 20);  // measured: 10.04 x input + slice at -d3 -q2 (8-byte records)
 }
 size_t estimate_decode_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes);
 
