@@ -682,6 +682,11 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			else hipLaunchKernelGGL((k_sort<0, false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state);
 			KCHK();
 			stage_mark(0); stage_mark(1);
+#ifdef DSRC_REPLAY_TURNS
+			static std::mutex replay_mu;                 // experiment: one instance's k_replay on the GPU at a time
+			static const bool turns = getenv("DSRC_GPU_REPLAY_TURNS") != nullptr;
+			if (turns) { (void)hipEventSynchronize(h->stage_ev[h->stage_used - 1]); replay_mu.lock(); }
+#endif
 			for (u32 lo = s_lo; lo < s_hi;)
 			{
 				u32 hi = lo;
@@ -724,6 +729,9 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 				lo = hi;
 			}
 			stage_mark(1);
+#ifdef DSRC_REPLAY_TURNS
+			if (turns) { (void)hipEventSynchronize(h->stage_ev[h->stage_used - 1]); replay_mu.unlock(); }
+#endif
 		}
 		// the serial coder runs on its own high-priority stream: its few waves must not queue behind the
 		// data-parallel kernels of another scheduler instance sharing the GPU
@@ -1358,6 +1366,21 @@ int dsrcgpu_selftest(dsrcgpu_handle* h, uint32_t* mismatches)
 	HIPCHK(hipMalloc((void**)&d_bad, 4));
 	HIPCHK(hipMemsetAsync(d_bad, 0, 4, h->stream));
 	hipLaunchKernelGGL(k_selftest, dim3(256), dim3(256), 0, h->stream, d_bad); KCHK();
+	{	// the property k_sort's atomic ranking stands on (dsrcgpu_create runs the same test to choose the variant); a violation
+		// counts as a mismatch here so that the test-suite notices a device on which the ballot variant is in use
+		u32* d_ord = nullptr; u32 ord = 0;
+		HIPCHK(hipMalloc((void**)&d_ord, 4));
+		HIPCHK(hipMemsetAsync(d_ord, 0, 4, h->stream));
+#ifdef DSRC_EMU_BUILD
+		hipLaunchKernelGGL(k_lds_order_test, dim3(1), dim3(256), 0, h->stream, d_ord, 20u); KCHK();
+#else
+		hipLaunchKernelGGL(k_lds_order_test, dim3(256), dim3(256), 0, h->stream, d_ord, 4096u); KCHK();
+#endif
+		HIPCHK(hipMemcpyAsync(&ord, d_ord, 4, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		HIPCHK(hipFree(d_ord));
+		if (ord) HIPCHK(hipMemsetAsync(d_bad, 0xFF, 4, h->stream));
+	}
 	HIPCHK(hipMemcpyAsync(mismatches, d_bad, 4, hipMemcpyDeviceToHost, h->stream));
 	HIPCHK(hipStreamSynchronize(h->stream));
 	HIPCHK(hipFree(d_bad));

@@ -259,6 +259,15 @@ def test_range_coder_reference_loop_path(emu, oracle, monkeypatch):
         assert run(emu, cfg, data) == oracle.compress_block(cfg, data)
 
 
+def test_sort_ballot_variant(emu, oracle, monkeypatch):
+    """k_sort has two ranking variants (LDS atomics where the device applies them in lane order, else ballots): same blocks."""
+    monkeypatch.setenv("DSRC_GPU_SORT_BALLOT", "1")
+    data = synth.illumina_fastq(300)[:-1]
+    for d, q, lossy in [(3, 2, False), (2, 1, True), (1, 2, False)]:
+        cfg = Config.from_levels(d, q, lossy)
+        assert run(emu, cfg, data) == oracle.compress_block(cfg, data)
+
+
 def test_exact_division_selftest(emu):
     h = emu.Handle()
     assert h.selftest() == 0

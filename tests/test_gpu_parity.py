@@ -200,6 +200,24 @@ def test_full_size_iontorrent_lossy(gpu, oracle):
         assert lines[0::4][:-1] == src[0::4] and [len(x) for x in lines[1::4]] == [len(x) for x in src[1::4]]
 
 
+def test_sort_ballot_variant(gpu, oracle, monkeypatch):
+    """k_sort ranks with LDS atomics on a device that passed k_lds_order_test (the self-test below fails if MI355X ever does
+    not) and with ballots otherwise; DSRC_GPU_SORT_BALLOT=1 forces the second variant: identical blocks, both equal to the oracle."""
+    chunks = [synth.illumina_fastq(3000, first=1 + 3000 * i)[:-1] for i in range(3)] + [fuzz_fastq(77, 3000)[0]]
+    for d, q, lossy in [(3, 2, False), (2, 1, True)]:
+        cfg = Config.from_levels(d, q, lossy)
+        want = [oracle.compress_block(cfg, c) for c in chunks]
+        h = gpu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
+        atomic = [h.compress_block(c) for c in chunks]
+        h.close()
+        monkeypatch.setenv("DSRC_GPU_SORT_BALLOT", "1")
+        h = gpu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
+        ballot = [h.compress_block(c) for c in chunks]
+        h.close()
+        monkeypatch.delenv("DSRC_GPU_SORT_BALLOT")
+        assert atomic == want and ballot == want
+
+
 def test_exact_division_selftest(gpu):
     h = gpu.Handle()
     assert h.selftest() == 0
