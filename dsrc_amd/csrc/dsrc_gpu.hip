@@ -682,11 +682,6 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			else hipLaunchKernelGGL((k_sort<0, false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state);
 			KCHK();
 			stage_mark(0); stage_mark(1);
-#ifdef DSRC_REPLAY_TURNS
-			static std::mutex replay_mu;                 // experiment: one instance's k_replay on the GPU at a time
-			static const bool turns = getenv("DSRC_GPU_REPLAY_TURNS") != nullptr;
-			if (turns) { (void)hipEventSynchronize(h->stage_ev[h->stage_used - 1]); replay_mu.lock(); }
-#endif
 			for (u32 lo = s_lo; lo < s_hi;)
 			{
 				u32 hi = lo;
@@ -729,9 +724,6 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 				lo = hi;
 			}
 			stage_mark(1);
-#ifdef DSRC_REPLAY_TURNS
-			if (turns) { (void)hipEventSynchronize(h->stage_ev[h->stage_used - 1]); replay_mu.unlock(); }
-#endif
 		}
 		// the serial coder runs on its own high-priority stream: its few waves must not queue behind the
 		// data-parallel kernels of another scheduler instance sharing the GPU
