@@ -790,7 +790,7 @@ struct RcFin { u32 n; u8 b[60]; };
 #endif                                 // CU with two k_sort workgroups, and it issues half as many DMA requests per symbol
 #define RC_CHUNK 64                    // symbols per chain per LDS chunk (768 B = 48 lanes x 16 B)
 #define RC_ROW_U4 49                   // LDS row pitch in 16-byte units: 48 of data + 1 so that a 16-lane ds_read_b128 pass covers all 64 banks
-#define RC_OVERREAD (5 * RC_CHUNK)     // records the loaders may touch past the longest chain of a wave (arena slack)
+#define RC_OVERREAD (8 * RC_CHUNK)     // records the loaders may touch past the longest chain of a wave (arena slack)
 #ifndef RC_LOADERS
 #define RC_LOADERS 2                   // loader waves per workgroup (each feeds RC_LANES / RC_LOADERS rows)
 #endif
@@ -972,19 +972,33 @@ __device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains
 		const u8* base = uniform_ptr(rec_pool + __shfl(c.trip, 0));
 		const u32 pitch = (u32)__builtin_amdgcn_readfirstlane((int)(c.pitch * (u32)sizeof(RcPack)));
 		const u32 lw = wave_id() - 1u, CB = RC_CHUNK * (u32)sizeof(RcPack);
-		RcPack ra[RC_ROWS_PER_LOADER], rb[RC_ROWS_PER_LOADER];
-		rc_fetch(ra, base, pitch, 0, lw, n_live);
-		rc_fetch(rb, base, pitch, CB, lw, n_live);
-		rc_convert(buf_a, ra, lw, n_live);
+		// four register sets: a chunk is requested three chunk periods (~8 us) before it is converted -- with other instances'
+		// scatter traffic on the memory system a load can take several microseconds (one period ahead: k_rc 174 ms per 300 blocks
+		// under contention, 77 alone)
+		RcPack r0[RC_ROWS_PER_LOADER], r1[RC_ROWS_PER_LOADER], r2[RC_ROWS_PER_LOADER], r3[RC_ROWS_PER_LOADER];
+		rc_fetch(r0, base, pitch, 0, lw, n_live);
+		rc_fetch(r1, base, pitch, CB, lw, n_live);
+		rc_fetch(r2, base, pitch, 2 * CB, lw, n_live);
+		rc_fetch(r3, base, pitch, 3 * CB, lw, n_live);
+		rc_convert(buf_a, r0, lw, n_live);
 		__syncthreads();                                                       // chunk 0 is there
 		for (u32 t0 = 0; t0 < wave_full; t0 += 2 * RC_CHUNK)
 		{
-			rc_fetch(ra, base, pitch, (t0 + 2 * RC_CHUNK) * (u32)sizeof(RcPack), lw, n_live);
-			rc_convert(buf_b, rb, lw, n_live);
+			const u32 off = t0 * (u32)sizeof(RcPack);
+			rc_fetch(r0, base, pitch, off + 4 * CB, lw, n_live);
+			rc_convert(buf_b, r1, lw, n_live);
 			__syncthreads();                                                   // coder is through buf_a, chunk t0+64 is in buf_b
-			rc_fetch(rb, base, pitch, (t0 + 3 * RC_CHUNK) * (u32)sizeof(RcPack), lw, n_live);
-			rc_convert(buf_a, ra, lw, n_live);
+			rc_fetch(r1, base, pitch, off + 5 * CB, lw, n_live);
+			rc_convert(buf_a, r2, lw, n_live);
 			__syncthreads();                                                   // coder is through buf_b, chunk t0+128 is in buf_a
+			t0 += 2 * RC_CHUNK;
+			if (t0 >= wave_full) break;                                        // one coder iteration = two barriers: the halves are the same code on rotated sets
+			rc_fetch(r2, base, pitch, off + 6 * CB, lw, n_live);
+			rc_convert(buf_b, r3, lw, n_live);
+			__syncthreads();
+			rc_fetch(r3, base, pitch, off + 7 * CB, lw, n_live);
+			rc_convert(buf_a, r0, lw, n_live);
+			__syncthreads();
 		}
 		return;
 	}
