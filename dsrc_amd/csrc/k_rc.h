@@ -486,13 +486,23 @@ template <int N> struct ReplayRow
 	}
 };
 
+// value of lane 63 in every lane (v_readlane: no trip through the LDS crossbar)
+__device__ __forceinline__ u32 wave_last(u32 v)
+{
+#ifdef DSRC_EMU_BUILD
+	return __shfl(v, 63);
+#else
+	return (u32)__builtin_amdgcn_readlane((int)v, 63);
+#endif
+}
+
 template <int N> __device__ __forceinline__ void replay_prefix(const ReplayRow<N>& r, ReplayRow<N>& ex, u32* total)
 {
-	const u32 ia = wave_incl_scan(r.a);
-	const u32 ta = __shfl(ia, 63);
+	const u32 ia = wave_incl_scan_dpp(r.a);
+	const u32 ta = wave_last(ia);
 	ex.a = ia - r.a;
 	u32 tb = 0; ex.b = 0;
-	if (N > 64) { const u32 ib = wave_incl_scan(r.b); tb = __shfl(ib, 63); ex.b = ta + ib - r.b; }
+	if (N > 64) { const u32 ib = wave_incl_scan_dpp(r.b); tb = wave_last(ib); ex.b = ta + ib - r.b; }
 	*total = ta + tb;
 }
 
@@ -706,8 +716,10 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 		const u32 in_seg = (u32)__popcll(segmask_lt & tmask);
 		u32 f, cum, tot;
 		{
-			const u32 b0 = base.get(sym), cb = cumbase.get(sym), cc = cnt.get(sym), cp = cntpre.get(sym);
-			if (in_cont) { f = b0 + 2 * (cc + same); cum = cb + 2 * (cp + less); tot = T0 + 2 * (epoch_cnt + in_seg); }
+			ReplayRow<N> st, cs;                                   // the row and its prefix as they stand at the start of the window
+			st.a = base.a + 2 * cnt.a; st.b = base.b + 2 * cnt.b; cs.a = cumbase.a + 2 * cntpre.a; cs.b = cumbase.b + 2 * cntpre.b;
+			const u32 b0 = st.get(sym), cb = cs.get(sym);
+			if (in_cont) { f = b0 + 2 * same; cum = cb + 2 * less; tot = T0 + 2 * (epoch_cnt + in_seg); }
 			else { f = 1 + 2 * same; cum = sym + 2 * less; tot = N + 2 * in_seg; }
 		}
 		if (active)
