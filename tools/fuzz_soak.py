@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off soak: many more fuzz seeds than the test-suite runs, GPU path vs oracle, for a bounded time.
-Usage: tools/fuzz_soak.py [first_seed] [seconds] [batch|solid|records]"""
+Usage: tools/fuzz_soak.py [first_seed] [seconds] [batch|solid|records|decode]"""
 import dataclasses
 import os
 import sys
@@ -106,7 +106,50 @@ def records_mode(seed, limit):
     print(f"fuzz soak (record layout): {n} blocks identical, seeds up to {seed - 1}, {time.time() - t0:.0f} s")
 
 
+def decode_mode(seed, limit):
+    """Round trip on the GPU: batches of 20-40 heterogeneous chunks compressed (state carried in chunk order), the blocks
+    decompressed by the GPU decoder and compared with the oracle's decoder on the same blocks (lossless unfiltered
+    configurations: also with the input) and with the stored checksums."""
+    import random
+    o = Oracle()
+    t0 = time.time(); n = 0; nb = 0; broken = 0
+    cfgs = [(3, 2, False, True), (0, 0, False, False), (2, 1, True, True), (1, 2, False, False), (3, 0, False, True), (0, 2, True, False)]
+    while time.time() - t0 < limit:
+        rng = random.Random(seed)
+        d, q, lossy, crc = cfgs[seed % len(cfgs)]
+        flags = [0, 0, 0b110, 0][seed % 4]
+        cfg = dataclasses.replace(Config.from_levels(d, q, lossy, crc), tag_flags=flags)
+        chunks = []; s2 = seed * 1000
+        want_n = rng.randrange(20, 41)
+        while len(chunks) < want_n:
+            data, _ = fuzz_fastq(s2, rng.choice([None, None, 2000, 6000])); s2 += 1
+            try:
+                o.compress_block(cfg, data)
+            except RuntimeError:
+                continue
+            chunks.append(data)
+        h = _lib.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, tag_flags=flags)
+        blocks = [b[0] for b in h.compress_batch(chunks)]
+        keep = []; want = []
+        for blk, ch in zip(blocks, chunks):
+            try:
+                want.append(o.decompress_block(cfg, blk, len(ch) + 4096)); keep.append((blk, ch))
+            except RuntimeError:
+                broken += 1                                      # the reference's own decoder runs off this block (DESIGN section 1)
+        texts, ok = h.decompress_batch([b for b, _ in keep], text_caps=[len(c) + 4096 for _, c in keep], verify=True)
+        h.close()
+        for i, (blk, ch) in enumerate(keep):
+            assert texts[i] == want[i], f"decode seed {seed} chunk {i} -d{d} -q{q} lossy={lossy} flags={flags:#x}: GPU text differs from the oracle's"
+            if crc: assert ok[i] == 1, f"decode seed {seed} chunk {i}: checksum verdict {ok[i]}"
+            if not lossy and not flags: assert texts[i] == ch + b"\n", f"decode seed {seed} chunk {i}: round trip differs from the input"
+            n += 1
+        nb += 1; seed += 1
+    print(f"fuzz soak (decode round trips): {nb} batches, {n} blocks decoded identically, {broken} blocks the reference cannot decode skipped, {time.time() - t0:.0f} s")
+
+
 def main():
+    if len(sys.argv) > 3 and sys.argv[3] == "decode":
+        return decode_mode(int(sys.argv[1]), float(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "batch":
         return batch_mode(int(sys.argv[1]), float(sys.argv[2]))
     if len(sys.argv) > 3 and sys.argv[3] == "solid":
