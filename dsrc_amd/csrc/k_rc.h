@@ -607,7 +607,9 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay_seams(const CtxJob* jobs, 
 		{
 			u32* st = seams + (u64)(pos / per) * REPLAY_SEAM_WORDS;
 			if (lane == 0) { st[0] = T0; st[1] = epoch_cnt; st[2] = epoch_left; st[3] = 0x5EA35EA3u; }
-			st[4 + lane] = base_a; st[68 + lane] = base_b; st[132 + lane] = cnt_a; st[196 + lane] = cnt_b;
+			// lanes >= N hold zeros by construction and the second halves only exist for N = 128: nothing else is written or read
+			if (lane < (u32)N) { st[4 + lane] = base_a; st[132 + lane] = cnt_a; }
+			if (N > 64) { st[68 + lane] = base_b; st[196 + lane] = cnt_b; }
 			next_b += per;
 		}
 	}
@@ -644,7 +646,8 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 	{
 		const u32* st = (const u32*)(pool + (j.sorted_in_b ? j.elems : j.elems_b)) + (u64)(pos / per) * REPLAY_SEAM_WORDS;
 		T0 = st[0]; epoch_cnt = st[1]; epoch_left = st[2];
-		base.a = st[4 + lane]; base.b = st[68 + lane]; cnt.a = st[132 + lane]; cnt.b = st[196 + lane];
+		base.a = lane < (u32)N ? st[4 + lane] : 0u; cnt.a = lane < (u32)N ? st[132 + lane] : 0u;
+		base.b = N > 64 ? st[68 + lane] : 0u; cnt.b = N > 64 ? st[196 + lane] : 0u;
 		u32 t; replay_prefix<N>(base, cumbase, &t); replay_prefix<N>(cnt, cntpre, &t);
 		open = true;
 	}

@@ -108,8 +108,9 @@ def records_mode(seed, limit):
 
 def decode_mode(seed, limit):
     """Round trip on the GPU: batches of 20-40 heterogeneous chunks compressed (state carried in chunk order), the blocks
-    decompressed by the GPU decoder and compared with the oracle's decoder on the same blocks (lossless unfiltered
-    configurations: also with the input) and with the stored checksums."""
+    decompressed by the GPU decoder and compared with the oracle's decoder (pinned to the reference's Read) on the same
+    blocks and with the stored checksums.  (The fuzz inputs carry CR LF, repeated titles on the + line ...: the reference does
+    not give those back byte for byte, so the input itself is not the yardstick here; tests/test_gpu_decode.py has the round trips.)"""
     import random
     o = Oracle()
     t0 = time.time(); n = 0; nb = 0; broken = 0
@@ -141,7 +142,6 @@ def decode_mode(seed, limit):
         for i, (blk, ch) in enumerate(keep):
             assert texts[i] == want[i], f"decode seed {seed} chunk {i} -d{d} -q{q} lossy={lossy} flags={flags:#x}: GPU text differs from the oracle's"
             if crc: assert ok[i] == 1, f"decode seed {seed} chunk {i}: checksum verdict {ok[i]}"
-            if not lossy and not flags: assert texts[i] == ch + b"\n", f"decode seed {seed} chunk {i}: round trip differs from the input"
             n += 1
         nb += 1; seed += 1
     print(f"fuzz soak (decode round trips): {nb} batches, {n} blocks decoded identically, {broken} blocks the reference cannot decode skipped, {time.time() - t0:.0f} s")
