@@ -34,6 +34,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 RECS_PER_BLOCK = 22300
 PMC_RC_BYTES_PER_BLOCK = (13.3515e6 * 2 + 13.3427e6) * 1024 / 512   # measured, see roofline.traffic below
 PMC_SORT_BYTES_PER_BLOCK = (16.6858e6 * 2 + 65.8718e6) * 1024 / 512  # k_sort, eight launches of a 512-block batch (same profile)
+PMC_REPLAY_BYTES_PER_BLOCK = ((9.2572e6 + 8.9190e6) * 2 + 55.0891e6 + 54.9436e6) * 1024 / 512   # k_replay<32> + k_replay<4>: 293 MB per block, 225 of them the scattered 8-byte records at one 32-byte sector each
 MAX_RESIDENT = 3                  # distinct input shards kept in HBM per scheduler instance (2 when N > 1: rank 0 also holds the gathered streams)
 
 
@@ -418,8 +419,10 @@ def main():
                 "achieved": round(alg / (sort_ms / 1e3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(alg / (sort_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5), "kernel_ms": round(sort_ms, 2), "replay_ms": round(replay_ms, 2),
                 "launch_bytes": int(alg), "traffic": int(PMC_SORT_BYTES_PER_BLOCK * sub_blocks),
+                "replay_traffic": int(PMC_REPLAY_BYTES_PER_BLOCK * sub_blocks),
                 "note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE of the k_sort launches of a 512-block batch / 512 (profiles/r02_pmc_b512_p1_d3q2.txt); "
-                        "replay_ms = k_replay_seams + k_replay of the same sub-batch"}
+                        "replay_ms = k_replay_seams + k_replay of the same sub-batch, replay_traffic = the same counters for k_replay: its scatter of one 8-byte record per symbol to stream order "
+                        "(one 32-byte sector each) is what bounds the pipeline with several instances (DESIGN section 10: 33.7 instead of 25.8 GB/s without it)"}
         decode_line = None
         if args.decode_blocks > 0 and world == 1:
             decode_line = measure_decode(lanes, cfg, args.decode_blocks, total_steps - 1)
