@@ -532,6 +532,19 @@ __device__ __forceinline__ u32 replay_per(u32 n, u32 n_ranges)
 	return per < 256u ? 256u : per;
 }
 
+// Ranges bend to the segments: the boundary between two ranges is nominally b = w * per, but if a segment starts in
+// [b, b + 64) the ranges meet at that segment's head -- the wave before replays the few elements up to it, nobody needs a row
+// state for b.  Only a segment that runs through the whole window (a long one) is cut at b itself, with the state from
+// k_replay_seams.  Both neighbours and k_replay_seams call this with the same b and get the same answer.  0 < b < n.
+__device__ __forceinline__ u32 replay_snap(const u64* src, u32 b, u32 n, bool* inside)
+{
+	const u32 idx = b + lane_id(), i = idx < n ? idx : n - 1;
+	const bool head = idx < n && (src[i] >> ELEM_CTX_SHIFT) != (src[i - 1] >> ELEM_CTX_SHIFT);
+	const u64 m = __ballot(head);
+	*inside = m == 0;
+	return m ? b + (u32)__ffsll((long long)m) - 1u : b;
+}
+
 template <int N>
 __global__ void __launch_bounds__(REPLAY_WG) k_replay_seams(const CtxJob* jobs, u64* pool, u32 parts, u32 n_streams)
 {
@@ -548,7 +561,7 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay_seams(const CtxJob* jobs, 
 	const u64 r_lo64 = (u64)(part * (REPLAY_WG / 64) + wave_id()) * per;
 	if (r_lo64 + per >= n) return;                          // no boundary after this range
 	const u32 r_lo = (u32)r_lo64, hi = r_lo + per;
-	if ((src[hi] >> ELEM_CTX_SHIFT) != (src[hi - 1] >> ELEM_CTX_SHIFT)) return;      // nothing crosses my upper boundary
+	{ bool inside; (void)replay_snap(src, hi, n, &inside); if (!inside) return; }      // nothing long crosses my upper boundary
 	// head of the segment that crosses it, if it lies in my range (otherwise the owner of that head walks through here)
 	u32 h = 0; bool found = false;
 	for (u32 we = hi; we > r_lo && !found; we -= 64)
@@ -632,10 +645,13 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 	const u32 per = replay_per(n, parts * (REPLAY_WG / 64));
 	const u64 r_lo = (u64)(part * (REPLAY_WG / 64) + wave_id()) * per;
 	if (r_lo >= n) return;
-	const u32 hi = (u32)(r_lo + per < n ? r_lo + per : n);
+	u32 hi = (u32)(r_lo + per < n ? r_lo + per : n);
 	u32 pos = (u32)r_lo;
-	// a range that starts inside a segment takes the row state k_replay_seams left for its lower boundary
-	const bool mid = pos > 0 && (src[pos] >> ELEM_CTX_SHIFT) == (src[pos - 1] >> ELEM_CTX_SHIFT);
+	// both ends bend to the next segment head if there is one within 64 elements (replay_snap); a range that still starts
+	// inside a segment takes the row state k_replay_seams left for its lower boundary
+	bool mid = false;
+	if (pos > 0) pos = replay_snap(src, pos, n, &mid);
+	if (hi < n) { bool in_hi; hi = replay_snap(src, hi, n, &in_hi); }
 
 	ReplayRow<N> base, cnt, cumbase, cntpre;
 	base.a = base.b = 1; cnt.a = cnt.b = 0; cumbase.a = cumbase.b = 0; cntpre.a = cntpre.b = 0;
