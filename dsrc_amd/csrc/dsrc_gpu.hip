@@ -705,8 +705,8 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 #define RPROBE_RUN(NN, M) { hipEventRecord(e0, s); hipLaunchKernelGGL((k_replay<NN, M>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt); \
 						hipEventRecord(e1, s); hipEventSynchronize(e1); float ms = 0; hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[probe] k_replay<%d,%d> %u streams x %u parts: %.2f ms\n", NN, M, cnt, parts, ms); }
 						hipLaunchKernelGGL(k_replay_seams<32>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt);
-						if (jobs[lo].n_alpha == 32) { RPROBE_RUN(32, 0) RPROBE_RUN(32, 0) RPROBE_RUN(32, 1) RPROBE_RUN(32, 2) RPROBE_RUN(32, 8) RPROBE_RUN(32, 16) RPROBE_RUN(32, 32) }
-						else { RPROBE_RUN(4, 0) RPROBE_RUN(4, 0) RPROBE_RUN(4, 1) RPROBE_RUN(4, 2) RPROBE_RUN(4, 8) RPROBE_RUN(4, 16) RPROBE_RUN(4, 32) }
+						if (jobs[lo].n_alpha == 32) { RPROBE_RUN(32, 0) RPROBE_RUN(32, 0) RPROBE_RUN(32, 1) RPROBE_RUN(32, 2) RPROBE_RUN(32, 8) RPROBE_RUN(32, 16) }
+						else { RPROBE_RUN(4, 0) RPROBE_RUN(4, 0) RPROBE_RUN(4, 1) RPROBE_RUN(4, 2) RPROBE_RUN(4, 8) RPROBE_RUN(4, 16) }
 						hipEventDestroy(e0); hipEventDestroy(e1);
 					}
 				}

@@ -628,7 +628,8 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay_seams(const CtxJob* jobs, 
 	}
 }
 
-// PROBE != 0: timing experiments only (-DDSRC_SORT_PROBE): 1 no record store, 2 records stored in sorted order (no scatter), 4 no reciprocal
+// PROBE != 0: timing experiments only (-DDSRC_SORT_PROBE): 1 no record store, 2 records stored in sorted order (no scatter),
+// 8 / 16 scatter inside an 8 MB / 128 KB window
 template <int N, int PROBE = 0>
 __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const u64* pool, RcPack* rec_pool, u32 parts, u32 n_streams)
 {
