@@ -178,6 +178,42 @@ __device__ __forceinline__ u32 dna_index(u32 c)
 	}
 }
 
+// The switch above compiles into a tree of divergent branches: with four or five different bases in a wave every path runs.
+// The same function as selects on two packed constants (5-bit entries for 'A'..'Y'), checked against the switch for all
+// 256 characters at compile time.
+constexpr u32 dna_index_packed(u32 c, u64 K0, u64 K1)
+{
+	const u32 i = c - 'A';
+	const bool lo = i < 12;
+	const u64 k = lo ? K0 : K1;
+	const u32 j = lo ? i : i - 12;
+	const u32 sh = 5 * (j < 12 ? j : 12);
+	u32 v = i < 25 ? (u32)(k >> sh) & 31u : 31u;
+	v = c == '.' ? 17u : v;
+	v = c == '-' ? 18u : v;
+	return v == 31u ? 255u : v;
+}
+#define DNA_INDEX_K0 0x0fa3ff607ff509a0ull
+#define DNA_INDEX_K1 0xe7997019cbfffc89ull
+constexpr u32 dna_index_switch_c(u32 c)
+{
+	switch (c)
+	{
+	case 'A': return 0; case 'G': return 1; case 'C': return 2; case 'T': return 3; case 'N': return 4;
+	case 'R': return 5; case 'W': return 6; case 'S': return 7; case 'K': return 8; case 'M': return 9;
+	case 'D': return 10; case 'V': return 11; case 'H': return 12; case 'B': return 13; case 'Y': return 14;
+	case 'X': return 15; case 'U': return 16; case '.': return 17; case '-': return 18;
+	default: return 255;
+	}
+}
+constexpr bool dna_index_same()
+{
+	for (u32 c = 0; c < 256; ++c) if (dna_index_packed(c, DNA_INDEX_K0, DNA_INDEX_K1) != dna_index_switch_c(c)) return false;
+	return true;
+}
+static_assert(dna_index_same(), "dna_index: packed table differs from src/RecordsProcessor.cpp:186-206");
+template <bool FAST> __device__ __forceinline__ u32 dna_index_t(u32 c) { return FAST ? dna_index_packed(c, DNA_INDEX_K0, DNA_INDEX_K1) : dna_index(c); }
+
 // lossy Illumina 8-bin quantiser (src/RecordsProcessor.cpp:318-341)
 __device__ __forceinline__ u32 lossy_bin(u32 q)
 {
@@ -186,10 +222,20 @@ __device__ __forceinline__ u32 lossy_bin(u32 q)
 	return 255;
 }
 
+// k_prep_stats takes the select form of dna_index (12.2 -> 5.5 ms per 512 blocks).  k_prep_write does NOT: with it the kernel
+// (10.4 -> 5.1 ms) left the quality stream wrong on the GPU -- box-dependent garbage, the emulator build green, the function
+// itself identical on the device for all inputs; not understood, so that kernel keeps the switch.
+#ifndef FAST_STATS
+#define FAST_STATS true
+#endif
+#ifndef FAST_WRITE
+#define FAST_WRITE false
+#endif
 // one base: returns transformed quality, sets *keep / *sidx
+template <bool FAST = false>
 __device__ __forceinline__ u32 transform_base(u32 base, u32 qual, u32 qoff, u32 lossy, u32* sidx, bool* keep)
 {
-	const u32 s = dna_index(base);
+	const u32 s = dna_index_t<FAST>(base);
 	*sidx = s;
 	u32 q;
 	if (!lossy)
@@ -305,8 +351,8 @@ __global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* 
 			const u32 j = j0 + lane;
 			const bool in_r = j < len;
 			u32 sidx = 0, q = 0; bool keep = false;
-			if (in_r) q = j0 ? transform_base(p[so + j], p[qo + j], prm.quality_offset, prm.lossy, &sidx, &keep)
-							 : transform_base(c_b, c_q, prm.quality_offset, prm.lossy, &sidx, &keep);
+			if (in_r) q = j0 ? transform_base<FAST_STATS>(p[so + j], p[qo + j], prm.quality_offset, prm.lossy, &sidx, &keep)
+							 : transform_base<FAST_STATS>(c_b, c_q, prm.quality_offset, prm.lossy, &sidx, &keep);
 			const bool k2 = in_r && keep;
 			if (in_r) atomicAdd(&s_qf[q], 1u);
 			if (in_r && sidx >= 20) a_bad = 1;
@@ -443,7 +489,7 @@ __global__ void __launch_bounds__(WG) k_prep_write(const u8* in, const BlkDesc* 
 			const u32 j = j0 + lane;
 			const bool in_r = j < len;
 			u32 sidx = 0, q = 0; bool keep = false;
-			if (in_r) q = transform_base(p[so + j], p[qo + j], prm.quality_offset, prm.lossy, &sidx, &keep);
+			if (in_r) q = transform_base<FAST_WRITE>(p[so + j], p[qo + j], prm.quality_offset, prm.lossy, &sidx, &keep);
 			const bool k2 = in_r && keep;
 			const u64 km = __ballot(k2);
 			if (in_r && j >= red) { qs[j - red] = (u8)q; if (write_qp) qps[j - red] = (u8)(((j - red) * 128u) / rlen); }
