@@ -129,7 +129,10 @@ int fail(dsrcgpu_handle* h, int code, const char* fmt, ...)
 
 int ensure_arena(dsrcgpu_handle* h, size_t need)
 {
-	if (h->arena.cap >= need) { h->arena.top = 0; h->arena.failed = false; return 0; }
+	// debugging aid: DSRC_GPU_DEBUG_FILL=<byte> fills the arena before every batch -- an output that changes with the byte
+	// means some kernel reads arena bytes nobody wrote
+	const char* fill = getenv("DSRC_GPU_DEBUG_FILL");
+	if (h->arena.cap >= need) { h->arena.top = 0; h->arena.failed = false; if (fill) HIPCHK(hipMemsetAsync(h->arena.base, atoi(fill), h->arena.cap, h->stream)); return 0; }
 	if (h->arena_fixed && need > h->arena_fixed)
 		return fail(h, DSRCGPU_E_NOMEM, "batch needs %zu bytes of HBM scratch, arena is fixed at %llu", need, (unsigned long long)h->arena_fixed);
 	if (h->arena.base) { HIPCHK(hipFree(h->arena.base)); h->arena.base = nullptr; h->arena.cap = 0; }
@@ -137,6 +140,7 @@ int ensure_arena(dsrcgpu_handle* h, size_t need)
 	hipError_t e = hipMalloc((void**)&h->arena.base, want);
 	if (e != hipSuccess) return fail(h, DSRCGPU_E_NOMEM, "hipMalloc(%zu) for the batch arena failed: %s", want, hipGetErrorString(e));
 	h->arena.cap = want; h->arena.top = 0; h->arena.failed = false;
+	if (fill) HIPCHK(hipMemsetAsync(h->arena.base, atoi(fill), h->arena.cap, h->stream));
 	return 0;
 }
 

@@ -218,6 +218,25 @@ def test_sort_ballot_variant(gpu, oracle, monkeypatch):
         assert atomic == want and ballot == want
 
 
+def test_no_kernel_reads_unwritten_arena_bytes(gpu, oracle, monkeypatch):
+    """DSRC_GPU_DEBUG_FILL=<byte> fills the arena before every batch: the blocks must not depend on the byte (nothing reads
+    what nobody wrote) and equal the oracle's."""
+    chunks = [synth.illumina_fastq(4000, first=1 + 4000 * i)[:-1] for i in range(3)] + [fuzz_fastq(91, 3000)[0]]
+    for d, q, lossy, crc in [(3, 2, False, True), (0, 0, False, False), (2, 1, True, False)]:
+        cfg = Config.from_levels(d, q, lossy, crc)
+        want0 = oracle.compress_block(cfg, chunks[0])
+        ref = None
+        for fill in ("0", "255", "90"):
+            monkeypatch.setenv("DSRC_GPU_DEBUG_FILL", fill)
+            h = gpu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
+            got = h.compress_batch(chunks) + h.compress_batch(chunks[::-1])
+            h.close()
+            assert got[0] == want0, (d, q, fill)
+            assert ref is None or got == ref, (d, q, fill)
+            ref = got
+        monkeypatch.delenv("DSRC_GPU_DEBUG_FILL")
+
+
 def test_exact_division_selftest(gpu):
     h = gpu.Handle()
     assert h.selftest() == 0
