@@ -222,14 +222,12 @@ __device__ __forceinline__ u32 lossy_bin(u32 q)
 	return 255;
 }
 
-// k_prep_stats takes the select form of dna_index (12.2 -> 5.5 ms per 512 blocks).  k_prep_write does NOT: with it the kernel
-// (10.4 -> 5.1 ms) left the quality stream wrong on the GPU -- box-dependent garbage, the emulator build green, the function
-// itself identical on the device for all inputs; not understood, so that kernel keeps the switch.
+// k_prep_stats and k_prep_write take the select form of dna_index (12.2 -> 5.5 and 10.4 -> 5.x ms per 512 blocks); false = the switch
 #ifndef FAST_STATS
 #define FAST_STATS true
 #endif
 #ifndef FAST_WRITE
-#define FAST_WRITE false
+#define FAST_WRITE true
 #endif
 // one base: returns transformed quality, sets *keep / *sidx
 template <bool FAST = false>
@@ -489,7 +487,13 @@ __global__ void __launch_bounds__(WG) k_prep_write(const u8* in, const BlkDesc* 
 			const u32 j = j0 + lane;
 			const bool in_r = j < len;
 			u32 sidx = 0, q = 0; bool keep = false;
-			if (in_r) q = transform_base<FAST_WRITE>(p[so + j], p[qo + j], prm.quality_offset, prm.lossy, &sidx, &keep);
+			{	// every lane evaluates the (branch-free) transform, lanes past the end of the read on a harmless stand-in: with the call
+				// inside `if (in_r)` this kernel gave a wrong quality stream on the GPU once dna_index had become selects (DESIGN.md
+				// section 10) -- the emulator build, the function on its own and k_prep_stats with the same call were all right
+				const u32 cb = in_r ? (u32)p[so + j] : (u32)'A', cq = in_r ? (u32)p[qo + j] : prm.quality_offset + 40u;
+				const u32 qq = transform_base<FAST_WRITE>(cb, cq, prm.quality_offset, prm.lossy, &sidx, &keep);
+				if (in_r) q = qq; else { keep = false; sidx = 0; }
+			}
 			const bool k2 = in_r && keep;
 			const u64 km = __ballot(k2);
 			if (in_r && j >= red) { qs[j - red] = (u8)q; if (write_qp) qps[j - red] = (u8)(((j - red) * 128u) / rlen); }
