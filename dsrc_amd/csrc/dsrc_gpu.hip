@@ -34,6 +34,7 @@
 #include "k_block.h"
 #include "k_synth.h"
 #include "k_dec.h"
+#include "k_dec_rc.h"
 
 namespace
 {
@@ -111,6 +112,7 @@ struct dsrcgpu_handle
 	float sort_ms = 0.f, replay_ms = 0.f, decode_stream_ms = 0.f;
 	bool sort_atomic = false;        // k_sort ranks with LDS atomics (device passed k_lds_order_test), else with ballots
 	u64 dec_table_budget = 0;        // dsrcgpu_set_table_budget: HBM a decoding pass may take for model tables (0 = automatic)
+	u32* dec_tables = nullptr; u64 dec_tables_cap = 0;     // model tables of the range-decoded levels (bytes), kept between passes
 };
 
 namespace
@@ -837,29 +839,80 @@ struct DecodeIO
 	u32* crc_ok;                     // optional, per block: 1 = the stored checksums match the decoded records
 };
 
-// u32 words of the largest model table the settings can ask for
+// ---- model tables of the range-decoded levels (here DENSE: every row is reachable) ------------------------
+// u32 words of the table of an order-context quality scheme: alphabet^order contexts x position contexts x alphabet counters
+// `cnt` = symbols present in the block (0: the whole alphabet): contexts are made of decoded symbols, so a context holding a
+// symbol the block does not have is never reached and the decoder's rows are numbered in base cnt (k_dec_rc.h)
+u64 q_table_words(u32 quality_order, bool lossy, u32 scheme, u32 cnt, u32* n_out)
+{
+	u32 n, ord, resc;
+	if (lossy) { n = 8; ord = quality_order; resc = 8; }
+	else
+	{
+		const u32 sc = scheme & 3u;
+		n = 16u << sc;
+		ord = quality_order == 1 ? (sc == 0 ? 3u : sc == 1 ? 2u : 1u) : (4u - sc);
+		resc = scheme < 4 ? 8u : n;
+	}
+	if (n_out) *n_out = n;
+	(void)cnt;                  // rows numbered in base cnt were measured slower (3.18 instead of 2.79 s per 2400 blocks): not used
+	return ((u64)1 << (log2u(n) * ord)) * resc * n / 2;
+}
+// the same for the order-k DNA models: 4 symbols at the full order, 8 symbols at order <= 7 (src/DnaModelerProxy.h:196-229)
+u64 d_table_words(u32 dna_order, u32 d_scheme)
+{
+	return d_scheme ? ((u64)1 << (3 * std::min(dna_order, 7u))) * 4 : ((u64)1 << (2 * dna_order)) * 2;
+}
+// the largest table the settings can ask for: one slot of the one-lane decoder (DSRC_GPU_DEC_SERIAL)
 u64 dec_table_words(const dsrcgpu_settings& set)
 {
 	u64 q = 0, d = 0;
 	const u32 qo = set.quality_order, dn = set.dna_order;
-	if (qo > 0 && set.lossy) q = (1ull << (3 * (qo + 1))) * 4;
-	else if (qo == 1) q = 1ull << 20;                        // <128,1>: 128^2 rows x 128 counters
-	else if (qo == 2) q = 1ull << 24;                        // <32,3>: 32^4 rows x 32 counters = 64 MiB
-	if (dn > 0) d = std::max((1ull << (2 * dn)) * 2, (1ull << (3 * std::min(dn, 7u))) * 4);
+	if (qo > 0 && set.lossy) q = q_table_words(qo, true, 0, 0, nullptr);
+	else if (qo > 0) for (u32 sch = 0; sch < 8; ++sch) q = std::max(q, q_table_words(qo, false, sch, 0, nullptr));
+	if (dn > 0) d = std::max(d_table_words(dn, 0), d_table_words(dn, 1));
 	return std::max<u64>(std::max(q, d), 16);
 }
 
-// bytes of HBM the model-table slots of one decode pass may take: DSRC_GPU_DEC_TABLE_MB, else 70 % of what is free once
-// the rest of the pass (`other` bytes of arena) is accounted for, but never more than 160 GiB
-u64 dec_table_budget(const dsrcgpu_handle* h, size_t other)
+// bytes of HBM the model tables of one decode pass may take: DSRC_GPU_DEC_TABLE_MB / dsrcgpu_set_table_budget, else 70 % of
+// what is free (counting the region the handle already holds), never more than 160 GiB
+u64 dec_table_budget(const dsrcgpu_handle* h)
 {
 	if (const char* env = getenv("DSRC_GPU_DEC_TABLE_MB")) return (u64)atol(env) << 20;
 	if (h->dec_table_budget) return h->dec_table_budget;
 	size_t free_b = 0, total_b = 0;
 	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (u64)8192 << 20;
-	const u64 avail = (u64)free_b + h->arena.cap;             // the arena is re-allocated when it has to grow
-	const u64 rest = avail > other + ((u64)2048 << 20) ? avail - other - ((u64)2048 << 20) : 0;
+	const u64 avail = (u64)free_b + h->dec_tables_cap;
+	const u64 rest = avail > ((u64)2048 << 20) ? avail - ((u64)2048 << 20) : 0;
 	return std::min<u64>(std::max<u64>(rest * 7 / 10, (u64)256 << 20), (u64)160 << 30);
+}
+
+// the table region lives outside the batch arena (its size is known only in the middle of a pass) and is kept between passes
+int ensure_dec_tables(dsrcgpu_handle* h, u64 bytes)
+{
+	if (h->dec_tables_cap >= bytes) return 0;
+	if (h->dec_tables) { HIPCHK(hipStreamSynchronize(h->stream)); HIPCHK(hipFree(h->dec_tables)); h->dec_tables = nullptr; h->dec_tables_cap = 0; }
+	const u64 want = bytes + bytes / 16 + 4096;
+	hipError_t e = hipMalloc((void**)&h->dec_tables, want);
+	if (e != hipSuccess) return fail(h, DSRCGPU_E_HIP, "hipMalloc(%llu) for the decoder's model tables failed: %s", (unsigned long long)want, hipGetErrorString(e));
+	h->dec_tables_cap = want;
+	return 0;
+}
+
+// Rounds: the tables of as many blocks as fit the region at once; a round is one streaming clear and one decode launch.
+struct DecRound { u32 first, count; };
+std::vector<DecRound> plan_rounds(std::vector<DecTab>& tabs, u64 region_words)
+{
+	std::vector<DecRound> rounds;
+	u64 top = 0; u32 first = 0;
+	for (u32 i = 0; i < tabs.size(); ++i)
+	{
+		const u64 w = (tabs[i].words + 31) & ~31ull;                  // 128-byte aligned tables
+		if (top + w > region_words && i > first) { rounds.push_back({first, i - first}); first = i; top = 0; }
+		tabs[i].off = top; top += w;
+	}
+	if (first < tabs.size()) rounds.push_back({first, (u32)tabs.size() - first});
+	return rounds;
 }
 
 int run_decode(dsrcgpu_handle* h, DecodeIO io)
@@ -873,6 +926,7 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 	prm.crc = h->set.calculate_crc32 ? 1u : 0u; prm.quality_offset = h->ds.quality_offset; prm.n_blocks = B;
 	prm.tag_flags = (u32)h->set.tag_preserve_flags; prm.plus_rep = h->ds.plus_repetition ? 1u : 0u; prm.color_space = h->ds.color_space ? 1u : 0u;
 	prm.serial_quality = getenv("DSRC_GPU_DEC_SERIAL") ? 1u : 0u;
+	const bool q_rc = prm.quality_order > 0, d_rc = prm.dna_order > 0;
 
 	std::vector<DecDesc> desc(B); std::vector<DecState> st(B);
 	memset(desc.data(), 0, sizeof(DecDesc) * B);
@@ -882,6 +936,7 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 		desc[b].in_off = io.offs[b]; desc[b].in_size = (u32)io.sizes[b];
 	}
 	const size_t o_desc = A.alloc(sizeof(DecDesc) * B), o_state = A.alloc(sizeof(DecState) * B);
+	const size_t o_qtabs = A.alloc(sizeof(DecTab) * B), o_dtabs = A.alloc(sizeof(DecTab) * B);
 	if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (decode, phase 1)");
 	DecDesc* d_desc = AP<DecDesc>(h, o_desc); DecState* d_state = AP<DecState>(h, o_state);
 	HIPCHK(hipEventRecord(h->ev[0], s));
@@ -890,7 +945,20 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(DecState) * B, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
 
-	// ---- layout: text, record tables, symbol scratch, tree pools, model-table slots ---------------------------------
+	// what the device says about the blocks so far (mid-pass and final)
+	auto check_blocks = [&](bool final) -> int
+	{
+		for (u32 b = 0; b < B; ++b)
+		{
+			const DecState& S = st[b];
+			if (S.err == DEC_ERR_TEXT) return fail(h, DSRCGPU_E_CAPACITY, "block %u: the decoded text does not fit the %u bytes reserved for it", b, desc[b].out_cap);
+			if (S.err) return fail(h, DSRCGPU_E_INPUT, "block %u cannot be decoded (error bits 0x%x: 1 truncated, 2 malformed, 4 text overflow, 8 undefined in the reference's decoder, 16 scratch)", b, S.err);
+			if (final && S.end_pos != desc[b].in_size) return fail(h, DSRCGPU_E_INPUT, "block %u: %u of %u bytes consumed (wrong settings for this archive?)", b, S.end_pos, desc[b].in_size);
+		}
+		return DSRCGPU_OK;
+	};
+
+	// ---- layout: text, record tables, symbol scratch, tree pools ---------------------------------------------------------
 	u64 text_total = 0, recs = 0, dbytes = 0, nodes = 0, fbytes = 0; u32 max_recs = 1;
 	for (u32 b = 0; b < B; ++b)
 	{
@@ -914,11 +982,6 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 	rp.kept = AP<u16>(h, A.alloc(recs * 2)); rp.trunc = nullptr;
 	rp.q_off = nullptr; rp.d_off = AP<u32>(h, A.alloc(recs * 4));
 	const size_t o_d = A.alloc(dbytes + 64), o_nodes = A.alloc(nodes * 4 + 64), o_fld = A.alloc(fbytes + 64);
-	prm.table_words = (u32)dec_table_words(h->set);
-	// Model tables: one slot per block in flight.  A stream advances one symbol per dependent row read (~1 us), so the
-	// rate of the range-decoded levels is (slots in flight) / latency: the slots take what HBM is left
-	const u32 slots = (u32)std::max<u64>(1, std::min<u64>(B, dec_table_budget(h, A.top) / ((u64)prm.table_words * 4)));
-	const size_t o_tab = A.alloc((size_t)slots * prm.table_words * 4 + 64);
 	u8* d_out = io.d_out;
 	size_t o_out = 0;
 	if (!d_out) o_out = A.alloc(text_total + 64);
@@ -932,8 +995,109 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 
 	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(DecDesc) * B, hipMemcpyHostToDevice, s));
 	hipLaunchKernelGGL(k_dec_tags, dim3(B), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), AP<u8>(h, o_fld), prm); KCHK();
-	if (prm.quality_order == 0) { hipLaunchKernelGGL(k_dec_qhuff, dim3(B), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), prm); KCHK(); }
-	hipLaunchKernelGGL(k_dec_streams, dim3(slots), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), AP<u8>(h, o_d), AP<u32>(h, o_tab), prm); KCHK();
+	if (!q_rc) { hipLaunchKernelGGL(k_dec_qhuff, dim3(B), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), prm); KCHK(); }
+
+	if (prm.serial_quality)
+	{	// the one-lane decoder: a slot of the worst-case size per wave, the waves loop over the blocks
+		prm.table_words = (u32)dec_table_words(h->set);
+		const u32 slots = (u32)std::max<u64>(1, std::min<u64>(B, dec_table_budget(h) / ((u64)prm.table_words * 4)));
+		const int rc = ensure_dec_tables(h, (u64)slots * prm.table_words * 4 + 64);
+		if (rc) return rc;
+		hipLaunchKernelGGL(k_dec_streams, dim3(slots), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), AP<u8>(h, o_d), h->dec_tables, prm); KCHK();
+	}
+	else
+	{
+		// A stream advances one symbol per dependent row read, so the rate of the range-decoded levels is (chains in flight) /
+		// latency: every block of the batch gets its own table, sized from the scheme byte of its stream
+		const u64 budget_words = dec_table_budget(h) / 4;
+		u64 region_words = 0;
+		std::vector<DecTab> qtabs;
+		if (q_rc)
+		{
+			HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(DecState) * B, hipMemcpyDeviceToHost, s));
+			HIPCHK(hipStreamSynchronize(s));
+			const int rc = check_blocks(false);
+			if (rc) return rc;
+			u64 sum = 0;
+			for (u32 b = 0; b < B; ++b)
+			{
+				DecTab t; t.block = b; t.off = 0;
+				t.words = q_table_words(prm.quality_order, prm.lossy != 0, st[b].q_scheme, st[b].q_cnt, &t.n);
+				sum += (t.words + 31) & ~31ull;
+				qtabs.push_back(t);
+			}
+			region_words = sum;
+		}
+		if (d_rc) region_words = std::max<u64>(region_words, (u64)B * ((d_table_words(prm.dna_order, 0) + 31) & ~31ull));
+		u64 biggest = 0;
+		for (const DecTab& t : qtabs) biggest = std::max<u64>(biggest, (t.words + 31) & ~31ull);
+		region_words = std::max<u64>(std::min<u64>(region_words, budget_words), biggest);
+		if (region_words) { const int rc = ensure_dec_tables(h, region_words * 4); if (rc) return rc; }
+		region_words = h->dec_tables_cap / 4;
+		auto fill_round = [&](const DecTab* d_tabs, const std::vector<DecTab>& tabs, const DecRound& r)
+		{
+			u64 mx = 0;
+			for (u32 i = 0; i < r.count; ++i) mx = std::max(mx, tabs[r.first + i].words);
+			const u32 gx = (u32)std::max<u64>(1, std::min<u64>(1024, mx / 4 / (256 * 4)));
+			hipLaunchKernelGGL(k_dec_fill, dim3(gx, r.count), dim3(256), 0, s, h->dec_tables, d_tabs + r.first);
+		};
+		if (q_rc)
+		{
+			const std::vector<DecRound> rounds = plan_rounds(qtabs, region_words);
+			DecTab* d_tabs = AP<DecTab>(h, o_qtabs);
+			HIPCHK(hipMemcpyAsync(d_tabs, qtabs.data(), sizeof(DecTab) * qtabs.size(), hipMemcpyHostToDevice, s));
+			for (const DecRound& r : rounds)
+			{
+				fill_round(d_tabs, qtabs, r); KCHK();
+				hipLaunchKernelGGL(k_dec_qrc, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, d_tabs + r.first, rp, d_out, h->dec_tables, prm); KCHK();
+			}
+		}
+		hipLaunchKernelGGL(k_dec_dhead, dim3((B + 63) / 64), dim3(64), 0, s, io.d_in, d_desc, d_state, prm); KCHK();
+		bool any_plain = !d_rc;
+		if (d_rc)
+		{
+			HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(DecState) * B, hipMemcpyDeviceToHost, s));
+			HIPCHK(hipStreamSynchronize(s));
+			const int rc = check_blocks(false);
+			if (rc) return rc;
+			std::vector<DecTab> dtabs;
+			u32 n4 = 0;
+			for (u32 pass = 0; pass < 2; ++pass)                      // the 4-symbol blocks first, then the 8-symbol ones
+			{
+				for (u32 b = 0; b < B; ++b)
+				{
+					if (st[b].d_scheme == 255) { any_plain = true; continue; }
+					if (st[b].d_scheme != pass) continue;
+					DecTab t; t.block = b; t.off = 0; t.n = 0; t.words = d_table_words(prm.dna_order, pass);
+					dtabs.push_back(t);
+				}
+				if (pass == 0) n4 = (u32)dtabs.size();
+			}
+			if (n4 < dtabs.size())
+			{	// 8-symbol tables are larger than what was reserved from the 4-symbol size
+				const u64 w8 = (d_table_words(prm.dna_order, 1) + 31) & ~31ull;
+				const u64 want = std::max<u64>(std::min<u64>((u64)(dtabs.size() - n4) * w8, budget_words), w8);
+				if (want > region_words) { const int rc2 = ensure_dec_tables(h, want * 4); if (rc2) return rc2; region_words = h->dec_tables_cap / 4; }
+			}
+			DecTab* d_tabs = AP<DecTab>(h, o_dtabs);
+			std::vector<DecTab> t4(dtabs.begin(), dtabs.begin() + n4), t8(dtabs.begin() + n4, dtabs.end());
+			const std::vector<DecRound> r4 = plan_rounds(t4, region_words), r8 = plan_rounds(t8, region_words);
+			std::copy(t4.begin(), t4.end(), dtabs.begin()); std::copy(t8.begin(), t8.end(), dtabs.begin() + n4);
+			if (!dtabs.empty()) HIPCHK(hipMemcpyAsync(d_tabs, dtabs.data(), sizeof(DecTab) * dtabs.size(), hipMemcpyHostToDevice, s));
+			for (const DecRound& r : r4)
+			{
+				fill_round(d_tabs, dtabs, r); KCHK();
+				hipLaunchKernelGGL(k_dec_dnarc<4>, dim3((r.count + 63) / 64), dim3(64), 0, s, io.d_in, d_desc, d_state, d_tabs + r.first, r.count, AP<u8>(h, o_d), h->dec_tables, prm); KCHK();
+			}
+			for (const DecRound& r8r : r8)
+			{
+				const DecRound r{r8r.first + n4, r8r.count};
+				fill_round(d_tabs, dtabs, r); KCHK();
+				hipLaunchKernelGGL(k_dec_dnarc<8>, dim3((r.count + 63) / 64), dim3(64), 0, s, io.d_in, d_desc, d_state, d_tabs + r.first, r.count, AP<u8>(h, o_d), h->dec_tables, prm); KCHK();
+			}
+		}
+		if (any_plain) { hipLaunchKernelGGL(k_dec_dna0, dim3(B), dim3(64), 0, s, io.d_in, d_desc, d_state, AP<u32>(h, o_nodes), AP<u8>(h, o_d), prm); KCHK(); }
+	}
 	{
 		const u32 gx = std::max(1u, std::min(64u, (max_recs + 4 * WAVES - 1) / (4 * WAVES)));
 		hipLaunchKernelGGL(k_dec_layout, dim3(gx, B), dim3(WG), 0, s, d_desc, d_state, rp, d_out, AP<u8>(h, o_d), prm); KCHK();
@@ -943,12 +1107,13 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 	HIPCHK(hipEventRecord(h->ev[1], s));
 	if (io.host_out) HIPCHK(hipMemcpyAsync(io.host_out, d_out, text_total, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
+	{
+		const int rc = check_blocks(true);
+		if (rc) return rc;
+	}
 	for (u32 b = 0; b < B; ++b)
 	{
 		const DecState& S = st[b];
-		if (S.err == DEC_ERR_TEXT) return fail(h, DSRCGPU_E_CAPACITY, "block %u: the decoded text does not fit the %u bytes reserved for it", b, desc[b].out_cap);
-		if (S.err) return fail(h, DSRCGPU_E_INPUT, "block %u cannot be decoded (error bits 0x%x: 1 truncated, 2 malformed, 4 text overflow, 8 undefined in the reference's decoder, 16 scratch)", b, S.err);
-		if (S.end_pos != desc[b].in_size) return fail(h, DSRCGPU_E_INPUT, "block %u: %u of %u bytes consumed (wrong settings for this archive?)", b, S.end_pos, desc[b].in_size);
 		io.out_offs[b] = desc[b].out_off; io.out_sizes[b] = S.text_bytes;
 		if (io.crc_ok)
 		{
@@ -969,11 +1134,10 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 
 size_t estimate_decode_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
 {
+	(void)h;
 	size_t tot = 0;
 	for (u32 i = 0; i < n; ++i) tot += (size_t)sizes[i] + 4096;
-	const u64 tw = dec_table_words(h->set) * 4;
-	const size_t other = tot * 12 + (size_t)n * (2u << 20) + (16u << 20);
-	return other + (size_t)std::min<u64>(dec_table_budget(h, other), tw * n);
+	return tot * 12 + (size_t)n * (2u << 20) + (16u << 20);
 }
 
 // The reference's compressing worker decodes every block it has just written and compares the checksums
@@ -1105,6 +1269,7 @@ void dsrcgpu_destroy(dsrcgpu_handle* h)
 	}
 	for (QBatch& b : h->qb) { if (b.in) hipHostFree(b.in); if (b.out) hipHostFree(b.out); }
 	if (h->arena.base) hipFree(h->arena.base);
+	if (h->dec_tables) hipFree(h->dec_tables);
 	if (h->d_crc_tab) hipFree(h->d_crc_tab);
 	for (int i = 0; i < 5; ++i) if (h->ev[i]) hipEventDestroy(h->ev[i]);
 	for (hipEvent_t e : h->stage_ev) hipEventDestroy(e);
@@ -1362,6 +1527,7 @@ int dsrcgpu_selftest(dsrcgpu_handle* h, uint32_t* mismatches)
 	HIPCHK(hipMalloc((void**)&d_bad, 4));
 	HIPCHK(hipMemsetAsync(d_bad, 0, 4, h->stream));
 	hipLaunchKernelGGL(k_selftest, dim3(256), dim3(256), 0, h->stream, d_bad); KCHK();
+	hipLaunchKernelGGL(k_selftest_dec, dim3(256), dim3(256), 0, h->stream, d_bad); KCHK();      // the decoder's division (k_dec_rc.h)
 	{	// the property k_sort's atomic ranking stands on (dsrcgpu_create runs the same test to choose the variant); a violation
 		// counts as a mismatch here so that the test-suite notices a device on which the ballot variant is in use
 		u32* d_ord = nullptr; u32 ord = 0;

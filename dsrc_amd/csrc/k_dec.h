@@ -59,7 +59,8 @@ struct DecState         // device -> host, and device scratch between the stages
 	u32 text_bytes;                         // laid-out text
 	u32 q_total, d_total;
 	u32 q_scheme, d_scheme;
-	u32 pad[3];
+	u32 q_cnt;                              // order-context quality: symbols present (the alphabet's presence bitmap)
+	u32 pad[2];
 };
 
 struct DecField
@@ -583,6 +584,24 @@ __global__ void __launch_bounds__(64) k_dec_tags(const u8* in, const DecDesc* de
 	}
 	bs_align(s);
 	S->qua_pos = bs_pos(s); S->text_bytes = pos; S->q_total = q_total;
+	// the scheme byte of the quality stream (IQualityModelerProxy::Decode, src/QualityModelerProxy.h:59-69): the host sizes the
+	// model table of an order-context scheme from it
+	if (!s.err && !(prm.quality_order > 0 && prm.lossy))
+	{
+		BitSrc t = s;
+		const u32 sch = bs_byte(t);
+		S->q_scheme = sch;
+		if (t.err || (prm.quality_order == 0 ? sch > 2 : sch > 7)) s.err |= t.err | DEC_ERR_FORMAT;
+		if (prm.quality_order > 0 && !s.err)
+		{	// TTranslationalQualityEncoder::Read (src/QualityEncoder.h:344-357): 256 presence bits; the decoder's table has
+			// one row per context made of PRESENT symbols
+			bs_align(t);
+			u32 cnt = 0;
+			for (u32 i = 0; i < 8; ++i) cnt += (u32)__popc(bs_word(t));
+			S->q_cnt = cnt;
+			if (t.err || cnt == 0) s.err |= t.err | DEC_ERR_FORMAT;
+		}
+	}
 	S->err |= s.err;
 }
 
@@ -623,7 +642,7 @@ __device__ __forceinline__ void qua_order_decode(BitSrc& s, u16* tab, u32 ord, u
 		for (u32 j = 0; j < ql; ++j)
 		{
 			const u32 pctx = j * rescale / ql;
-			const u64 h = ((hash & hash_mask) << abits) | pctx;
+			const u64 h = (hash & hash_mask) * rescale + pctx;       // dense: the table is the decoder's own (the reference shifts by abits)
 			const u32 c = rd_symbol<N>(rd, s, tab + h * N);
 			const u32 qv = translate ? translate[c] : c;
 			q[j] = (u8)qv;
@@ -645,91 +664,6 @@ __device__ __forceinline__ u32 dec_wave_scan(u32 v) { return wave_incl_scan_dpp(
 __device__ __forceinline__ u32 dec_readlane(u32 v, u32 l)
 {
 	return (u32)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)l));
-}
-
-// The same decoder with the WAVE on one stream (N <= 64): lane i holds counter i of the current row, so the row is one
-// coalesced load, its total and the cumulative frequencies one prefix scan, the symbol search one ballot.  What stays
-// serial per symbol is a dependent row read (~0.4 us from HBM) plus ~100 instructions, instead of ~400 instructions that
-// one lane needs for a 32-counter row.  Counter traffic goes through workgroup-scope atomics (plain loads / stores that
-// are coherent within the CU): lane j reads counters that lane j' wrote a few symbols earlier.
-template <u32 N>
-__device__ __forceinline__ void qua_order_decode_wave(BitSrc& s, u16* tab, u32 ord, u32 rescale, const u8* translate, u32 lossy,
-									  const DecDesc& d, DecState* S, RecPools rp, u8* text)
-{
-	const u32 lane = lane_id();
-	const u32 abits = dec_int_log2(N);
-	const u64 sym_mask = ((u64)1 << abits) - 1;
-	const u32 bits_lo = (ord / 2) * abits, bits_hi = (ord / 2 + 1) * abits;
-	const u64 lo_mask = bits_lo ? (((u64)1 << bits_lo) - 1) : 0;
-	const u64 hi_mask = ((u64)1 << bits_hi) - 1;
-	const u64 swap_mask = lo_mask | ~hi_mask;
-	const u64 hash_mask = ((u64)1 << (ord * abits)) - 1;
-	u64 hash = 0, sym_buf = 0;
-	RangeDec rd; rd_start(rd, s);
-	u32 d_total = 0;
-	const u32 n_recs = S->n_recs;
-	for (u32 k = 0; k < n_recs && !s.err; ++k)
-	{
-		const u64 g = (u64)d.rec_base + k;
-		const u32 ql = rp.len[g];
-		u8* q = text + rp.qual_off[g];
-		u32 ncount = 0, pctx = 0, rem = 0;            // pctx = j * rescale / ql, kept incrementally
-		for (u32 j = 0; j < ql; ++j)
-		{
-			const u64 h = ((hash & hash_mask) << abits) | pctx;
-			u16* row = tab + h * N;
-			u32 c = lane < N ? (u32)__hip_atomic_load(row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-			u32 incl = dec_wave_scan(c);
-			u32 acc = dec_readlane(incl, N - 1);
-			bool rescaled = false;
-			if (acc >= (1u << 16) - N * 2)
-			{	// TSymbolCoderRC::Rescale: the halved counters stay in the row
-				c -= c >> 1;
-				incl = dec_wave_scan(c);
-				acc = dec_readlane(incl, N - 1);
-				rescaled = true;
-			}
-			rd.range /= acc;
-			if (rd.range == 0) { s.err |= DEC_ERR_FORMAT; rd.range = 1; }
-			const u32 cul = div_u64_u32(rd.buffer, rd.range);
-			const u64 m = __ballot(lane < N && incl > cul);
-			u32 idx;
-			if (m == 0) { s.err |= DEC_ERR_FORMAT; idx = N - 1; }     // the reference walks off the row here
-			else idx = (u32)__ffsll((long long)m) - 1u;
-			const u32 f = dec_readlane(c, idx);
-			const u32 hi = dec_readlane(incl, idx) - f;
-			const u32 rr = hi * rd.range;                          // uint32 product
-			rd.buffer -= rr; rd.low += rr;
-			rd.range *= f;
-			while (rd.range <= 0x00FFFFFFu)
-			{
-				if ((rd.low ^ (rd.low + rd.range)) & 0xFF00000000000000ull)
-				{
-					const u32 lo = (u32)rd.low;
-					rd.range = (lo | 0x00FFFFFFu) - lo;
-				}
-				rd.buffer = (rd.buffer << 8) + rd_byte(rd, s);
-				rd.low <<= 8; rd.range <<= 8;
-				if (rd.range == 0) { s.err |= DEC_ERR_FORMAT; rd.range = 0xFFFFFFFFu; break; }
-			}
-			if (lane == idx) __hip_atomic_store(row + lane, (u16)(c + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			else if (rescaled && lane < N) __hip_atomic_store(row + lane, (u16)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			const u32 qv = translate ? translate[idx] : idx;
-			if (lane == 0) q[j] = (u8)qv;
-			ncount += q_special(qv, lossy) ? 1u : 0u;
-			hash <<= abits;
-			const u64 next_buf = (hash >> bits_lo) & sym_mask;
-			const u64 swp = (next_buf + sym_buf) / 2;
-			hash &= swap_mask; hash |= swp << bits_lo; hash |= idx;
-			sym_buf = next_buf;
-			rem += rescale;
-			while (rem >= ql) { rem -= ql; ++pctx; }
-		}
-		if (lane == 0) { rp.kept[g] = (u16)(ql - ncount); rp.d_off[g] = d_total; }
-		d_total += ql - ncount;
-	}
-	rd_finish(rd, s);
-	if (lane == 0) S->d_total = d_total;
 }
 
 // rd_symbol on a row held in registers (the caller stores it back): *rescaled tells whether every counter changed
@@ -1037,6 +971,10 @@ __global__ void __launch_bounds__(64) k_dec_qhuff(const u8* in, const DecDesc* d
 	S->err |= s.err;
 }
 
+// The ONE-LANE form of the range-decoded levels: wave per model-table slot looping over blocks, lane 0 walks the quality stream
+// and then the DNA stream with the reference's own loops (qua_order_decode, dna_order_decode), the wave clears the slot's table.
+// It is what DSRC_GPU_DEC_SERIAL=1 runs (an independent second implementation for the tests, and quick on the CPU emulator);
+// the product path is k_dec_qrc / k_dec_dnarc / k_dec_dna0 (k_dec_rc.h).
 __global__ void __launch_bounds__(64) k_dec_streams(const u8* in, const DecDesc* desc, DecState* st, RecPools rp, u8* out, u32* pool,
 													 u8* d_stream, u32* tables, DecParams prm)
 {
@@ -1062,12 +1000,11 @@ __global__ void __launch_bounds__(64) k_dec_streams(const u8* in, const DecDesc*
 		if (threadIdx.x == 0 && q_elsewhere) s.bit = (u64)S->dna_pos * 8;
 		if (threadIdx.x == 0 && !q_elsewhere)
 		{
-			if (qo > 0 && lossy) q_rc = true;
+			if (lossy) q_rc = true;
 			else
 			{
 				q_scheme = bs_byte(s);
-				if (qo == 0) { if (q_scheme > 2) s.err |= DEC_ERR_FORMAT; }
-				else if (q_scheme > 7) s.err |= DEC_ERR_FORMAT;
+				if (q_scheme > 7) s.err |= DEC_ERR_FORMAT;
 				else
 				{
 					const u32 sc = q_scheme & 3u;
@@ -1083,47 +1020,25 @@ __global__ void __launch_bounds__(64) k_dec_streams(const u8* in, const DecDesc*
 					bs_align(s);
 				}
 			}
-			s_flag = (q_rc && !s.err) ? (qN | (q_ord << 8)) : 0u;
+			s_flag = (q_rc && !s.err) ? (qN | (q_ord << 8) | (q_rescale << 16)) : 0u;
 		}
 		if (threadIdx.x == 0 && q_elsewhere) s_flag = 0;
-		if (threadIdx.x == 0) { s_par[0] = q_rescale; s_par[1] = q_translate ? 1u : 0u; s_par[2] = (u32)s.bit; s_par[3] = (u32)(s.bit >> 32); s_par[4] = q_scheme; }
 		__syncthreads();
 		const u32 flag = s_flag;
-		bool q_done = false;
 		if (flag)
 		{
-			const u32 nn = flag & 0xFFu, ord = flag >> 8;
+			const u32 nn = flag & 0xFFu, ord = (flag >> 8) & 0xFFu, resc = flag >> 16;
 			u32 ab = 0; for (u32 t = nn; t > 1; t >>= 1) ++ab;
-			const u64 words = ((u64)1 << (ab * (ord + 1))) * nn / 2;
+			const u64 words = ((u64)1 << (ab * ord)) * resc * nn / 2;
 			if (words > prm.table_words) { if (threadIdx.x == 0) s.err |= DEC_ERR_POOL; }
-			else
-			{
-				table_fill(table, words);
-				__syncthreads();
-				if (nn <= 64 && !prm.serial_quality)
-				{	// the whole wave decodes the quality stream
-					s.bit = ((u64)s_par[3] << 32) | s_par[2];
-					const u8* tr = s_par[1] ? s_sym : nullptr;
-					const u32 resc = s_par[0];
-					switch (nn)
-					{
-					case 8:   qua_order_decode_wave<8>(s, (u16*)table, ord, resc, tr, lossy, d, S, rp, text); break;
-					case 16:  qua_order_decode_wave<16>(s, (u16*)table, ord, resc, tr, lossy, d, S, rp, text); break;
-					case 32:  qua_order_decode_wave<32>(s, (u16*)table, ord, resc, tr, lossy, d, S, rp, text); break;
-					default:  qua_order_decode_wave<64>(s, (u16*)table, ord, resc, tr, lossy, d, S, rp, text); break;
-					}
-					if (threadIdx.x == 0) S->q_scheme = s_par[4];
-					q_done = true;
-				}
-			}
+			else table_fill(table, words);
 		}
 		__syncthreads();
-		if (threadIdx.x == 0 && !s.err && q_done) S->dna_pos = bs_pos(s);
-		if (threadIdx.x == 0 && !s.err && !q_done && !q_elsewhere)
+		if (threadIdx.x == 0 && !s.err && !q_elsewhere)
 		{
 			S->q_scheme = q_scheme;
 			if (q_rc)
-			{	// 128-symbol alphabets (two counters per lane would be needed), or the one-lane decoder was asked for
+			{
 				const u8* tr = q_translate ? s_sym : nullptr;
 				switch (qN)
 				{

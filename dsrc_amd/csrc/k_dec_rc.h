@@ -1,0 +1,626 @@
+// The range-decoded levels of the decompressor (-q1/-q2 quality, -d1..-d3 DNA), laid out for LATENCY.
+// Replaces TQualityOrderModeler::Decode + T*QualityEncoder::Decode + TQualityModelExt::DecodeSymbol
+// (src/QualityOrderModeler.h:49-65, src/QualityEncoder.h:77-143,248-263,306-326), TDnaRCOrderModeler::Decode
+// (src/DnaModelerRCO.h:62-79), TSymbolCoderRC<N>::DecodeSymbol (src/SymbolCoderRC.h:50-91) and RangeDecoder
+// (src/RangeCoder.h:90-142).
+//
+// A decoded stream advances one symbol per DEPENDENT row read: the address of the next model row is a function of the symbol
+// just decoded.  The rate of a pass is (chains in flight) / (time per symbol), so everything here is about what sits between
+// "row arrives" and "next row requested":
+//   * the model table is PRIVATE to the decoder, so its layout is ours: rows are dense (hash * rescale + pctx: every row is
+//     reachable), sized per block from the block's scheme, cleared by a streaming kernel -- and a quality row holds INCLUSIVE
+//     CUMULATIVE counts, so neither a prefix scan nor the row total has to be computed when it arrives;
+//   * the symbol is found without dividing by the range: incl[i] * r > buffer  <=>  incl[i] > floor(buffer / r), one 64-bit
+//     multiply per lane and a ballot; r = floor(range / total) is one f64 reciprocal with a Newton step, exact (dec_div);
+//   * Rescale() is applied when a row is WRITTEN (the reference applies it at the next visit; nothing else reads the row in
+//     between), so a row is ready when it arrives;
+//   * the next row is requested as soon as the symbol index is known; the coder's state, the counter update, the output byte and
+//     the context bookkeeping of the next symbol all run in the shadow of that request.
+// DNA (4 or 8 counters per row) is decoded ONE LANE PER BLOCK, 64 blocks per wave: the N candidate rows of the next symbol are
+// consecutive and are requested before this symbol is decoded.  (Touching the line of the 16 candidates of the symbol after that
+// one symbol earlier does not work on this machine: a wave's vector loads return in order, so the younger request that hits
+// could not be consumed before the older one that misses.)
+#pragma once
+#include "k_dec.h"
+
+// every vector-memory request of this wave has completed: s_waitcnt vmcnt(0) (gfx9 encoding, expcnt / lgkmcnt left at their maxima)
+__device__ __forceinline__ void dec_vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+struct DecTab            // one model table of one block in the table region (host -> device)
+{
+	u64 off;             // u32 words from the start of the region
+	u64 words;           // u32 words
+	u32 block;           // block index in the batch
+	u32 n;               // quality: alphabet size of the cumulative fill pattern (row = 1, 2, .., n); 0: all counters 1 (DNA, serial decoder)
+};
+
+// ---- streaming clear of the model tables of one round --------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_dec_fill(u32* tables, const DecTab* tabs)
+{
+	const DecTab t = tabs[blockIdx.y];
+	uint4* dst = (uint4*)(tables + t.off);
+	const u64 n16 = t.words / 4;                             // table sizes are multiples of 16 bytes
+	const u32 n = t.n;
+	for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (u64)gridDim.x * blockDim.x)
+	{
+		uint4 v;
+		if (n == 0) { v.x = v.y = v.z = v.w = 0x00010001u; }
+		else
+		{	// eight u16 elements e0 .. e0 + 7 of a row of n (n >= 8, a power of two): value = index in the row + 1
+			const u32 e0 = (u32)((i * 8) & (u64)(n - 1)) + 1;
+			v.x = e0 | ((e0 + 1) << 16); v.y = (e0 + 2) | ((e0 + 3) << 16); v.z = (e0 + 4) | ((e0 + 5) << 16); v.w = (e0 + 6) | ((e0 + 7) << 16);
+		}
+		dst[i] = v;
+	}
+}
+
+// ---- exact floor(n / d) for n < 2^32, 1 <= d < 2^16 ------------------------------------------------------------------------
+// x1 = one Newton step on the hardware reciprocal (relative error e0 <= 2^-22 -> e1 <= 2^-43); nf = n * (1 + 2^-40), prepared
+// when n becomes known (off the critical path).  nf * x1 = (n / d) * (1 + 2^-40) * (1 + e1) lies in [n / d, n / d * (1 + 2^-39)]:
+// it cannot fall below n / d (the bias outweighs e1 and the roundings of 2^-53), and it cannot reach the next integer, which is
+// at least 1 / d away while n / d * 2^-39 < 2^-7 / d.  So the truncation is the quotient.  Checked for every d on the device by
+// dsrcgpu_selftest (k_selftest_dec), like the encoder's reciprocal.
+__device__ __forceinline__ double dec_rcp(double x)
+{
+#ifdef DSRC_EMU_BUILD
+	return 1.0 / x;
+#else
+	return __builtin_amdgcn_rcp(x);
+#endif
+}
+__device__ __forceinline__ double dec_div_prep(u32 n) { return (double)n * (1.0 + 0x1p-40); }
+__device__ __forceinline__ u32 dec_div(double nf, u32 d)
+{
+	const double df = (double)d;
+	double x = dec_rcp(df);
+	x = __builtin_fma(__builtin_fma(-df, x, 1.0), x, x);
+	return (u32)(nf * x);
+}
+
+__global__ void __launch_bounds__(256) k_selftest_dec(u32* bad)
+{
+	const u32 d = blockIdx.x * blockDim.x + threadIdx.x + 1;
+	if (d >= 65536) return;
+	u32 wrong = 0;
+	for (u32 k = 0; k < 96; ++k)
+	{
+		// multiples of d, the values just below them, and a spread of others; the largest quotients included
+		const u32 q = k < 32 ? (0xFFFFFFFFu / d) >> k : (k * 2654435761u) % (0xFFFFFFFFu / d + 1u);
+		const u64 base = (u64)q * d;
+		const u32 ns[3] = {(u32)base, base ? (u32)(base - 1) : 0u, (u32)(base + d - 1 < 0xFFFFFFFFull ? base + d - 1 : 0xFFFFFFFFull)};
+		for (u32 j = 0; j < 3; ++j)
+			if (dec_div(dec_div_prep(ns[j]), d) != ns[j] / d) wrong = 1;
+	}
+	if (wrong) atomicAdd(bad, 1u);
+}
+
+// ---- the coder's bytes for a wave-uniform stream: scalar loads -----------------------------------------------------------------
+// The block is read-only while the pass runs, so its bytes can come through the scalar cache (s_load_dword: constant address
+// space), whose loads return out of order and on their own counter -- a vector load here would have to be waited for together
+// with the row request that is in flight (a wave's vector loads return in order).  Two dwords are kept requested ahead; the
+// index is clamped to the dword that holds the block's last byte, so nothing outside the block's dwords is touched.
+#ifdef DSRC_EMU_BUILD
+#define CONST_AS
+#else
+#define CONST_AS __attribute__((address_space(4)))
+#endif
+struct UWin { const CONST_AS u32* p4; u32 cw, left, q0, q1, nextw, lastw, origin; };
+
+__device__ __forceinline__ u32 uw_bswap(u32 x) { return __builtin_bswap32(x); }
+__device__ __forceinline__ void uw_start(UWin& w, const BitSrc& s)
+{
+	const u64 a = (u64)s.p, x = a + (s.bit >> 3);
+	const u64 w0 = x & ~3ull;
+	const u32 mis = (u32)(x & 3ull);
+	w.p4 = (const CONST_AS u32*)w0;
+	w.lastw = (u32)((((a + s.size - 1) & ~3ull) - w0) >> 2);
+	w.origin = (u32)(s.bit >> 3) - mis;                             // block position of byte 0 of dword 0
+	w.cw = uw_bswap(w.p4[0]) << (8 * mis); w.left = 4 - mis;
+	w.q0 = w.p4[1 < w.lastw ? 1 : w.lastw]; w.q1 = w.p4[2 < w.lastw ? 2 : w.lastw];
+	w.nextw = 3;
+}
+__device__ __forceinline__ u32 uw_byte(UWin& w)
+{
+	if (w.left == 0)
+	{
+		w.cw = uw_bswap(w.q0); w.q0 = w.q1;
+		w.q1 = w.p4[w.nextw < w.lastw ? w.nextw : w.lastw];
+		++w.nextw; w.left = 4;
+	}
+	const u32 b = w.cw >> 24;
+	w.cw <<= 8; --w.left;
+	return b;
+}
+// bytes of the block consumed so far, as a position inside the block
+__device__ __forceinline__ u64 uw_pos(const UWin& w) { return (u64)w.origin + (u64)(w.nextw - 2) * 4 - w.left; }
+
+// ---- quality: the wave on one stream ----------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 qrc_readlane(u32 v, u32 l)
+{
+	return (u32)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)l));
+}
+
+// element i of a row held one (N <= 64) or two (N == 128: low half = even element) per lane
+template <u32 CPL> __device__ __forceinline__ u32 qrc_elem(u32 cur, u32 i)
+{
+	if (CPL == 1) return qrc_readlane(cur, i);
+	const u32 w = qrc_readlane(cur, i >> 1);
+	return (i & 1u) ? w >> 16 : w & 0xFFFFu;
+}
+
+template <u32 N>
+__device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 rescale, u32 cnt, bool translate, const u8* sym_tab, u32 lossy,
+										   const DecDesc& d, DecState* S, RecPools rp, u8* text)
+{
+	constexpr u32 CPL = N > 64 ? 2u : 1u;
+	constexpr u32 LANES = N / CPL;
+	constexpr u32 LIM = (1u << 16) - 2 * N;
+	const u32 lane = lane_id();
+	const bool live = lane < LANES;
+	const u32 abits = dec_int_log2(N);
+	const u32 sym_mask = N - 1;
+	const u32 bits_lo = (ord / 2) * abits, bits_hi = (ord / 2 + 1) * abits;
+	const u32 hash_mask = (1u << (ord * abits)) - 1u;                   // ord * abits <= 21 for every scheme
+	const u32 swap_mask = ((1u << bits_lo) - 1u) | ~((1u << bits_hi) - 1u);
+	u16* tab16 = (u16*)table;
+	// symbol value of counter i, in the lane that holds counter i (two per lane when N == 128)
+	u32 tr_v = 0;
+	if (translate) tr_v = CPL == 1 ? (live ? (u32)sym_tab[lane] : 0u) : ((u32)sym_tab[2 * lane] | ((u32)sym_tab[2 * lane + 1] << 16));
+
+	const u64 g0 = d.rec_base;
+	const u32 n_recs = S->n_recs;
+	u32 k = 0, d_total = 0, err = 0;
+	u32 ql = 0;
+	for (; k < n_recs; ++k)
+	{	// records without a quality line code nothing
+		ql = rp.len[g0 + k];
+		if (ql) break;
+		if (lane == 0) { rp.kept[g0 + k] = 0; rp.d_off[g0 + k] = d_total; }
+	}
+	// RangeDecoder::Start (src/RangeCoder.h:97-106): eight bytes into the buffer
+	struct { u64 low, buffer; u32 range; } rd;
+	UWin win; uw_start(win, s);
+	rd.low = 0; rd.range = 0xFFFFFFFFu; rd.buffer = 0;
+	for (u32 i = 0; i < 8; ++i) rd.buffer = (rd.buffer << 8) | uw_byte(win);
+	if (k < n_recs)
+	{
+		u8* q = text + rp.qual_off[g0 + k];
+		u32 hash = 0, sym_buf = 0, j = 0, pctx = 0, rem = 0, ncount = 0, mine = 0;
+		u32 ri = 0;                                                   // row of the symbol being decoded: (hash & mask) * rescale + pctx
+		// this lane's element(s) of that row; row 0 of a fresh table is 1, 2, .., N (no load: a request pending at the loop's entry would
+		// make the compiler's wait at the top of the loop cover the stores of every later iteration as well)
+		u32 cur = !live ? 0u : CPL == 1 ? lane + 1 : (2 * lane + 1) | ((2 * lane + 2) << 16);
+		double nf = dec_div_prep(rd.range);
+		dec_vm_drain();
+		for (;;)
+		{
+			// ---- independent of the row: where the next symbol's row is, up to the symbol itself ------------------------
+			const bool rec_end = j + 1 == ql;
+			u32 pn = 0, rem2 = 0;
+			if (!rec_end) { pn = pctx; rem2 = rem + rescale; while (rem2 >= ql) { rem2 -= ql; ++pn; } }
+			const u32 h2 = hash << abits;
+			const u32 nb = (h2 >> bits_lo) & sym_mask;
+			const u32 hpre = (h2 & swap_mask) | (((nb + sym_buf) >> 1) << bits_lo);      // the hash after this symbol, its low slot still empty
+			const u32 base_next = (hpre & hash_mask) * rescale + pn;
+
+			// ---- the row has arrived: symbol index ---------------------------------------------------------------------
+			const u32 total = qrc_elem<CPL>(cur, N - 1);
+			u32 r = dec_div(nf, total);
+			if (r == 0) { err |= DEC_ERR_FORMAT; r = 1; }
+			u32 idx;
+			{
+				const u32 e_hi = CPL == 1 ? cur : cur >> 16, e_lo = cur & 0xFFFFu;
+				u64 m = __ballot(live && (u64)e_hi * r > rd.buffer);
+				u64 m0 = CPL == 2 ? __ballot(live && (u64)e_lo * r > rd.buffer) : 0ull;
+				if (m == 0)
+				{	// buffer >= total * r: not a stream the encoder writes; the reference compares with the TRUNCATED quotient
+					const u32 cul = div_u64_u32(rd.buffer, r);
+					m = __ballot(live && e_hi > cul);
+					if (CPL == 2) m0 = __ballot(live && e_lo > cul);
+				}
+				if (m == 0) { err |= DEC_ERR_FORMAT; idx = N - 1; }          // the reference walks off the row here
+				else
+				{
+					const u32 l = (u32)__ffsll((long long)m) - 1u;
+					idx = CPL == 1 ? l : 2 * l + (((m0 >> l) & 1ull) ? 0u : 1u);
+				}
+				if (idx >= cnt) { err |= DEC_ERR_FORMAT; idx = cnt - 1; }     // a symbol the block's alphabet does not have: no encoder writes it
+			}
+			// ---- request the next row -----------------------------------------------------------------------------------
+			const u32 ri_next = base_next + idx * rescale;
+			u32 nxt = 0;
+			if (live) nxt = CPL == 1 ? (u32)tab16[(u64)ri_next * N + lane] : table[(u64)ri_next * (N / 2) + lane];
+
+			// ---- in its shadow: coder state ------------------------------------------------------------------------------
+			const u32 hi = qrc_elem<CPL>(cur, idx);
+			const u32 lo = idx ? qrc_elem<CPL>(cur, idx - 1) : 0u;
+			const u32 f = hi - lo;
+			const u32 rr = lo * r;                                     // uint32 product
+			rd.buffer -= rr; rd.low += rr;
+			rd.range = r * f;
+			while (rd.range <= 0x00FFFFFFu)
+			{
+				if ((rd.low ^ (rd.low + rd.range)) & 0xFF00000000000000ull)
+				{
+					const u32 l32 = (u32)rd.low;
+					rd.range = (l32 | 0x00FFFFFFu) - l32;
+				}
+				rd.buffer = (rd.buffer << 8) + uw_byte(win);
+				rd.low <<= 8; rd.range <<= 8;
+				if (rd.range == 0) { err |= DEC_ERR_FORMAT; rd.range = 0xFFFFFFFFu; break; }
+			}
+			nf = dec_div_prep(rd.range);
+			// ---- the row: +2 on the symbol = +2 on every cumulative count from it on; Rescale() now instead of at the next visit
+			{
+				const u32 il = CPL == 1 ? idx : idx >> 1;
+				if (CPL == 1) { if (lane >= il) cur += 2; }
+				else if (lane > il) cur += 0x00020002u;
+				else if (lane == il) cur += (idx & 1u) ? 0x00020000u : 0x00020002u;
+				if (total + 2 >= LIM)
+				{
+					if (CPL == 1)
+					{
+						u32 p = __shfl_up(cur, 1); if (lane == 0) p = 0;
+						u32 c = live ? cur - p : 0u;
+						c -= c >> 1;
+						cur = dec_wave_scan(c);
+					}
+					else
+					{
+						const u32 e0 = cur & 0xFFFFu, e1 = cur >> 16;
+						u32 p = __shfl_up(e1, 1); if (lane == 0) p = 0;
+						u32 c0 = e0 - p, c1 = e1 - e0;
+						c0 -= c0 >> 1; c1 -= c1 >> 1;
+						const u32 inc = dec_wave_scan(c0 + c1);
+						cur = (inc - c1) | (inc << 16);
+					}
+					if (live) { if (CPL == 1) tab16[(u64)ri * N + lane] = (u16)cur; else table[(u64)ri * (N / 2) + lane] = cur; }
+				}
+				else if (live && lane >= il) { if (CPL == 1) tab16[(u64)ri * N + lane] = (u16)cur; else table[(u64)ri * (N / 2) + lane] = cur; }
+			}
+			// ---- the symbol: lane (j mod 64) keeps it until 64 are together or the record ends ----------------------------
+			u32 qv = idx;
+			if (translate) qv = qrc_elem<CPL>(tr_v, idx);
+			if (lane == (j & 63u)) mine = qv;
+			ncount += q_special(qv, lossy) ? 1u : 0u;
+			++j;
+			if ((j & 63u) == 0 || j == ql)
+			{
+				const u32 base = (j - 1) & ~63u;
+				if (lane < j - base) q[base + lane] = (u8)mine;
+			}
+			// a row that is visited twice in a row was requested before it was written
+			if (ri_next == ri) nxt = cur;
+			cur = nxt; ri = ri_next;
+			hash = hpre | idx; sym_buf = nb; pctx = pn; rem = rem2;
+			if (j == ql)
+			{
+				if (lane == 0) { rp.kept[g0 + k] = (u16)(ql - ncount); rp.d_off[g0 + k] = d_total; }
+				d_total += ql - ncount;
+				for (++k; k < n_recs; ++k)
+				{
+					ql = rp.len[g0 + k];
+					if (ql) break;
+					if (lane == 0) { rp.kept[g0 + k] = 0; rp.d_off[g0 + k] = d_total; }
+				}
+				if (k == n_recs) break;
+				q = text + rp.qual_off[g0 + k];
+				j = 0; ncount = 0;
+			}
+			if (err) break;
+		}
+	}
+	s.bit = uw_pos(win) * 8;
+	if (s.bit > (u64)s.size * 8) s.err |= DEC_ERR_TRUNC;
+	s.err |= err;
+	if (lane == 0) S->d_total = d_total;
+}
+
+// the scheme byte and the alphabet of an order-context quality stream: IQualityModelerProxy::Decode (src/QualityModelerProxy.h:59-69;
+// the lossy order proxy has no scheme byte, :156-159), TTranslationalQualityEncoder::Read (src/QualityEncoder.h:344-357)
+struct QrcScheme { u32 n, ord, rescale, translate; };
+__device__ __forceinline__ bool qrc_scheme(u32 quality_order, u32 lossy, u32 scheme_byte, QrcScheme* q)
+{
+	if (lossy) { q->n = 8; q->ord = quality_order; q->rescale = 8; q->translate = 0; return true; }
+	if (scheme_byte > 7) return false;
+	const u32 sc = scheme_byte & 3u;
+	q->n = 16u << sc;
+	q->ord = quality_order == 1 ? (sc == 0 ? 3u : sc == 1 ? 2u : 1u) : (4u - sc);
+	q->rescale = scheme_byte < 4 ? 8u : q->n;
+	q->translate = 1;
+	return true;
+}
+
+// wave per block of the round; tabs[blockIdx.x] names the block and its table
+__global__ void __launch_bounds__(64) k_dec_qrc(const u8* in, const DecDesc* desc, DecState* st, const DecTab* tabs, RecPools rp, u8* out, u32* tables, DecParams prm)
+{
+	__shared__ u8 s_sym[256];
+	__shared__ u32 s_par[4];
+	const DecTab tb = tabs[blockIdx.x];
+	const u32 b = tb.block;
+	DecState* S = &st[b];
+	if (S->err) return;                                   // wave-uniform
+	const DecDesc d = desc[b];
+	BitSrc s; s.p = in + d.in_off; s.size = d.in_size; s.err = 0; s.bit = (u64)S->qua_pos * 8;
+	if (threadIdx.x == 0)
+	{
+		for (u32 i = 0; i < 256; ++i) s_sym[i] = 255;
+		if (!prm.lossy)
+		{
+			(void)bs_byte(s);                             // scheme byte: k_dec_tags has left it in q_scheme
+			bs_align(s);
+			u32 cnt = 0;
+			for (u32 i = 0; i < 256; ++i) if (bs_bit(s)) s_sym[cnt++] = (u8)i;
+			bs_align(s);
+		}
+		s_par[0] = (u32)s.bit; s_par[1] = (u32)(s.bit >> 32); s_par[2] = s.err;
+	}
+	__syncthreads();
+	s.bit = ((u64)s_par[1] << 32) | s_par[0]; s.err = s_par[2];
+	QrcScheme qs;
+	if (!qrc_scheme(prm.quality_order, prm.lossy, S->q_scheme, &qs)) s.err |= DEC_ERR_FORMAT;
+	const u32 cnt = prm.lossy ? 8u : S->q_cnt;
+	if (cnt == 0 || cnt > qs.n) s.err |= DEC_ERR_FORMAT;
+	if (!s.err)
+	{
+		const u32 ab = dec_int_log2(qs.n);
+		const u64 words = ((u64)1 << (ab * qs.ord)) * qs.rescale * qs.n / 2;
+		if (words > tb.words) s.err |= DEC_ERR_POOL;
+	}
+	if (!s.err)
+	{
+		u32* table = tables + tb.off;
+		u8* text = out + d.out_off;
+		switch (qs.n)
+		{
+		case 8:   qrc_decode<8>(s, table, qs.ord, qs.rescale, cnt, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
+		case 16:  qrc_decode<16>(s, table, qs.ord, qs.rescale, cnt, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
+		case 32:  qrc_decode<32>(s, table, qs.ord, qs.rescale, cnt, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
+		case 64:  qrc_decode<64>(s, table, qs.ord, qs.rescale, cnt, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
+		default:  qrc_decode<128>(s, table, qs.ord, qs.rescale, cnt, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
+		}
+	}
+	if (threadIdx.x == 0)
+	{
+		if (!s.err) S->dna_pos = bs_pos(s);
+		S->err |= s.err;
+	}
+}
+
+// ---- the scheme byte of the DNA stream (IDnaModelerProxy::Decode, src/DnaModelerProxy.h:61-71): thread per block --------------
+__global__ void __launch_bounds__(64) k_dec_dhead(const u8* in, const DecDesc* desc, DecState* st, DecParams prm)
+{
+	const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= prm.n_blocks) return;
+	DecState* S = &st[b];
+	if (S->err) return;
+	const DecDesc d = desc[b];
+	if (S->dna_pos >= d.in_size) { S->err |= DEC_ERR_TRUNC; return; }
+	const u32 sch = in[d.in_off + S->dna_pos];
+	S->d_scheme = sch;
+	if (sch != 255 && sch > 1) S->err |= DEC_ERR_FORMAT;
+}
+
+// ---- the coder's bytes for one lane's stream ------------------------------------------------------------------------------------
+// A wave's vector loads return in order, so a window load that is waited for in the middle of a symbol would also wait for the
+// candidate rows requested just before it -- and with 64 unsynchronised streams some lane refills its window at almost every
+// symbol.  So the refill only moves registers: every symbol requests the 8 bytes behind the window together with the candidate
+// rows (`wl`, mostly the same cached address), and the refill takes the copy that arrived one symbol earlier (`wp`).
+struct LWin { const u8* p; u32 size; u64 w0, w1, wp; u32 left, nx, wp_pos; };
+
+// 8 bytes of the block at byte position pos, the first one in the top bits; bytes behind the end read as zero, nothing
+// outside the block is touched (size >= 16)
+__device__ __forceinline__ u64 lw_load(const u8* p, u32 size, u32 pos)
+{
+	const u32 at = pos < size ? pos : size;
+	const u32 over = at + 8 > size ? at + 8 - size : 0u;
+	const u64 v = __builtin_bswap64(*(const dec_u64_unaligned*)(p + (at - over)));
+	return (v << (4 * over)) << (4 * over);                    // over <= 8; no select, so that the load stays unconditional
+}
+__device__ __forceinline__ u64 lw_start(LWin& w, const BitSrc& s)          // returns the coder's first 8 bytes
+{
+	const u32 at = (u32)(s.bit >> 3);
+	w.p = s.p; w.size = s.size;
+	w.w0 = lw_load(w.p, w.size, at + 8); w.w1 = lw_load(w.p, w.size, at + 16); w.nx = at + 16; w.left = 8;
+	w.wp_pos = w.nx + 8; w.wp = lw_load(w.p, w.size, w.wp_pos);
+	return lw_load(w.p, w.size, at);
+}
+__device__ __forceinline__ u32 lw_byte(LWin& w)
+{
+	if (w.left == 0)
+	{
+		w.w0 = w.w1;
+		if (w.wp_pos != w.nx + 8) { w.wp_pos = w.nx + 8; w.wp = lw_load(w.p, w.size, w.wp_pos); }      // two refills within two symbols
+		w.w1 = w.wp; w.nx += 8; w.left = 8;
+	}
+	const u32 b = (u32)(w.w0 >> 56);
+	w.w0 <<= 8; --w.left;
+	return b;
+}
+__device__ __forceinline__ u32 lw_pos(const LWin& w) { return w.nx - w.left; }
+
+// ---- DNA, order-k range coder: one LANE per block ----------------------------------------------------------------------------
+template <u32 N>
+__global__ void __launch_bounds__(64) k_dec_dnarc(const u8* in, const DecDesc* desc, DecState* st, const DecTab* tabs, u32 n_tabs,
+												   u8* d_stream, u32* tables, DecParams prm)
+{
+	constexpr u32 W = N / 2;                                  // dwords per row
+	constexpr u32 LIM = (1u << 16) - 2 * N;
+	constexpr u32 abits = N == 8 ? 3u : 2u;
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_tabs) return;
+	const DecTab tb = tabs[i];
+	const u32 b = tb.block;
+	DecState* S = &st[b];
+	if (S->err) return;
+	const DecDesc d = desc[b];
+	const u32 ord = N == 8 ? (prm.dna_order < 7u ? prm.dna_order : 7u) : prm.dna_order;
+	const u32 mask = (1u << (abits * ord)) - 1u;              // <= 21 bits
+	BitSrc s; s.p = in + d.in_off; s.size = d.in_size; s.err = 0; s.bit = ((u64)S->dna_pos + 1) * 8;      // behind the scheme byte
+	if ((((u64)mask + 1) * W) > tb.words) { S->err |= DEC_ERR_POOL; return; }
+	u32* tab = tables + tb.off;
+	u8* dst = d_stream + d.d_base;
+	const u32 total = S->d_total;
+	// RangeDecoder::Start (src/RangeCoder.h:97-106)
+	struct { u64 low, buffer; u32 range; } rd;
+	LWin win;
+	rd.buffer = lw_start(win, s); rd.low = 0; rd.range = 0xFFFFFFFFu;
+	double nf = dec_div_prep(rd.range);
+	u32 hash = 0, err = 0;
+	u32 cur[W];                                               // row 0 of a fresh table
+#pragma unroll
+	for (u32 w = 0; w < W; ++w) cur[w] = 0x00010001u;
+	u64 pack = 0;
+	dec_vm_drain();                                           // nothing pending at the loop's entry: the waits inside it then count only its own requests
+	for (u32 t = 0; t < total; ++t)
+	{
+		// the N candidate rows of the next symbol are consecutive and known before this symbol is
+		const u32 nbase = (hash << abits) & mask;
+		const uint2* cp = (const uint2*)(tab + (u64)nbase * W);
+		uint2 cand[N * W / 2];
+#pragma unroll
+		for (u32 w = 0; w < N * W / 2; ++w) cand[w] = cp[w];
+		const u32 wl_pos = win.nx + 8;
+		const u64 wl = lw_load(win.p, win.size, wl_pos);
+		u32 c[N], a[N];
+#pragma unroll
+		for (u32 k = 0; k < N; ++k) c[k] = (cur[k / 2] >> (16 * (k & 1))) & 0xFFFFu;
+		a[0] = c[0];
+#pragma unroll
+		for (u32 k = 1; k < N; ++k) a[k] = a[k - 1] + c[k];
+		const u32 T = a[N - 1];
+		u32 r = dec_div(nf, T);
+		if (r == 0) { err |= DEC_ERR_FORMAT; r = 1; }
+		u32 idx = 0, rr = 0, f = c[0];
+		if (rd.buffer >= (u64)T * r)
+		{	// not a stream the encoder writes: the reference's search with the truncated quotient
+			const u32 cul = div_u64_u32(rd.buffer, r);
+			u32 lo = 0; bool found = false;
+#pragma unroll
+			for (u32 k = 0; k < N; ++k)
+				if (!found) { if (a[k] > cul) { found = true; idx = k; f = c[k]; rr = lo * r; } lo = a[k]; }
+			if (!found) { err |= DEC_ERR_FORMAT; idx = N - 1; f = c[N - 1]; rr = (a[N - 1] - f) * r; }
+		}
+		else
+		{
+#pragma unroll
+			for (u32 k = 1; k < N; ++k)
+			{
+				const u64 sk = (u64)a[k - 1] * r;
+				if (rd.buffer >= sk) { idx = k; rr = (u32)sk; f = c[k]; }
+			}
+		}
+		rd.buffer -= rr; rd.low += rr;
+		rd.range = r * f;
+		while (rd.range <= 0x00FFFFFFu)
+		{
+			if ((rd.low ^ (rd.low + rd.range)) & 0xFF00000000000000ull)
+			{
+				const u32 l32 = (u32)rd.low;
+				rd.range = (l32 | 0x00FFFFFFu) - l32;
+			}
+			rd.buffer = (rd.buffer << 8) + lw_byte(win);
+			rd.low <<= 8; rd.range <<= 8;
+			if (rd.range == 0) { err |= DEC_ERR_FORMAT; rd.range = 0xFFFFFFFFu; break; }
+		}
+		nf = dec_div_prep(rd.range);
+		// the row: +2, Rescale() now instead of at the next visit
+#pragma unroll
+		for (u32 w = 0; w < W; ++w) cur[w] += (idx >> 1) == w ? (2u << (16 * (idx & 1u))) : 0u;
+		if (T + 2 >= LIM)
+		{
+#pragma unroll
+			for (u32 w = 0; w < W; ++w)
+			{
+				const u32 x0 = cur[w] & 0xFFFFu, x1 = cur[w] >> 16;
+				cur[w] = (x0 - (x0 >> 1)) | ((x1 - (x1 >> 1)) << 16);
+			}
+		}
+		{
+			u32* row = tab + (u64)hash * W;
+			if (W == 2) *(uint2*)row = make_uint2(cur[0], cur[1]);
+			else *(uint4*)row = make_uint4(cur[0], cur[1], cur[W - 2], cur[W - 1]);
+		}
+		pack |= (u64)idx << (8 * (t & 7u));
+		if ((t & 7u) == 7u) { *(u64*)(dst + (t & ~7u)) = pack; pack = 0; }
+		const u32 nh = nbase | idx;
+		if (nh != hash)
+		{	// candidate row idx (a row visited twice in a row is the one in registers)
+			constexpr u32 R2 = W / 2 > 0 ? W / 2 : 1;               // uint2 per row: 1 (N = 4), 2 (N = 8)
+			uint2 sel[R2];
+#pragma unroll
+			for (u32 w = 0; w < R2; ++w) sel[w] = cand[w];
+#pragma unroll
+			for (u32 k = 1; k < N; ++k)
+				if (idx == k)
+				{
+#pragma unroll
+					for (u32 w = 0; w < R2; ++w) sel[w] = cand[k * R2 + w];
+				}
+#pragma unroll
+			for (u32 w = 0; w < R2; ++w) { cur[2 * w] = sel[w].x; cur[2 * w + 1] = sel[w].y; }
+		}
+		hash = nh;
+		win.wp = wl; win.wp_pos = wl_pos;
+		if (err) break;
+	}
+	if (total & 7u)
+	{	// d_base is 64-byte aligned and the stream's allocation is padded: the last, partial group is stored whole
+		*(u64*)(dst + (total & ~7u)) = pack;
+	}
+	const u32 end = lw_pos(win);
+	if (end > s.size) err |= DEC_ERR_TRUNC;
+	S->end_pos = end;
+	S->err |= err;
+}
+
+// ---- DNA of the -d0 level and blocks without a DNA stream: wave per block -----------------------------------------------------
+// DnaModelerBasicB2::Decode (src/DnaModelerBasicB2.h:48-60): symbol t is bits 2t, 2t+1, unpacked by the whole wave;
+// DnaModelerHuffman::Decode (src/DnaModelerHuffman.cpp:75-113): lane 0 walks the tree.
+__global__ void __launch_bounds__(64) k_dec_dna0(const u8* in, const DecDesc* desc, DecState* st, u32* pool, u8* d_stream, DecParams prm)
+{
+	__shared__ u8 s_sym[32];
+	const u32 b = blockIdx.x;
+	DecState* S = &st[b];
+	if (S->err) return;
+	const u32 d_scheme = S->d_scheme;
+	if (prm.dna_order > 0 && d_scheme != 255) return;          // k_dec_dnarc's
+	const DecDesc d = desc[b];
+	BitSrc s; s.p = in + d.in_off; s.size = d.in_size; s.err = 0; s.bit = ((u64)S->dna_pos + 1) * 8;
+	const u32 total = S->d_total;
+	u8* dst = d_stream + d.d_base;
+	if (d_scheme == 0)
+	{
+		BitSrc t = s;
+		const u64 bit0 = s.bit;
+		for (u32 t0 = threadIdx.x * 16u; t0 < total; t0 += blockDim.x * 16u)
+		{
+			t.bit = bit0 + 2ull * t0;
+			const u32 w = bs_peek32(t);
+			const u32 cnt = total - t0 < 16u ? total - t0 : 16u;
+			if (cnt == 16u)
+			{	// sixteen bytes as two aligned 8-byte stores (d_base and t0 are multiples of 16)
+				u64 lo = 0, hi = 0;
+#pragma unroll
+				for (u32 k = 0; k < 8; ++k) { lo |= (u64)((w >> (30 - 2 * k)) & 3u) << (8 * k); hi |= (u64)((w >> (14 - 2 * k)) & 3u) << (8 * k); }
+				((u64*)(dst + t0))[0] = lo; ((u64*)(dst + t0))[1] = hi;
+			}
+			else for (u32 k = 0; k < cnt; ++k) dst[t0 + k] = (u8)((w >> (30 - 2 * k)) & 3u);
+		}
+	}
+	if (threadIdx.x != 0) return;
+	if (d_scheme == 0) { bs_skip(s, total); bs_skip(s, total); bs_align(s); }
+	else if (d_scheme == 1)
+	{
+		NodePool np; np.w = pool + d.qnode_off; np.cap = d.qnode_cap; np.top = 0;
+		u32 n = 0;
+		for (u32 i = 0; i < 20; ++i) s_sym[i] = 255;
+		for (u32 i = 0; i < 20; ++i) if (bs_bit(s)) s_sym[n++] = (u8)i;
+		const u32 tr = huff_load(s, np);
+		for (u32 t = 0; t < total && !s.err; ++t) { const u32 x = huff_sym(s, np.w + tr); dst[t] = x < 20 ? s_sym[x] : 255; }
+		bs_align(s);
+	}
+	// d_scheme == 255: no DNA stream at all, the block ends behind the scheme byte
+	S->end_pos = bs_pos(s);
+	S->err |= s.err;
+}

@@ -62,6 +62,11 @@ uint64_t wave_exchange(uint64_t v, uint64_t out[64]);   // returns active mask
 
 static const int warpSize = 64;
 
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+
 inline void __syncthreads() { emu::g_cur->state = 1; emu::yield_to_scheduler(); }
 inline void __threadfence() {}
 inline void __threadfence_block() {}

@@ -2,6 +2,7 @@
 through dsrcgpu_decompress_batch, against the oracle's decoder (pinned to the reference's BlockCompressor::Read).
 Test harness for a GPU-less container; the product loads only libdsrc_gpu.so."""
 import dataclasses
+import os
 
 import pytest
 
@@ -15,7 +16,7 @@ from tests.test_emu_kernels import emu  # noqa: F401  (fixture)
 def one_lane_quality_decoder(request, monkeypatch):
     """The wave-cooperative range decoder costs the emulator 64 context switches per symbol; most tests here use the
     one-lane form of the same decoder (DSRC_GPU_DEC_SERIAL) and test_wave_decoder covers the cooperative one."""
-    if "wave" not in request.node.name:
+    if "wave" not in request.node.name and not os.environ.get("DSRC_TEST_EMU_FAST_DECODER"):
         monkeypatch.setenv("DSRC_GPU_DEC_SERIAL", "1")
 
 
@@ -145,3 +146,17 @@ def test_wave_decoder(emu, oracle, d, q, lossy):
     wide = b"\n".join(b"@w.%d\n%s\n+\n%s" % (i, b"A" * (20 + i % 7), bytes(33 + rng.randrange(2, 62) for _ in range(20 + i % 7))) for i in range(60))
     chunks = [synth.illumina_fastq(40)[:-1], few] + ([] if lossy else [wide])
     check(emu, oracle, Config.from_levels(d, q, lossy), chunks)
+
+
+@pytest.mark.parametrize("d,q,wide", [(3, 2, False), (1, 2, True), (2, 1, True)])
+def test_wave_decoder_rescale(emu, oracle, d, q, wide):
+    """Rows hot enough for TSymbolCoderRC::Rescale (src/SymbolCoderRC.h:69-90; > 32 k visits of one row) in the cooperative quality
+    decoder -- which applies it when the row is written, not at the next visit -- with one counter per lane and, for the
+    128-symbol alphabet (`wide`), two; and in the lane-per-block DNA decoder (one homopolymer context)."""
+    import random
+    rng = random.Random(7 * d + q)
+    recs = [b"@r\nA\n+\n%c" % (73 if rng.random() < 0.97 else 72) for _ in range(42000)]        # reads of length 1: one position context
+    if wide:
+        recs += [b"@w\n%s\n+\n%s" % (b"C" * 70, bytes(range(33, 103)))]                          # 70 distinct qualities: 128-symbol alphabet
+    recs += [b"@h\n%s\n+\n%s" % (b"A" * 200, b"I" * 200) for _ in range(180)]                  # 36 k bases in one DNA context
+    check(emu, oracle, Config.from_levels(d, q, False), [b"\n".join(recs)])
