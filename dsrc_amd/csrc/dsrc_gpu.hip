@@ -35,6 +35,7 @@
 #include "k_synth.h"
 #include "k_dec.h"
 #include "k_dec_rc.h"
+#include "k_dec_tags.h"
 
 namespace
 {
@@ -994,7 +995,8 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 	else if (text_total > io.out_cap) return fail(h, DSRCGPU_E_CAPACITY, "output needs %llu bytes, caller gave %llu", (unsigned long long)text_total, (unsigned long long)io.out_cap);
 
 	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(DecDesc) * B, hipMemcpyHostToDevice, s));
-	hipLaunchKernelGGL(k_dec_tags, dim3(B), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), AP<u8>(h, o_fld), prm); KCHK();
+	if (prm.serial_quality) { hipLaunchKernelGGL(k_dec_tags, dim3(B), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), AP<u8>(h, o_fld), prm); KCHK(); }
+	else { hipLaunchKernelGGL(k_dec_tags_wave, dim3(B), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), AP<u8>(h, o_fld), prm); KCHK(); }
 	if (!q_rc) { hipLaunchKernelGGL(k_dec_qhuff, dim3(B), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), prm); KCHK(); }
 
 	if (prm.serial_quality)

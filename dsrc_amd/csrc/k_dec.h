@@ -441,26 +441,17 @@ __device__ __forceinline__ u32 tag_numeric(BitSrc& s, DecField& f, const u32* po
 // ReadTags (src/BlockCompressor.cpp:491-573) with TagTokenizerDecoder / TagRawDecoder (src/TagModeler.cpp:887-1343):
 // titles are decoded straight into the text at their final position; the positions of the other three lines of the
 // record follow from its length.  The separators ('\n', '+', the repeated title) are written by k_dec_layout.
-__global__ void __launch_bounds__(64) k_dec_tags(const u8* in, const DecDesc* desc, DecState* st, RecPools rp, u8* out, u32* pool, u8* fld_pool, DecParams prm)
-{
-	const u32 b = blockIdx.x;
-	DecState* S = &st[b];
-	if (threadIdx.x != 0 || S->err) return;
-	const DecDesc d = desc[b];
-	BitSrc s; s.p = in + d.in_off; s.size = d.in_size; s.err = 0; s.bit = (u64)S->tag_pos * 8;
-	NodePool np; np.w = pool + d.node_off; np.cap = d.node_cap; np.top = 0;
-	DecField* F = (DecField*)(fld_pool + d.fld_off);
-	u8* text = out + d.out_off; const u32 cap = d.out_cap;
-	const bool mixed = (S->flags & 4u) != 0;
-	const u32 len_bits = dec_bit_length((u64)(S->max_qlen - S->min_qlen));
-	const u32 cs_delta = (prm.color_space && (S->flags & 1u)) ? 1u : 0u;
-	u32 nf = 0, raw_tree = 0, min_title = 0, max_title = 0, tl_bits = 0, raw_n = 0;
-	u32 raw_map = 0;          // node-pool index of the 128-entry symbol list of the raw coder
+struct TagHead { u32 nf, raw_tree, min_title, max_title, tl_bits, raw_n, raw_map; };
 
+// the header of the tag stream: field descriptors and Huffman trees (TagTokenizerDecoder::ReadFields, src/TagModeler.cpp:896-1017;
+// TagRawDecoder::StartDecoding, :1287-1316); one lane
+__device__ __forceinline__ void tags_header(BitSrc& s, NodePool& np, DecField* F, bool mixed, TagHead& H)
+{
+	H.nf = 0; H.raw_tree = 0; H.min_title = 0; H.max_title = 0; H.tl_bits = 0; H.raw_n = 0; H.raw_map = 0;
 	if (!mixed)
 	{
-		nf = bs_byte(s);
-		for (u32 i = 0; i < nf && !s.err; ++i)
+		H.nf = bs_byte(s);
+		for (u32 i = 0; i < H.nf && !s.err; ++i)
 		{
 			DecField f; memset(&f, 0, sizeof(f));
 			f.sep = (u8)bs_byte(s);
@@ -510,13 +501,23 @@ __global__ void __launch_bounds__(64) k_dec_tags(const u8* in, const DecDesc* de
 	}
 	else
 	{
-		min_title = bs_word(s); max_title = bs_word(s);
-		tl_bits = dec_bit_length((u64)(max_title - min_title));
-		raw_map = pool_take(np, 128, &s.err);
-		for (u32 i = 0; i < 128 && !s.err; ++i) if (bs_bit(s)) np.w[raw_map + raw_n++] = i;
-		if (!s.err) raw_tree = huff_load(s, np);
+		H.min_title = bs_word(s); H.max_title = bs_word(s);
+		H.tl_bits = dec_bit_length((u64)(H.max_title - H.min_title));
+		H.raw_map = pool_take(np, 128, &s.err);
+		for (u32 i = 0; i < 128 && !s.err; ++i) if (bs_bit(s)) np.w[H.raw_map + H.raw_n++] = i;
+		if (!s.err) H.raw_tree = huff_load(s, np);
 	}
 
+}
+
+// the records of the tag stream, one lane walking the bit stream (the reference's own loop; the fallback of k_dec_tags_wave and
+// what DSRC_GPU_DEC_SERIAL runs)
+__device__ __forceinline__ void tags_records_serial(BitSrc& s, NodePool& np, DecField* F, const TagHead& H, bool mixed, DecState* S, const DecDesc& d,
+													RecPools rp, u8* text, const DecParams& prm, u32* pos_out, u32* q_total_out)
+{
+	const u32 cap = d.out_cap;
+	const u32 len_bits = dec_bit_length((u64)(S->max_qlen - S->min_qlen));
+	const u32 cs_delta = (prm.color_space && (S->flags & 1u)) ? 1u : 0u;
 	const u64 r0 = d.rec_base;
 	u32 pos = 0, q_total = 0;
 	for (u32 i = 0; i < S->n_recs && !s.err; ++i)
@@ -525,7 +526,7 @@ __global__ void __launch_bounds__(64) k_dec_tags(const u8* in, const DecDesc* de
 		u32 tl;
 		if (!mixed)
 		{
-			for (u32 j = 0; j < nf; ++j)
+			for (u32 j = 0; j < H.nf; ++j)
 			{
 				DecField& f = F[j];
 				if (f.is_constant)
@@ -564,11 +565,11 @@ __global__ void __launch_bounds__(64) k_dec_tags(const u8* in, const DecDesc* de
 		}
 		else
 		{
-			tl = tl_bits ? bs_bits(s, tl_bits) + min_title : max_title;
+			tl = H.tl_bits ? bs_bits(s, H.tl_bits) + H.min_title : H.max_title;
 			for (u32 k = 0; k < tl && !s.err; ++k)
 			{
-				const u32 x = huff_sym(s, np.w + raw_tree);
-				text_put(text, cap, pos, x < raw_n ? np.w[raw_map + x] : 255u, &s.err);
+				const u32 x = huff_sym(s, np.w + H.raw_tree);
+				text_put(text, cap, pos, x < H.raw_n ? np.w[H.raw_map + x] : 255u, &s.err);
 			}
 		}
 		pos++;                                                    // '\n'
@@ -582,6 +583,12 @@ __global__ void __launch_bounds__(64) k_dec_tags(const u8* in, const DecDesc* de
 		q_total += ql;
 		if (pos > cap) s.err |= DEC_ERR_TEXT;
 	}
+	*pos_out = pos; *q_total_out = q_total;
+}
+
+// what follows the records: where the quality stream starts, and the head of it that the host sizes the model table from
+__device__ __forceinline__ void tags_finish(BitSrc& s, DecState* S, const DecParams& prm, u32 pos, u32 q_total)
+{
 	bs_align(s);
 	S->qua_pos = bs_pos(s); S->text_bytes = pos; S->q_total = q_total;
 	// the scheme byte of the quality stream (IQualityModelerProxy::Decode, src/QualityModelerProxy.h:59-69): the host sizes the
@@ -603,6 +610,23 @@ __global__ void __launch_bounds__(64) k_dec_tags(const u8* in, const DecDesc* de
 		}
 	}
 	S->err |= s.err;
+}
+
+__global__ void __launch_bounds__(64) k_dec_tags(const u8* in, const DecDesc* desc, DecState* st, RecPools rp, u8* out, u32* pool, u8* fld_pool, DecParams prm)
+{
+	const u32 b = blockIdx.x;
+	DecState* S = &st[b];
+	if (threadIdx.x != 0 || S->err) return;
+	const DecDesc d = desc[b];
+	BitSrc s; s.p = in + d.in_off; s.size = d.in_size; s.err = 0; s.bit = (u64)S->tag_pos * 8;
+	NodePool np; np.w = pool + d.node_off; np.cap = d.node_cap; np.top = 0;
+	DecField* F = (DecField*)(fld_pool + d.fld_off);
+	const bool mixed = (S->flags & 4u) != 0;
+	TagHead H;
+	tags_header(s, np, F, mixed, H);
+	u32 pos = 0, q_total = 0;
+	tags_records_serial(s, np, F, H, mixed, S, d, rp, out + d.out_off, prm, &pos, &q_total);
+	tags_finish(s, S, prm, pos, q_total);
 }
 
 // ---- stage 3: quality and DNA streams (wave per slot; lane 0 walks, all lanes clear the model table) ------------------------

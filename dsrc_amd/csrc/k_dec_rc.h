@@ -26,6 +26,10 @@
 // every vector-memory request of this wave has completed: s_waitcnt vmcnt(0) (gfx9 encoding, expcnt / lgkmcnt left at their maxima)
 __device__ __forceinline__ void dec_vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
+#ifndef DEC_SWIZZLE
+#define DEC_SWIZZLE 0
+#endif
+
 struct DecTab            // one model table of one block in the table region (host -> device)
 {
 	u64 off;             // u32 words from the start of the region
@@ -149,7 +153,7 @@ template <u32 CPL> __device__ __forceinline__ u32 qrc_elem(u32 cur, u32 i)
 }
 
 template <u32 N>
-__device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 rescale, u32 cnt, bool translate, const u8* sym_tab, u32 lossy,
+__device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 rescale, u32 cnt, u32 swz_seed, bool translate, const u8* sym_tab, u32 lossy,
 										   const DecDesc& d, DecState* S, RecPools rp, u8* text)
 {
 	constexpr u32 CPL = N > 64 ? 2u : 1u;
@@ -163,6 +167,10 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 	const u32 hash_mask = (1u << (ord * abits)) - 1u;                   // ord * abits <= 21 for every scheme
 	const u32 swap_mask = ((1u << bits_lo) - 1u) | ~((1u << bits_hi) - 1u);
 	u16* tab16 = (u16*)table;
+	// Where a row lives: its number XOR a per-block constant.  Blocks of one file have the same hot contexts, and tables that are laid
+	// out alike put them on the same memory channels: 2400 waves then queue on a few of them (measured: 2.8 instead of 1.7 s per
+	// pass).  The XOR is a bijection on the 2^k rows; which row is which is nobody's business but this decoder's.
+	const u32 swz = DEC_SWIZZLE ? swz_seed & (((hash_mask + 1u) * rescale) - 1u) : 0u;
 	// symbol value of counter i, in the lane that holds counter i (two per lane when N == 128)
 	u32 tr_v = 0;
 	if (translate) tr_v = CPL == 1 ? (live ? (u32)sym_tab[lane] : 0u) : ((u32)sym_tab[2 * lane] | ((u32)sym_tab[2 * lane + 1] << 16));
@@ -192,17 +200,20 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 		u32 cur = !live ? 0u : CPL == 1 ? lane + 1 : (2 * lane + 1) | ((2 * lane + 2) << 16);
 		double nf = dec_div_prep(rd.range);
 		dec_vm_drain();
+		// Where the row of the symbol AFTER the one being decoded is, up to that symbol itself: position context, and the hash with
+		// its low slot still empty.  It is prepared one symbol ahead (in the shadow of the previous request), so that between
+		// "row arrives" and "next row requested" there is only the symbol search.
+		u32 pn, rem2, nb, hpre, base_next;
+#define QRC_PREP() do { \
+			pn = 0; rem2 = 0; \
+			if (j + 1 != ql) { pn = pctx; rem2 = rem + rescale; while (rem2 >= ql) { rem2 -= ql; ++pn; } } \
+			const u32 h2_ = hash << abits; \
+			nb = (h2_ >> bits_lo) & sym_mask; \
+			hpre = (h2_ & swap_mask) | (((nb + sym_buf) >> 1) << bits_lo); \
+			base_next = (hpre & hash_mask) * rescale + pn; } while (0)
+		QRC_PREP();
 		for (;;)
 		{
-			// ---- independent of the row: where the next symbol's row is, up to the symbol itself ------------------------
-			const bool rec_end = j + 1 == ql;
-			u32 pn = 0, rem2 = 0;
-			if (!rec_end) { pn = pctx; rem2 = rem + rescale; while (rem2 >= ql) { rem2 -= ql; ++pn; } }
-			const u32 h2 = hash << abits;
-			const u32 nb = (h2 >> bits_lo) & sym_mask;
-			const u32 hpre = (h2 & swap_mask) | (((nb + sym_buf) >> 1) << bits_lo);      // the hash after this symbol, its low slot still empty
-			const u32 base_next = (hpre & hash_mask) * rescale + pn;
-
 			// ---- the row has arrived: symbol index ---------------------------------------------------------------------
 			const u32 total = qrc_elem<CPL>(cur, N - 1);
 			u32 r = dec_div(nf, total);
@@ -229,7 +240,7 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 			// ---- request the next row -----------------------------------------------------------------------------------
 			const u32 ri_next = base_next + idx * rescale;
 			u32 nxt = 0;
-			if (live) nxt = CPL == 1 ? (u32)tab16[(u64)ri_next * N + lane] : table[(u64)ri_next * (N / 2) + lane];
+			if (live) nxt = CPL == 1 ? (u32)tab16[(u64)(ri_next ^ swz) * N + lane] : table[(u64)(ri_next ^ swz) * (N / 2) + lane];
 
 			// ---- in its shadow: coder state ------------------------------------------------------------------------------
 			const u32 hi = qrc_elem<CPL>(cur, idx);
@@ -274,9 +285,9 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 						const u32 inc = dec_wave_scan(c0 + c1);
 						cur = (inc - c1) | (inc << 16);
 					}
-					if (live) { if (CPL == 1) tab16[(u64)ri * N + lane] = (u16)cur; else table[(u64)ri * (N / 2) + lane] = cur; }
+					if (live) { if (CPL == 1) tab16[(u64)(ri ^ swz) * N + lane] = (u16)cur; else table[(u64)(ri ^ swz) * (N / 2) + lane] = cur; }
 				}
-				else if (live && lane >= il) { if (CPL == 1) tab16[(u64)ri * N + lane] = (u16)cur; else table[(u64)ri * (N / 2) + lane] = cur; }
+				else if (live && lane >= il) { if (CPL == 1) tab16[(u64)(ri ^ swz) * N + lane] = (u16)cur; else table[(u64)(ri ^ swz) * (N / 2) + lane] = cur; }
 			}
 			// ---- the symbol: lane (j mod 64) keeps it until 64 are together or the record ends ----------------------------
 			u32 qv = idx;
@@ -308,7 +319,9 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 				j = 0; ncount = 0;
 			}
 			if (err) break;
+			QRC_PREP();
 		}
+#undef QRC_PREP
 	}
 	s.bit = uw_pos(win) * 8;
 	if (s.bit > (u64)s.size * 8) s.err |= DEC_ERR_TRUNC;
@@ -367,17 +380,18 @@ __global__ void __launch_bounds__(64) k_dec_qrc(const u8* in, const DecDesc* des
 		const u64 words = ((u64)1 << (ab * qs.ord)) * qs.rescale * qs.n / 2;
 		if (words > tb.words) s.err |= DEC_ERR_POOL;
 	}
+	const u32 swz_seed = (b + 1u) * 0x9E3779B1u >> 7;
 	if (!s.err)
 	{
 		u32* table = tables + tb.off;
 		u8* text = out + d.out_off;
 		switch (qs.n)
 		{
-		case 8:   qrc_decode<8>(s, table, qs.ord, qs.rescale, cnt, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
-		case 16:  qrc_decode<16>(s, table, qs.ord, qs.rescale, cnt, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
-		case 32:  qrc_decode<32>(s, table, qs.ord, qs.rescale, cnt, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
-		case 64:  qrc_decode<64>(s, table, qs.ord, qs.rescale, cnt, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
-		default:  qrc_decode<128>(s, table, qs.ord, qs.rescale, cnt, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
+		case 8:   qrc_decode<8>(s, table, qs.ord, qs.rescale, cnt, swz_seed, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
+		case 16:  qrc_decode<16>(s, table, qs.ord, qs.rescale, cnt, swz_seed, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
+		case 32:  qrc_decode<32>(s, table, qs.ord, qs.rescale, cnt, swz_seed, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
+		case 64:  qrc_decode<64>(s, table, qs.ord, qs.rescale, cnt, swz_seed, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
+		default:  qrc_decode<128>(s, table, qs.ord, qs.rescale, cnt, swz_seed, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
 		}
 	}
 	if (threadIdx.x == 0)

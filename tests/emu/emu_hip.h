@@ -102,6 +102,7 @@ template <typename T> inline T __shfl_xor(T v, int m, int width = 64) { (void)wi
 // gfx950 intrinsics used by k_common.h / k_rc.h
 #define __builtin_amdgcn_readlane(v, l) emu_shfl_from((int)(v), (int)(l))
 #define __builtin_amdgcn_readfirstlane(v) emu_shfl_from((int)(v), 0)
+#define __builtin_amdgcn_writelane(v, l, old) ((int)(threadIdx.x & 63) == (int)(l) ? (int)(v) : (int)(old))
 #define __builtin_assume(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_alignbit(hi, lo, sh) ((unsigned)(((((uint64_t)(unsigned)(hi)) << 32) | (unsigned)(lo)) >> ((sh) & 31)))
