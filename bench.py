@@ -35,6 +35,7 @@ RECS_PER_BLOCK = 22300
 PMC_RC_BYTES_PER_BLOCK = (13.3515e6 * 2 + 13.3427e6) * 1024 / 512   # measured, see roofline.traffic below
 PMC_SORT_BYTES_PER_BLOCK = (16.6858e6 * 2 + 65.8718e6) * 1024 / 512  # k_sort, eight launches of a 512-block batch (same profile)
 PMC_REPLAY_BYTES_PER_BLOCK = ((9.2572e6 + 8.9190e6) * 2 + 55.0891e6 + 54.9436e6) * 1024 / 512   # k_replay<32> + k_replay<4>: 293 MB per block, 225 of them the scattered 8-byte records at one 32-byte sector each
+DECODE_TRAFFIC_PER_BLOCK = 663e6  # HBM bytes per decoded block at -d3 -q2: (FETCH_SIZE + WRITE_SIZE of k_dec_qrc and k_dec_dnarc) x 1 KiB / 2400 blocks (profiles/r03_pmc_decode_b2400.txt)
 MAX_RESIDENT = 3                  # distinct input shards kept in HBM per scheduler instance (2 when N > 1: rank 0 also holds the gathered streams)
 
 
@@ -175,11 +176,15 @@ class StepGates:
             self.gathered.add(s); self.cv.notify_all()
 
 
-def measure_decode(lanes, cfg, n_blocks, last_step):
+def measure_decode(lanes, cfg, n_blocks, last_step, n_inst=int(os.environ.get("DSRC_BENCH_DECODE_INST", "2")), passes=2):
     """Secondary line: the same blocks back through the GPU decompressor (dsrcgpu_decompress_batch_device), everything in
     HBM.  The blocks are the ones instance 0 wrote in its last sub-batch, taken as many times as needed to make
-    `n_blocks` (every copy is decoded into its own text; the decoder's work does not depend on the data being distinct).
-    The other instances are closed first: a decoding pass wants the HBM for model tables (one per block in flight)."""
+    `n_blocks` per pass (every copy is decoded into its own text; the decoder's work does not depend on the data being distinct).
+    `n_inst` decoding instances run `passes` passes each, concurrently: a pass is a chain of stages (titles, quality, DNA,
+    layout) of which the quality stage fills the SIMDs and the DNA stage (one lane per block) hardly uses them, so two passes in
+    flight overlap one's DNA stage with the other's quality stage.
+    The compression instances are closed first: a decoding pass wants the HBM for model tables (one per block in flight)."""
+    from dsrc_amd._lib import Handle
     ln = lanes[0]
     for other in lanes[1:]:
         for d_in, _, _ in other.sub:
@@ -195,28 +200,50 @@ def measure_decode(lanes, cfg, n_blocks, last_step):
     reps = max(1, (n_blocks + len(o_offs) - 1) // len(o_offs))
     offs = (o_offs * reps)[:n_blocks]; szs = (o_sizes * reps)[:n_blocks]
     text_bytes = sum((sizes * reps)[:n_blocks]) + n_blocks
-    d_txt = ln.h.dev_alloc(text_bytes + 4096)
+    hs = [ln.h] + [Handle(cfg.dna_order, cfg.quality_order, quality_offset=33, device=ln.h.device) for _ in range(n_inst - 1)]
+    txts = [h.dev_alloc(text_bytes + 4096) for h in hs]
+    out = [None] * n_inst; gpu_ms = [0.0] * n_inst
     try:
-        t_offs, t_sizes, ok = ln.h.decompress_batch_device(d_blk, offs, szs, d_txt, text_bytes + 4096, verify=True)    # warm-up: sizes the arena
+        for h, d_txt in zip(hs, txts):                  # warm-up: sizes the arenas and the table regions
+            h.decompress_batch_device(d_blk, offs, szs, d_txt, text_bytes + 4096, verify=True)
+
+        def work(i):
+            for _ in range(passes):
+                out[i] = hs[i].decompress_batch_device(d_blk, offs, szs, txts[i], text_bytes + 4096, verify=True)
+                gpu_ms[i] += hs[i].last_timing()[0]
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(n_inst)]
         t0 = time.perf_counter()
-        t_offs, t_sizes, ok = ln.h.decompress_batch_device(d_blk, offs, szs, d_txt, text_bytes + 4096, verify=True)
+        for i, t in enumerate(ths):
+            t.start()
+            if i + 1 < n_inst:
+                time.sleep(float(os.environ.get("DSRC_BENCH_DECODE_STAGGER", "1.5")))     # half a pass apart: the stages interleave
+        for t in ths:
+            t.join()
         dt = time.perf_counter() - t0
-        gpu_ms = ln.h.last_timing()[0]
-        assert sum(t_sizes) == text_bytes and all(ok)
-        # parity: the text of the first and the last copy is the chunk that was compressed
-        for i in (0, n_blocks - 1):
-            src = ln.h.dev_download(d_in + starts[i % len(starts)], sizes[i % len(starts)])
-            assert ln.h.dev_download(d_txt + t_offs[i], t_sizes[i]) == src + b"\n", f"decode parity check failed on block {i}"
+        for i in range(n_inst):
+            t_offs, t_sizes, ok = out[i]
+            assert sum(t_sizes) == text_bytes and all(ok)
+            # parity: the text of the first and the last copy is the chunk that was compressed
+            for k in (0, n_blocks - 1):
+                src = ln.h.dev_download(d_in + starts[k % len(starts)], sizes[k % len(starts)])
+                assert hs[i].dev_download(txts[i] + t_offs[k], t_sizes[k]) == src + b"\n", f"decode parity check failed on block {k}"
     finally:
-        ln.h.dev_free(d_txt)
-    alg = text_bytes + sum(szs)
+        for h, d_txt in zip(hs, txts):
+            h.dev_free(d_txt)
+        for h in hs[1:]:
+            h.close()
+    total_text = text_bytes * n_inst * passes
+    alg = (text_bytes + sum(szs)) * n_inst * passes
+    pass_ms = sum(gpu_ms) / (n_inst * passes)
     return {"metric": f"raw FASTQ MB/s decompressed (text identical to the input) at -d{cfg.dna_order // 3} -q{cfg.quality_order}",
-            "value": round(text_bytes / dt / 1e6, 1), "unit": "MB/s", "blocks": n_blocks, "ms": round(dt * 1e3, 1),
-            "data": f"{len(o_offs)} distinct blocks of the timed region x {reps}, compressed blocks and decoded text resident in HBM; one scheduler instance, one pass",
-            "roofline": {"bound": "hbm", "kernel": "k_dec_streams (one wavefront per block: range / Huffman decoding of the quality and DNA streams)",
-                         "achieved": round(alg / (gpu_ms / 1e3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg / (gpu_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 6), "kernel_ms": round(gpu_ms, 1), "launch_bytes": int(alg), "traffic": None,
-                         "note": "algorithmic bytes = block bytes in + text bytes out of the pass; a decoded stream is a chain of dependent model-row reads (about one HBM latency per symbol), so the pass is bound by latency x blocks in flight, not by bandwidth (DESIGN section 11)"}}
+            "value": round(total_text / dt / 1e6, 1), "unit": "MB/s", "blocks": n_blocks, "instances": n_inst, "passes_per_instance": passes, "ms": round(dt * 1e3, 1),
+            "data": f"{len(o_offs)} distinct blocks of the timed region x {reps} per pass, compressed blocks and decoded text resident in HBM; "
+                    f"{n_inst} decoding instances x {passes} passes of {n_blocks} blocks, concurrent",
+            "roofline": {"bound": "hbm", "kernel": "k_dec_qrc (one wavefront per block: range decoding of the quality stream; the DNA stream follows in k_dec_dnarc, one lane per block)",
+                         "achieved": round(alg / dt / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 6), "pass_ms": round(pass_ms, 1), "launch_bytes": int(text_bytes + sum(szs)),
+                         "traffic": int(DECODE_TRAFFIC_PER_BLOCK * n_blocks) if cfg.dna_order == 9 and cfg.quality_order == 2 else None,
+                         "note": "algorithmic bytes = block bytes in + text bytes out of a pass; a decoded stream is a chain of dependent model-row accesses, one 64-byte row fetched and written back per symbol (traffic: rocprofv3 FETCH_SIZE + WRITE_SIZE of k_dec_qrc + k_dec_dnarc per block, profiles/r03_pmc_decode_b2400.txt), and the kernels are bound by instruction issue and latency x blocks in flight, not by bandwidth (DESIGN section 11)"}}
 
 
 def main():

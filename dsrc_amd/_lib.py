@@ -116,6 +116,7 @@ class Handle:
                  plus_repetition=False, color_space=False, tag_flags=0, device=0, arena_bytes=0, verify=False):
         self.L = load()
         self.h = C.c_void_p()
+        self.device = device
         s = Settings(dna_order, quality_order, tag_flags, int(lossy), int(crc), int(verify))
         d = Dataset(quality_offset, int(plus_repetition), int(color_space))
         rc = self.L.dsrcgpu_create(C.byref(s), C.byref(d), device, C.c_uint64(arena_bytes), C.byref(self.h))

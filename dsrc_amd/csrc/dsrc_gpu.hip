@@ -97,7 +97,7 @@ struct dsrcgpu_handle
 	uint64_t chain_seq = 0; bool chain_taken = false; u32 chain_cap_in = 0;
 	bool chain_batch_done = true;    // the batch announced by dsrcgpu_set_chain has run to completion
 	u32* d_crc_tab = nullptr;
-	std::string err;
+	std::string err; mutable std::mutex err_m;   // written by whichever thread fails (caller, scheduler thread, collector): guarded
 	u8* last_d_out = nullptr;        // device address of the blocks the last run_batch assembled (valid until the arena is reused)
 	QBatch qb[DSRC_QUEUE_DEPTH]; u32 q_fill = 0, q_collect = 0;     // ring: batches are filled, run and collected in this order
 	u32 q_pending = 0;                                               // flushed batches that still have blocks to hand out
@@ -105,7 +105,7 @@ struct dsrcgpu_handle
 	std::mutex q_m; std::condition_variable q_cv;
 	std::thread q_thread; bool q_stop = false, q_started = false;
 	int q_rc = 0; std::string q_err;                                 // first failure of the scheduler thread (sticky)
-	float batch_ms = 0.f, rc_ms = 0.f;
+	float batch_ms = 0.f, rc_ms = 0.f, verify_ms = 0.f;
 	u32 rc_launches = 0;
 	hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 	// per-stage HIP-event timing of the last batch: pairs of events around every k_sort launch and every replay group
@@ -123,7 +123,7 @@ int fail(dsrcgpu_handle* h, int code, const char* fmt, ...)
 {
 	char buf[512];
 	va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
-	if (h) h->err = buf;
+	if (h) { std::lock_guard<std::mutex> g(h->err_m); h->err = buf; }
 	return code;
 }
 
@@ -162,7 +162,7 @@ size_t estimate_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
 	const size_t sort_slice = std::min(tot * 14, ((size_t)7168 << 20) + mx * 16);       // see slice_lo in run_batch
 	return tot * 21 / 2 + (rc ? sort_slice : 0) + (size_t)n * (1u << 20) + (16u << 20);  // measured: 10.04 x input + slice at -d3 -q2 (8-byte records)
 }
-size_t estimate_decode_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes);
+size_t estimate_decode_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes, bool own_text);
 
 struct BatchIO
 {
@@ -822,9 +822,11 @@ template <typename F> int with_arena_retry_(dsrcgpu_handle* h, size_t initial, F
 		int rc = ensure_arena(h, need);
 		if (rc) return rc;
 		rc = body();
+		// a batch that did not complete (capacity, checksum, input, memory) leaves the block-to-block state where it was: the
+		// caller may run the same batch again (grow-and-retry) and must get the blocks a fresh pass would have written
+		if (rc != DSRCGPU_OK) h->fields_cap = saved_cap;
 		if (rc != DSRCGPU_E_NOMEM || h->arena_fixed || !h->arena.failed) return rc;
 		need = std::max(h->arena.top + h->arena.top / 8, need + need / 4);      // A.top is a lower bound of what the failed pass needed
-		h->fields_cap = saved_cap;
 	}
 	return fail(h, DSRCGPU_E_NOMEM, "batch does not fit in HBM scratch after 8 attempts");
 }
@@ -1134,12 +1136,14 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 	return DSRCGPU_OK;
 }
 
-size_t estimate_decode_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
+size_t estimate_decode_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes, bool own_text)
 {
 	(void)h;
+	// measured at -d3 -q2: ~1.9 x the blocks for record tables, base stream and tree pools, + 3.2 x for the text when it is not the
+	// caller's; a pass that needs more (highly compressible data) is re-run with what it asked for (with_arena_retry_)
 	size_t tot = 0;
 	for (u32 i = 0; i < n; ++i) tot += (size_t)sizes[i] + 4096;
-	return tot * 12 + (size_t)n * (2u << 20) + (16u << 20);
+	return tot * (own_text ? 7 : 3) + (size_t)n * (1u << 20) + (16u << 20);
 }
 
 // The reference's compressing worker decodes every block it has just written and compares the checksums
@@ -1149,11 +1153,14 @@ int verify_blocks(dsrcgpu_handle* h, u32 n, const u64* offs, const u64* sizes)
 {
 	std::vector<u64> to(n), ts(n); std::vector<u32> ok(n, 0);
 	DecodeIO io{h->last_d_out, offs, sizes, n, nullptr, nullptr, 0, nullptr, 0, to.data(), ts.data(), ok.data()};
+	// dsrcgpu_last_timing keeps reporting the compression batch: the verifying pass has its own figure
+	const float c_batch = h->batch_ms, c_rc = h->rc_ms; const u32 c_launches = h->rc_launches;
 	const int rc = run_decode(h, io);
+	h->verify_ms = h->batch_ms; h->batch_ms = c_batch; h->rc_ms = c_rc; h->rc_launches = c_launches;
 	if (rc != DSRCGPU_OK)
 	{
 		if (rc == DSRCGPU_E_NOMEM) return rc;                 // the batch is re-run with a larger arena
-		const std::string why = h->err;
+		std::string why; { std::lock_guard<std::mutex> g(h->err_m); why = h->err; }
 		return fail(h, DSRCGPU_E_CRC, "CRC32 checksums mismatch. (%s)", why.c_str());
 	}
 	for (u32 i = 0; i < n; ++i)
@@ -1280,7 +1287,14 @@ void dsrcgpu_destroy(dsrcgpu_handle* h)
 	delete h;
 }
 
-const char* dsrcgpu_last_error(const dsrcgpu_handle* h) { return h ? h->err.c_str() : "null handle"; }
+const char* dsrcgpu_last_error(const dsrcgpu_handle* h)
+{
+	if (!h) return "null handle";
+	// a copy per calling thread: the scheduler thread of the queue form may fail while the caller is reading
+	static thread_local std::string copy;
+	{ std::lock_guard<std::mutex> g(h->err_m); copy = h->err; }
+	return copy.c_str();
+}
 
 int dsrcgpu_compress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_fastq, const uint64_t* offs, const uint64_t* sizes,
 								  void* d_blocks, uint64_t blocks_cap, uint64_t* block_offs, uint64_t* block_sizes,
@@ -1326,7 +1340,7 @@ int dsrcgpu_decompress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d
 	if (!h) return DSRCGPU_E_ARG;
 	if (!d_blocks || !offs || !sizes || !d_text || !text_offs || !text_sizes) return fail(h, DSRCGPU_E_ARG, "null argument");
 	HIPCHK(hipSetDevice(h->device));
-	return with_arena_retry_(h, estimate_decode_arena(h, n, sizes), [&]() {
+	return with_arena_retry_(h, estimate_decode_arena(h, n, sizes, false), [&]() {
 		DecodeIO io{(const u8*)d_blocks, offs, sizes, n, text_caps, (u8*)d_text, text_cap, nullptr, 0, text_offs, text_sizes, crc_ok};
 		return run_decode(h, io);
 	});
@@ -1342,7 +1356,7 @@ int dsrcgpu_decompress_batch(dsrcgpu_handle* h, uint32_t n, const uint8_t* const
 	std::vector<u64> offs(n);
 	size_t in_bytes = 0;
 	for (u32 i = 0; i < n; ++i) { offs[i] = in_bytes; in_bytes += al((size_t)sizes[i] + 16, 64); }
-	return with_arena_retry_(h, estimate_decode_arena(h, n, sizes) + in_bytes, [&]() {
+	return with_arena_retry_(h, estimate_decode_arena(h, n, sizes, true) + in_bytes, [&]() {
 		const size_t o_in = h->arena.alloc(in_bytes + 256);
 		if (h->arena.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (input)");
 		u8* d_in = h->arena.base + o_in;
@@ -1415,13 +1429,13 @@ void queue_thread(dsrcgpu_handle* h)
 		for (int attempt = 0; attempt < 2; ++attempt)
 		{
 			rc = pinned_grow(b.out, b.out_cap, 0, cap);
-			if (rc) { h->err = "cannot allocate page-locked output memory"; break; }
+			if (rc) { fail(h, rc, "cannot allocate page-locked output memory"); break; }
 			rc = dsrcgpu_compress_batch(h, n, ptrs.data(), b.sizes.data(), b.out, b.out_cap, b.o_offs.data(), b.o_sizes.data(), b.raw.data(), b.comp.data());
 			if (rc != DSRCGPU_E_CAPACITY) break;
 			cap = b.in_used + (u64)n * (1u << 16);
 		}
 		std::lock_guard<std::mutex> g(h->q_m);
-		b.rc = rc; if (rc) { b.err = h->err; if (!h->q_rc) { h->q_rc = rc; h->q_err = b.err; } }
+		b.rc = rc; if (rc) { { std::lock_guard<std::mutex> g(h->err_m); b.err = h->err; } if (!h->q_rc) { h->q_rc = rc; h->q_err = b.err; } }
 		b.state = QBatch::Done; b.next_collect = 0; b.outstanding = 0;
 		h->q_cv.notify_all();
 	}

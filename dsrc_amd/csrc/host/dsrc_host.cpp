@@ -700,7 +700,8 @@ void TextCaps(const std::vector<uint32>& words, const std::vector<uint64_t>& blo
 	{
 		const uint64 own = (uint64)words[i] + 1;
 		const uint64 diff = (uint64)(uint32)(words[i] - prev) + 1;
-		caps[i] = (exact && have && diff < own && diff >= blockSizes[i]) ? diff : own;
+		// second try: whichever is larger (a running total that has wrapped past 4 GiB makes `own` the small one)
+		caps[i] = exact ? ((have && diff < own && diff >= blockSizes[i]) ? diff : own) : std::max(own, have ? diff : own);
 		prev = words[i]; have = true;
 	}
 }

@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) k_selftest_dec(u32* bad)
 	for (u32 k = 0; k < 96; ++k)
 	{
 		// multiples of d, the values just below them, and a spread of others; the largest quotients included
-		const u32 q = k < 32 ? (0xFFFFFFFFu / d) >> k : (k * 2654435761u) % (0xFFFFFFFFu / d + 1u);
+		const u32 q = k < 32 ? (0xFFFFFFFFu / d) >> k : (u32)((u64)(k * 2654435761u) % ((u64)(0xFFFFFFFFu / d) + 1));
 		const u64 base = (u64)q * d;
 		const u32 ns[3] = {(u32)base, base ? (u32)(base - 1) : 0u, (u32)(base + d - 1 < 0xFFFFFFFFull ? base + d - 1 : 0xFFFFFFFFull)};
 		for (u32 j = 0; j < 3; ++j)
@@ -475,18 +475,25 @@ __global__ void __launch_bounds__(64) k_dec_dnarc(const u8* in, const DecDesc* d
 	u32* tab = tables + tb.off;
 	u8* dst = d_stream + d.d_base;
 	const u32 total = S->d_total;
-	// RangeDecoder::Start (src/RangeCoder.h:97-106)
-	struct { u64 low, buffer; u32 range; } rd;
+	// RangeDecoder::Start (src/RangeCoder.h:97-106): eight bytes; buffer < range holds on every stream an encoder writes, so the
+	// first four are zero and the buffer is 32 bits wide from here on (anything else is refused).  The step is a chain of ~150
+	// dependent instructions that 64 streams share: it is written for instruction count (32-bit products: count * r <= total * r
+	// <= range; one shift per renormalisation unless the carry clamp can fire or the window runs dry).
 	LWin win;
-	rd.buffer = lw_start(win, s); rd.low = 0; rd.range = 0xFFFFFFFFu;
-	double nf = dec_div_prep(rd.range);
-	u32 hash = 0, err = 0;
+	u32 buffer, range = 0xFFFFFFFFu, err = 0; u64 low = 0;
+	{
+		const u64 first = lw_start(win, s);
+		if (total && (first >> 32)) err |= DEC_ERR_FORMAT;
+		buffer = (u32)first;
+	}
+	double nf = dec_div_prep(range);
+	u32 hash = 0;
 	u32 cur[W];                                               // row 0 of a fresh table
 #pragma unroll
 	for (u32 w = 0; w < W; ++w) cur[w] = 0x00010001u;
 	u64 pack = 0;
 	dec_vm_drain();                                           // nothing pending at the loop's entry: the waits inside it then count only its own requests
-	for (u32 t = 0; t < total; ++t)
+	for (u32 t = 0; t < total && !err; ++t)
 	{
 		// the N candidate rows of the next symbol are consecutive and known before this symbol is
 		const u32 nbase = (hash << abits) & mask;
@@ -503,41 +510,44 @@ __global__ void __launch_bounds__(64) k_dec_dnarc(const u8* in, const DecDesc* d
 #pragma unroll
 		for (u32 k = 1; k < N; ++k) a[k] = a[k - 1] + c[k];
 		const u32 T = a[N - 1];
-		u32 r = dec_div(nf, T);
-		if (r == 0) { err |= DEC_ERR_FORMAT; r = 1; }
+		const u32 r = dec_div(nf, T);
+		if (r == 0 || buffer >= T * r) err |= DEC_ERR_FORMAT;          // range < total, or the reference walks off the row
 		u32 idx = 0, rr = 0, f = c[0];
-		if (rd.buffer >= (u64)T * r)
-		{	// not a stream the encoder writes: the reference's search with the truncated quotient
-			const u32 cul = div_u64_u32(rd.buffer, r);
-			u32 lo = 0; bool found = false;
 #pragma unroll
-			for (u32 k = 0; k < N; ++k)
-				if (!found) { if (a[k] > cul) { found = true; idx = k; f = c[k]; rr = lo * r; } lo = a[k]; }
-			if (!found) { err |= DEC_ERR_FORMAT; idx = N - 1; f = c[N - 1]; rr = (a[N - 1] - f) * r; }
-		}
-		else
+		for (u32 k = 1; k < N; ++k)
 		{
-#pragma unroll
-			for (u32 k = 1; k < N; ++k)
-			{
-				const u64 sk = (u64)a[k - 1] * r;
-				if (rd.buffer >= sk) { idx = k; rr = (u32)sk; f = c[k]; }
-			}
+			const u32 sk = a[k - 1] * r;
+			if (buffer >= sk) { idx = k; rr = sk; f = c[k]; }
 		}
-		rd.buffer -= rr; rd.low += rr;
-		rd.range = r * f;
-		while (rd.range <= 0x00FFFFFFu)
+		buffer -= rr; low += rr;
+		range = r * f;
+		if (range == 0) { err |= DEC_ERR_FORMAT; range = 0xFFFFFFFFu; }
 		{
-			if ((rd.low ^ (rd.low + rd.range)) & 0xFF00000000000000ull)
+			const u32 nb8 = range <= 0x00FFFFFFu ? (u32)__clz((int)range) >> 3 : 0u;      // bytes to shift in: 0 .. 3
+			if ((((u32)(low >> 24)) & 0xFFFFu) != 0xFFFFu && win.left >= nb8)
 			{
-				const u32 l32 = (u32)rd.low;
-				rd.range = (l32 | 0x00FFFFFFu) - l32;
+				const u32 sh = nb8 * 8;
+				range <<= sh; low <<= sh;
+				buffer = (buffer << sh) | (u32)(((u64)(u32)(win.w0 >> 32) << sh) >> 32);
+				win.w0 <<= sh; win.left -= nb8;
 			}
-			rd.buffer = (rd.buffer << 8) + lw_byte(win);
-			rd.low <<= 8; rd.range <<= 8;
-			if (rd.range == 0) { err |= DEC_ERR_FORMAT; rd.range = 0xFFFFFFFFu; break; }
+			else
+			{	// RangeDecoder::DecodeFrequency's loop as written (src/RangeCoder.h:122-135)
+				while (range <= 0x00FFFFFFu)
+				{
+					if ((low ^ (low + range)) & 0xFF00000000000000ull)
+					{
+						const u32 l32 = (u32)low;
+						range = (l32 | 0x00FFFFFFu) - l32;
+					}
+					buffer = (buffer << 8) + lw_byte(win);
+					low <<= 8; range <<= 8;
+					if (range == 0) { err |= DEC_ERR_FORMAT; range = 0xFFFFFFFFu; break; }
+				}
+			}
+			if (win.left == 0 && win.wp_pos == win.nx + 8) { win.w0 = win.w1; win.w1 = win.wp; win.nx += 8; win.left = 8; }
 		}
-		nf = dec_div_prep(rd.range);
+		nf = dec_div_prep(range);
 		// the row: +2, Rescale() now instead of at the next visit
 #pragma unroll
 		for (u32 w = 0; w < W; ++w) cur[w] += (idx >> 1) == w ? (2u << (16 * (idx & 1u))) : 0u;
@@ -576,7 +586,6 @@ __global__ void __launch_bounds__(64) k_dec_dnarc(const u8* in, const DecDesc* d
 		}
 		hash = nh;
 		win.wp = wl; win.wp_pos = wl_pos;
-		if (err) break;
 	}
 	if (total & 7u)
 	{	// d_base is 64-byte aligned and the stream's allocation is padded: the last, partial group is stored whole

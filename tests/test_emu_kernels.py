@@ -432,3 +432,21 @@ def test_bad_arguments(emu):
     with pytest.raises(emu.DsrcGpuError):
         h.compress_block(b"not a fastq chunk")
     h.close()
+
+
+def test_capacity_failure_leaves_the_block_to_block_state(emu, oracle):
+    """A batch that fails with DSRCGPU_E_CAPACITY has already folded its first titles into the capacity of the reference's
+    TagStats::fields vector (DESIGN section 1); the handle must forget that, or the grow-and-retry pattern writes blocks
+    that differ from a fresh pass (record 0's extra count of a numeric field survives only behind the last reallocation)."""
+    recs = lambda first, n: b"\n".join(b"@r.%d a:%d b:%d c:%d d:%d e:%d f:%d g:%d\nACGT\n+\nIIII" % (i, i % 7, i % 5, (i * 3) % 11, i % 3, i % 13, i % 2, i % 17)
+                                          for i in range(first, first + n))
+    chunks = [recs(1, 60), recs(61, 60)]
+    cfg = Config.from_levels(0, 0)
+    want = [oracle_block for oracle_block, _, _ in oracle.compress_blocks_state(cfg, chunks)]
+    h = emu.Handle(cfg.dna_order, cfg.quality_order)
+    with pytest.raises(emu.DsrcGpuError) as ei:
+        h.compress_batch(chunks, cap=64)
+    assert ei.value.code == -4
+    got = [r[0] for r in h.compress_batch(chunks)]
+    h.close()
+    assert got == want
