@@ -82,7 +82,7 @@ def cpu_baseline(write_sample, d: int, q: int):
     from tests._oracle import Oracle, Ref, have_ref
     # the reference's queues use a 64-bit completion mask: thread counts >= 64 are undefined
     cores = min(os.cpu_count() or 1, 60)
-    dec = None
+    dec = None; crc = None
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
         src = os.path.join(td, "s.fastq"); dst = os.path.join(td, "s.dsrc"); back = os.path.join(td, "b.fastq")
         with open(src, "wb") as f:
@@ -91,6 +91,10 @@ def cpu_baseline(write_sample, d: int, q: int):
             r = Ref()
             t = time.time(); rc = r.compress_file(src, dst, d, q, False, False, 33, 8, cores); dt = time.time() - t
             kind = "reference"
+            t = time.time(); rc3 = r.compress_file(src, dst + "c", d, q, False, True, 33, 8, cores); dt3 = time.time() - t
+            if rc3 == 0:
+                crc = {"value": round(size / dt3 / 1e6, 2), "unit": "MB/s", "cores": cores, "kind": "reference",
+                       "sample": f"`dsrc c -d{d} -q{q} -c -t{cores}` on the same {size} bytes, tmpfs to tmpfs, wall {dt3:.2f} s"}
             os.unlink(src)
             t = time.time(); rc2 = r.decompress_file(dst, back, cores); dt2 = time.time() - t
             if rc2 == 0 and os.path.getsize(back) == size:
@@ -103,7 +107,7 @@ def cpu_baseline(write_sample, d: int, q: int):
         assert rc == 0
     return {"value": round(size / dt / 1e6, 2), "unit": "MB/s", "cores": cores, "kind": kind,
             "sample": f"{size} bytes of the same synthetic FASTQ ({size // BUF + 1} blocks), -d{d} -q{q} -b8, "
-                      f"input and output in tmpfs, {cores} worker threads, wall {dt:.2f} s"}, dec
+                      f"input and output in tmpfs, {cores} worker threads, wall {dt:.2f} s"}, dec, crc
 
 
 class Lane:
@@ -246,6 +250,131 @@ def measure_decode(lanes, cfg, n_blocks, last_step, n_inst=int(os.environ.get("D
                          "note": "algorithmic bytes = block bytes in + text bytes out of a pass; a decoded stream is a chain of dependent model-row accesses, one 64-byte row fetched and written back per symbol (traffic: rocprofv3 FETCH_SIZE + WRITE_SIZE of k_dec_qrc + k_dec_dnarc per block, profiles/r03_pmc_decode_b2400.txt), and the kernels are bound by instruction issue and latency x blocks in flight, not by bandwidth (DESIGN section 11)"}}
 
 
+def measure_queue_form(cfg, device, chunks, n_handles, batches=4, per_batch=192):
+    """The form INTEGRATION.md section 1 binds in place of DsrcCompressor::Process: host-resident chunks go in through
+    dsrcgpu_submit / flush, blocks come back through dsrcgpu_collect / release (reference: src/DsrcWorker.cpp:30-73).  PCIe and the
+    copy into the page-locked ring are inside the figure.  One submitting and one collecting thread per handle, as the header allows."""
+    import ctypes as C
+    from dsrc_amd._lib import Handle
+    hs = [Handle(cfg.dna_order, cfg.quality_order, quality_offset=33, device=device) for _ in range(n_handles)]
+    L = hs[0].L
+    errs = []
+
+    def submitter(h, nb):
+        try:
+            k = 0
+            for _ in range(nb):
+                for _ in range(per_batch):
+                    c = chunks[k % len(chunks)]; k += 1
+                    while True:
+                        rc = L.dsrcgpu_submit(h.h, C.c_int64(k), c, C.c_uint64(len(c)))
+                        if rc != -8:
+                            break
+                        time.sleep(0.0005)          # ring full: the collector is behind
+                    if rc:
+                        raise RuntimeError(L.dsrcgpu_last_error(h.h).decode())
+                if L.dsrcgpu_flush(h.h):
+                    raise RuntimeError(L.dsrcgpu_last_error(h.h).decode())
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+
+    def collector(h, want):
+        pid = C.c_int64(); blk = C.POINTER(C.c_uint8)(); sz = C.c_uint64()
+        got = 0
+        try:
+            while got < want and not errs:
+                rc = L.dsrcgpu_collect(h.h, C.byref(pid), C.byref(blk), C.byref(sz), None, None)
+                if rc < 0:
+                    raise RuntimeError(L.dsrcgpu_last_error(h.h).decode())
+                if rc == 0:
+                    time.sleep(0.0005); continue
+                L.dsrcgpu_release(h.h, blk); got += 1
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+
+    def run(nb):
+        ths = []
+        for h in hs:
+            ths += [threading.Thread(target=submitter, args=(h, nb)), threading.Thread(target=collector, args=(h, nb * per_batch))]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        return time.perf_counter() - t0
+    try:
+        run(3)                                   # sizes the page-locked ring (three batches) and the arena
+        dt = run(batches)
+    finally:
+        for h in hs:
+            h.close()
+    if errs:
+        raise errs[0]
+    nbytes = sum(len(chunks[k % len(chunks)]) for k in range(batches * per_batch)) * n_handles
+    return round(nbytes / dt / 1e6, 1), nbytes, dt
+
+
+def measure_verify(cfg, ln, n_inst):
+    """-c: the compressing call decodes on the device what it has just written and compares the checksums
+    (dsrcgpu_settings::verify_after_compress; reference: DsrcCompressor::Process, src/DsrcWorker.cpp:53-62).  `n_inst` scheduler
+    instances run concurrently, each on one of instance 0's resident shards: a verifying pass is a chain of dependent reads per
+    block, so its rate is the number of blocks in flight over the chain's length."""
+    from dsrc_amd._lib import Handle
+    hs = [Handle(cfg.dna_order, cfg.quality_order, crc=True, quality_offset=33, device=ln.h.device, verify=True) for _ in range(n_inst)]
+    outs = [h.dev_alloc(ln.cap_out) for h in hs]
+    done = [0] * n_inst
+
+    def work(i, passes):
+        d_in, starts, sizes = ln.shard(i)
+        for _ in range(passes):
+            hs[i].compress_batch_device(d_in, starts, sizes, outs[i], ln.cap_out)
+            done[i] += sum(sizes)
+    try:
+        for i in range(n_inst):
+            work(i, 1)                               # warm-up: arena, table region
+        done = [0] * n_inst
+        ths = [threading.Thread(target=work, args=(i, 2)) for i in range(n_inst)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+    finally:
+        for h, o in zip(hs, outs):
+            h.dev_free(o); h.close()
+    return round(sum(done) / dt / 1e6, 1), len(ln.shard(0)[1])
+
+
+def measure_host_e2e(src, size, td, inst=4, runs=3, gap=6.0):
+    """`dsrc-amd c` and `dsrc-amd d` (C++ host over the C ABI), file in tmpfs -> archive in tmpfs -> file in tmpfs, separated runs."""
+    import subprocess
+    cli = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dsrc_amd", "csrc", "dsrc-amd")
+    arc = os.path.join(td, "e2e.dsrc"); back = os.path.join(td, "e2e_back.fastq")
+    res = {"c": [], "d": []}
+    for _ in range(runs):
+        if os.path.exists(arc):
+            os.unlink(arc)
+        time.sleep(gap)                          # the driver is still reclaiming the previous process's HBM otherwise
+        t = time.time(); subprocess.check_call([cli, "c", "-d3", "-q2", f"-t{inst}", src, arc]); res["c"].append(size / (time.time() - t) / 1e6)
+    for _ in range(runs):
+        if os.path.exists(back):
+            os.unlink(back)
+        time.sleep(gap)
+        t = time.time(); subprocess.check_call([cli, "d", f"-t{inst}", arc, back]); res["d"].append(size / (time.time() - t) / 1e6)
+    ok = os.path.getsize(back) == size
+    with open(src, "rb") as fa, open(back, "rb") as fb:          # spot comparison: 64 MiB pieces across the file
+        for o in range(0, size, max(1, size // 8)):
+            fa.seek(o); fb.seek(o); ok = ok and fa.read(64 << 20) == fb.read(64 << 20)
+    os.unlink(back); os.unlink(arc)
+    med = lambda v: sorted(v)[len(v) // 2]
+    return {"unit": "MB/s", "bytes": size, "instances": inst, "runs": runs,
+            "compress": {"min": round(min(res["c"]), 1), "median": round(med(res["c"]), 1), "all": [round(x, 1) for x in res["c"]]},
+            "decompress": {"min": round(min(res["d"]), 1), "median": round(med(res["d"]), 1), "all": [round(x, 1) for x in res["d"]]},
+            "round_trip_identical": bool(ok),
+            "note": "dsrc-amd c -d3 -q2 / dsrc-amd d, file in tmpfs to file in tmpfs, process start to exit, PCIe and file I/O included; runs separated by %.0f s" % gap}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,6 +389,7 @@ def main():
     ap.add_argument("--decode-blocks", type=int, default=int(os.environ.get("DSRC_BENCH_DECODE_BLOCKS", "2400")),
                     help="blocks of the secondary decompression measurement (0 = skip)")
     ap.add_argument("--check", type=int, default=2, help="blocks of the first sub-batch to verify against the oracle")
+    ap.add_argument("--dump-step", default=None, help="N > 1 code path only (tests): rank 0 writes the gathered block stream of the last step as an archive (gathered.dsrc) and the FASTQ text of that step (step.fastq) into this directory")
     args = ap.parse_args()
 
     # Every scheduler instance drives two HIP streams (front end + range coder).  The HIP runtime multiplexes streams onto
@@ -307,13 +437,21 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def gather_step(step):
+    # rank 0 receives every peer's stream of one scheduler instance into buffers allocated once (not inside the timed region);
+    # the gathers of a step run one instance after the other on the main thread, so one set is enough
+    recv_bufs = None
+    if dist is not None and rank == 0 and world > 1:
+        recv_bufs = [None] + [torch.empty(lanes[0].cap_out, dtype=torch.uint8, device="cuda") for _ in range(1, world)]
+
+    def gather_step(step, keep=None):
         if dist is None:
             return
         from dsrc_amd.dist import gather_block_stream
-        for ln in lanes:
+        for li, ln in enumerate(lanes):
             _, o_sizes, _, _ = ln.results[step]
-            gather_block_stream(o_sizes, ln.outs[step % len(ln.outs)][1])
+            res = gather_block_stream(o_sizes, ln.outs[step % len(ln.outs)][1], recv_bufs=recv_bufs)
+            if keep is not None:
+                keep(li, ln, res)
 
     # ---- warmup (also sizes the arenas and measures one sub-batch for the stagger) ------------------------
     t_sub = 0.0
@@ -403,8 +541,49 @@ def main():
             assert got == o.compress_block(cfg, chunk)[0], f"bench parity check failed: instance {li}, last block of the timed region"
             checked += 1
 
+    per_rank = None; gather_verified = None
     if dist is not None:
+        # ---- one more gather of the last step, checked (outside the timed region): the footer table rank 0 assembled is every rank's
+        # own list of block sizes, and the bytes rank 0 holds for rank r have the md5 rank r computed of its own buffer
+        import hashlib
+        last = total_steps - 1
+        mine = []
+        for ln in lanes:
+            _, o_sizes, _, _ = ln.results[last]
+            mine.append((list(o_sizes), hashlib.md5(ln.h.dev_download(ln.outs[last % len(ln.outs)][0], sum(o_sizes))).hexdigest()))
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        verdicts = []; dumped = []
+
+        def keep(li, ln, res):
+            if rank != 0:
+                return
+            sizes, bufs = res
+            want_sizes = [x for r in range(world) for x in everyone[r][li][0]]
+            ok = sizes == want_sizes
+            for r in range(world):
+                ok = ok and hashlib.md5(bufs[r].cpu().numpy().tobytes()).hexdigest() == everyone[r][li][1]
+            verdicts.append(bool(ok))
+            if args.dump_step:
+                dumped.append((sizes, [b.cpu().numpy().tobytes() for b in bufs]))
+        gather_step(last, keep)
+        if rank == 0:
+            gather_verified = bool(verdicts) and all(verdicts)
+            if args.dump_step:
+                from dsrc_amd.dist import archive_bytes
+                os.makedirs(args.dump_step, exist_ok=True)
+                sizes = [x for sz, _ in dumped for x in sz]
+                with open(os.path.join(args.dump_step, "gathered.dsrc"), "wb") as f:
+                    f.write(archive_bytes(sizes, [p for _, bl in dumped for p in bl], dna_order=cfg.dna_order, quality_order=cfg.quality_order, lossy=False,
+                                          crc=False, tag_flags=0, quality_offset=33, plus_repetition=False, color_space=False))
+                with open(os.path.join(args.dump_step, "step.fastq"), "wb") as f:          # this rank's records of that step, instance by instance
+                    for ln in lanes:
+                        d_in, starts, szs = ln.shard(last)
+                        f.write(ln.h.dev_download(d_in + starts[0], starts[-1] + szs[-1] + 1 - starts[0]))
         t = torch.tensor([wall, float(in_bytes), float(out_bytes)], device="cuda", dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [round(float(x[1]) / float(x[0]) / 1e6, 1) for x in allt]
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         wall = float(tmax[0]); in_bytes = float(tsum[1]); out_bytes = float(tsum[2])
@@ -426,7 +605,9 @@ def main():
             "config": {"workload": f"Synthetic Illumina 150 bp FASTQ, 100M-read data set shape (BASELINE configs[2]), -d{args.dna} -q{args.qua} -b8; "
                                    f"step = {args.blocks} consecutive 8 MiB chunks per GPU, device-resident, {P} scheduler instances per GPU",
                        "blocks_per_step": args.blocks, "pipeline": P,
-                       "parallelism": f"blocks sharded over {world} GPU(s); per-step RCCL gather of the block stream to rank 0" if world > 1 else "1 GPU",
+                       "parallelism": (f"{world} process(es), one per GPU: contiguous partId ranges, no data-path collective; per step the block sizes are all-gathered and "
+                                       f"every rank's block stream goes to rank 0 by point-to-point send (RCCL), overlapped with the next step") if dist is not None else "1 GPU",
+                       **({"per_rank_MB_per_s": per_rank, "gather_verified": gather_verified} if dist is not None else {}),
                        "ratio_out_in": round(out_bytes / in_bytes, 4), "parity_checked_blocks": checked},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
@@ -472,9 +653,40 @@ def main():
                     if k >= ln.n_res and left > 0:
                         k = 0          # fewer distinct shards than asked for: the sample repeats them
                 return total
-            line["cpu_baseline"], dec_cpu = cpu_baseline(write_sample, args.dna, args.qua)
+            line["cpu_baseline"], dec_cpu, crc_cpu = cpu_baseline(write_sample, args.dna, args.qua)
             if decode_line and dec_cpu:
                 line["decompress"]["cpu_baseline"] = dec_cpu
+            # ---- the forms a user calls (task 6): verify, queue form, the CLI end to end -------------------
+            if not os.environ.get("DSRC_BENCH_NO_FORMS"):
+                try:
+                    v1, nb = measure_verify(cfg, ln, 1)
+                    v4, _ = measure_verify(cfg, ln, 4)
+                    line["verify"] = {"value": v4, "unit": "MB/s", "blocks_per_call": nb, "instances": 4, "one_instance": v1,
+                                      "what": "-d3 -q2 -c: dsrcgpu_compress_batch_device with calculate_crc32 + verify_after_compress (the blocks are decoded on the device and the three CRC-32 compared), inputs and outputs in HBM",
+                                      "cpu_baseline": crc_cpu}
+                    d_in, starts, sizes = ln.shard(0)
+                    n_host = min(len(starts), 192)
+                    chunks = [ln.h.dev_download(d_in + starts[i], sizes[i]) for i in range(n_host)]
+                    q = {}
+                    for nh in (1, 2):
+                        mbs, nbytes, dt = measure_queue_form(cfg, ln.h.device, chunks, nh)
+                        q[f"handles_{nh}"] = {"value": mbs, "unit": "MB/s", "bytes": nbytes, "s": round(dt, 2)}
+                    q["what"] = "dsrcgpu_submit / flush / collect / release with host-resident 8 MiB chunks, 192 chunks per flush, one submitting and one collecting thread per handle; host copy into the page-locked ring, PCIe both ways and the compression inside"
+                    line["queue_form"] = q
+                    del chunks
+                    # the CLI: a >= 16 GB file in tmpfs; every GPU resource of this process is released first
+                    import tempfile
+                    e2e_blocks = int(os.environ.get("DSRC_BENCH_E2E_BLOCKS", "1920"))
+                    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+                        src = os.path.join(td, "e2e.fastq")
+                        need = e2e_blocks
+                        with open(src, "wb") as f:
+                            size = write_sample(f)
+                        for l2 in lanes:
+                            l2.h.close()
+                        line["host_e2e"] = measure_host_e2e(src, size, td)
+                except Exception as e:          # noqa: BLE001  (secondary measurements must not take the headline line with them)
+                    line["forms_error"] = repr(e)
         out_line = json.dumps(line)
     for ln in lanes:
         ln.h.close()          # idempotent

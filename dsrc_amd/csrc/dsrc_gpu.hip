@@ -1629,8 +1629,18 @@ int dsrcgpu_device_memory(int device, uint64_t* free_bytes, uint64_t* total_byte
 	return DSRCGPU_OK;
 }
 
+// Every scheduler instance drives two HIP streams, and the HIP runtime multiplexes streams onto 4 hardware queues unless
+// GPU_MAX_HW_QUEUES says otherwise: unrelated instances then wait behind each other's range coder (7.7 instead of 12.9 GB/s,
+// DESIGN section 3).  The runtime reads the variable when it starts, i.e. at the process's first HIP call: it is set (when the
+// embedding process has not chosen a value) as soon as this library is loaded, and again by dsrcgpu_prepare for hosts that load
+// the library late; a process that has already used HIP keeps what it started with.
+#ifndef DSRC_EMU_BUILD
+__attribute__((constructor)) static void dsrcgpu_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+#endif
+
 int dsrcgpu_prepare(int device)
 {
+	setenv("GPU_MAX_HW_QUEUES", "24", 0);
 	// first touch of a device: the HIP runtime loads the code objects and creates the context (0.3-1 s); hosts call this
 	// on a side thread while they open files, so that dsrcgpu_create finds the device ready
 	if (hipSetDevice(device) != hipSuccess) return DSRCGPU_E_HIP;

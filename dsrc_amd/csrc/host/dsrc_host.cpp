@@ -2,6 +2,7 @@
 #include "dsrc_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -14,6 +15,7 @@
 #include <chrono>
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -726,7 +728,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 	{
 		rd.Open(args.inputFilename);
 		if (args.useFastqStdIo) out = stdout;
-		else { out = fopen(args.outputFilename.c_str(), "wb"); if (!out) throw DsrcException("Cannot open file to write:" + args.outputFilename); }
+		else { out = fopen(args.outputFilename.c_str(), "w+b"); if (!out) throw DsrcException("Cannot open file to write:" + args.outputFilename); }      // readable too: the output is mapped
 
 		const uint64 nBlocks = rd.BlockCount();
 		// A decoding pass is a chain per block: it takes about as long for 1000 blocks as for 10, so
@@ -755,14 +757,88 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 			uint64_t freeB = 0, totalB = 0;
 			if (dsrcgpu_device_memory(devs[0], &freeB, &totalB) == DSRCGPU_OK) tableShare = freeB / 100 * 60 / std::max<uint32>(1, (instances + (uint32)devs.size() - 1) / (uint32)devs.size());
 		}
-		uint64 next = 0, writeTurn = 0;
+		uint64 next = 0, writeTurn = 0, outPos = 0, mappedDone = 0;
 
+		// ---- a regular file as output: decode straight into its mapping -----------------------------------------------------------
+		// A block written from a FASTQ file declares its chunk size, so where every block's text goes is known before anything is
+		// decoded: the file is sized and mapped, helper threads fault its pages in (in batch order) while the GPU decodes, and the
+		// device-to-host copy of a batch lands in the file -- no text buffer, no second copy, no write.  Archives whose chunk-size
+		// words are running totals (record-level API) or whose texts come out shorter than declared take the buffered path below.
+		uchar* map = nullptr; uint64 mapBytes = 0;
+		std::vector<uint64> mapAt(batches.size(), 0);
+		std::vector<std::vector<uint64_t> > mapCaps(batches.size());
+		std::vector<std::thread> faulters;
+		std::atomic<bool> mapBroken(false);
+		struct MapGuard          // whatever way this scope is left: helper threads joined, mapping gone
+		{
+			std::vector<std::thread>& th; uchar*& p; uint64& n;
+			~MapGuard() { for (auto& t : th) if (t.joinable()) t.join(); if (p) munmap(p, n); p = nullptr; }
+		} mapGuard{faulters, map, mapBytes};
+		if (out != stdout && !getenv("DSRC_HOST_NO_MMAP") && nBlocks)
+		{
+			std::vector<uint32> words(nBlocks); std::vector<uint64_t> bsz(nBlocks);
+			bool ok = true;
+			for (uint64 i = 0; i < nBlocks && ok; ++i)
+			{
+				uchar hb[16]; bsz[i] = rd.BlockSizes()[i];
+				ok = bsz[i] >= 16 && pread(rd.Fd(), hb, 16, (off_t)rd.BlockOffset(i)) == 16;
+				if (ok) words[i] = (uint32)GetBE(hb + 12, 4);
+			}
+			// chunks cut from a file are all of one size within the 8 KiB the cutter looks ahead plus a record (src/FastqStream.cpp:18-72);
+			// running totals (record-level archives) grow by a chunk per block: those are not sizes
+			if (ok && nBlocks >= 2)
+			{
+				uint32 lo = words[0], hi = words[0];
+				for (uint64 i = 1; i + 1 < nBlocks; ++i) { lo = std::min(lo, words[i]); hi = std::max(hi, words[i]); }
+				if (hi - lo > (64u << 10) || words[nBlocks - 1] > hi + (64u << 10)) ok = false;
+			}
+			if (ok)
+			{
+				uint64 total = 0;
+				for (size_t k = 0; k < batches.size(); ++k)
+				{
+					mapAt[k] = total;
+					for (uint64 i = batches[k].first; i < batches[k].second; ++i) { mapCaps[k].push_back((uint64)words[i] + 1); total += (uint64)words[i] + 1; }
+				}
+				if (total && ftruncate(fileno(out), (off_t)total) == 0)
+				{
+					void* q = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fileno(out), 0);
+					if (q != MAP_FAILED)
+					{
+						map = (uchar*)q; mapBytes = total;
+						auto fault = [&, total](uint32 t, uint32 nt)
+						{	// 64 MiB pieces, in file order, round-robin over the threads
+							const uint64 piece = 64ull << 20;
+							for (uint64 o = (uint64)t * piece; o < total; o += (uint64)nt * piece)
+							{
+								const uint64 len = std::min<uint64>(piece, total - o);
+#ifdef MADV_POPULATE_WRITE
+								if (madvise(map + o, len, MADV_POPULATE_WRITE) == 0) continue;
+#endif
+								for (uint64 x = 0; x < len; x += 4096) (void)((volatile const uchar*)map)[o + x];      // a read: the decoded bytes may be there already
+							}
+						};
+						for (uint32 t = 0; t < 6; ++t) faulters.emplace_back(fault, t, 6u);
+					}
+					else if (ftruncate(fileno(out), 0) != 0) throw DsrcException("Error writing FASTQ output");
+				}
+			}
+		}
+
+		const bool trace = getenv("DSRC_HOST_TRACE") != nullptr;
+		const auto t0 = std::chrono::steady_clock::now();
+		auto mark = [&](uint32 idx, uint64 k, const char* what)
+		{
+			if (trace) fprintf(stderr, "[dsrc-amd d] worker %u batch %llu %-10s %8.1f ms\n", idx, (unsigned long long)k, what,
+							   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+		};
 		auto work = [&](uint32 idx)
 		{
 			dsrcgpu_handle* h = nullptr;
 			try
 			{
 				h = CreateDecodeInstance(devs[idx % devs.size()], rd.Settings(), rd.Type());
+				mark(idx, 0, "instance");
 				if (tableShare) dsrcgpu_set_table_budget(h, tableShare);
 				Pinned in, text;
 				for (;;)
@@ -777,11 +853,25 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 					std::vector<uint64_t> sizes(n), at(n), offs(n), tsz(n), caps;
 					uint64 inBytes = 0;
 					for (uint32 i = 0; i < n; ++i) { sizes[i] = rd.BlockSizes()[lo + i]; at[i] = inBytes; inBytes += (sizes[i] + 64) & ~(uint64)63; }
+					mark(idx, k, "start");
 					in.Reserve(inBytes);
 					std::vector<const uint8_t*> ptrs(n); std::vector<uint32> words(n);
+					{	// the blocks of the batch, read by up to 4 threads (positioned reads)
+						std::atomic<uint32> nextBlock(0); std::atomic<bool> bad(false);
+						auto get = [&]()
+						{
+							try { for (uint32 i; (i = nextBlock++) < n;) rd.ReadBlock(lo + i, in.p + at[i]); }
+							catch (...) { bad = true; }
+						};
+						std::vector<std::thread> rs;
+						for (uint32 t = 1; t < std::min<uint32>(4, n); ++t) rs.emplace_back(get);
+						get();
+						for (auto& t : rs) t.join();
+						if (bad) throw DsrcException("Error reading the DSRC archive");
+					}
 					for (uint32 i = 0; i < n; ++i)
 					{
-						rd.ReadBlock(lo + i, in.p + at[i]); ptrs[i] = in.p + at[i];
+						ptrs[i] = in.p + at[i];
 						if (sizes[i] < 16) throw DsrcException("Corrupted DSRC archive: block too small");
 						words[i] = (uint32)GetBE(ptrs[i] + 12, 4);
 					}
@@ -792,32 +882,94 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 						uchar hb[16];
 						if (rd.BlockSizes()[lo - 1] >= 16 && pread(rd.Fd(), hb, 16, (off_t)rd.BlockOffset(lo - 1)) == 16) { before = (uint32)GetBE(hb + 12, 4); haveBefore = true; }
 					}
+					mark(idx, k, "read");
 					int rc = DSRCGPU_OK;
+					if (map && !mapBroken)
+					{
+						uint64 cap = 0; for (uint64 c : mapCaps[k]) cap += c;
+						rc = dsrcgpu_decompress_batch(h, n, ptrs.data(), sizes.data(), mapCaps[k].data(), map + mapAt[k], cap, offs.data(), tsz.data(), nullptr);
+						bool exact = rc == DSRCGPU_OK;
+						for (uint32 i = 0; i < n && exact; ++i) exact = tsz[i] == mapCaps[k][i];
+						if (exact)
+						{
+							mark(idx, k, "decoded");
+							std::lock_guard<std::mutex> g(m);
+							++mappedDone; cv.notify_all();
+							continue;
+						}
+						if (rc != DSRCGPU_OK && rc != DSRCGPU_E_CAPACITY) throw DsrcException(dsrcgpu_last_error(h));
+						// the declared sizes are not where the texts end: this archive goes the buffered way, from the start
+						std::lock_guard<std::mutex> g(m);
+						mapBroken = true; cv.notify_all();
+						throw DsrcException("__remap__");
+					}
 					for (int attempt = 0; attempt < 2; ++attempt)
 					{
 						TextCaps(words, sizes, before, haveBefore, attempt == 0, caps);
 						uint64 cap = 0; for (uint64 c : caps) cap += c;
 						text.Reserve(cap + 64);
+						mark(idx, k, "reserved");
 						rc = dsrcgpu_decompress_batch(h, n, ptrs.data(), sizes.data(), caps.data(), text.p, text.cap, offs.data(), tsz.data(), nullptr);
 						if (rc != DSRCGPU_E_CAPACITY) break;
 					}
 					if (rc != DSRCGPU_OK) throw DsrcException(dsrcgpu_last_error(h));
+					mark(idx, k, "decoded");
+					uint64 total = 0; for (uint32 i = 0; i < n; ++i) total += tsz[i];
+					uint64 fileAt = 0;
 					{
 						std::unique_lock<std::mutex> g(m);
 						cv.wait(g, [&] { return !error.empty() || writeTurn == k; });
 						if (!error.empty()) break;
+						// a file: the batch claims its range (that needs the sizes of the batches before it, not their bytes) and
+						// passes the turn on at once; a pipe: the bytes go out in turn
+						if (out != stdout) { fileAt = outPos; outPos += total; ++writeTurn; cv.notify_all(); }
 					}
 					// texts are laid out back to back; they are contiguous whenever every block fills its reservation
+					std::vector<std::pair<uint64, uint64> > runs;           // (offset in text.p, length)
 					for (uint32 i = 0; i < n;)
 					{
 						uint32 j = i; uint64 len = tsz[i];
 						while (j + 1 < n && offs[j] + tsz[j] == offs[j + 1]) { ++j; len += tsz[j]; }
-						if (len && fwrite(text.p + offs[i], 1, len, out) != len) throw DsrcException("Error writing FASTQ output (disk full?)");
+						if (len) runs.emplace_back(offs[i], len);
 						i = j + 1;
 					}
+					if (out == stdout)
 					{
+						for (const auto& r : runs)
+							if (fwrite(text.p + r.first, 1, r.second, out) != r.second) throw DsrcException("Error writing FASTQ output (disk full?)");
 						std::lock_guard<std::mutex> g(m);
 						++writeTurn; cv.notify_all();
+					}
+					else
+					{	// positioned writes, 32 MiB pieces, by up to 8 threads (one thread copies into the page cache at ~2 GB/s)
+						struct Piece { const uchar* p; uint64 n; uint64 at; };
+						std::vector<Piece> pieces;
+						uint64 at = fileAt;
+						for (const auto& r : runs)
+						{
+							for (uint64 o = 0; o < r.second; o += 32ull << 20) pieces.push_back({text.p + r.first + o, std::min<uint64>(32ull << 20, r.second - o), at + o});
+							at += r.second;
+						}
+						std::atomic<size_t> nextPiece(0); std::atomic<bool> bad(false);
+						auto put = [&]()
+						{
+							for (size_t q; (q = nextPiece++) < pieces.size();)
+							{
+								const Piece& pc = pieces[q];
+								for (uint64 done = 0; done < pc.n;)
+								{
+									const ssize_t w = pwrite(fileno(out), pc.p + done, pc.n - done, (off_t)(pc.at + done));
+									if (w <= 0) { bad = true; return; }
+									done += (uint64)w;
+								}
+							}
+						};
+						std::vector<std::thread> ws;
+						for (size_t t = 1; t < std::min<size_t>(8, pieces.size()); ++t) ws.emplace_back(put);
+						put();
+						for (auto& t : ws) t.join();
+						if (bad) throw DsrcException("Error writing FASTQ output (disk full?)");
+						mark(idx, k, "written");
 					}
 				}
 			}
@@ -827,6 +979,20 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 		for (uint32 i = 0; i < instances; ++i) workers.emplace_back(work, i);
 		for (auto& t : workers) t.join();
 		workers.clear();
+		for (auto& t : faulters) t.join();
+		faulters.clear();
+		if (map)
+		{
+			munmap(map, mapBytes); map = nullptr;
+			if (mapBroken)
+			{	// once more without the mapping (record-level archives, texts shorter than declared)
+				if (ftruncate(fileno(out), 0) != 0) throw DsrcException("Error writing FASTQ output");
+				error.clear(); next = 0; writeTurn = 0; outPos = 0;
+				for (uint32 i = 0; i < instances; ++i) workers.emplace_back(work, i);
+				for (auto& t : workers) t.join();
+				workers.clear();
+			}
+		}
 		if (!error.empty()) throw DsrcException(error);
 		if (out != stdout) { FILE* f = out; out = nullptr; if (fclose(f) != 0) throw DsrcException("Error writing FASTQ output (disk full?)"); }
 		else fflush(stdout);

@@ -349,8 +349,13 @@ __global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* 
 			const u32 j = j0 + lane;
 			const bool in_r = j < len;
 			u32 sidx = 0, q = 0; bool keep = false;
-			if (in_r) q = j0 ? transform_base<FAST_STATS>(p[so + j], p[qo + j], prm.quality_offset, prm.lossy, &sidx, &keep)
-							 : transform_base<FAST_STATS>(c_b, c_q, prm.quality_offset, prm.lossy, &sidx, &keep);
+			{	// the transform on every lane, `in_r` applied afterwards: the form k_prep_write needed on gfx950 (see there); lanes past the
+				// end of the read take a harmless stand-in
+				u32 cb = 'A', cq = prm.quality_offset + 40u;
+				if (in_r) { cb = j0 ? (u32)p[so + j] : c_b; cq = j0 ? (u32)p[qo + j] : c_q; }
+				const u32 qq = transform_base<FAST_STATS>(cb, cq, prm.quality_offset, prm.lossy, &sidx, &keep);
+				if (in_r) q = qq; else { keep = false; sidx = 0; }
+			}
 			const bool k2 = in_r && keep;
 			if (in_r) atomicAdd(&s_qf[q], 1u);
 			if (in_r && sidx >= 20) a_bad = 1;
@@ -490,9 +495,13 @@ __global__ void __launch_bounds__(WG) k_prep_write(const u8* in, const BlkDesc* 
 			{	// every lane evaluates the (branch-free) transform, lanes past the end of the read on a harmless stand-in: with the call
 				// inside `if (in_r)` this kernel gave a wrong quality stream on the GPU once dna_index had become selects (DESIGN.md
 				// section 10) -- the emulator build, the function on its own and k_prep_stats with the same call were all right
+#ifdef DSRC_PREP_WRITE_IN_IF          // tools/r03_prep_write_repro.sh: the form that miscompared in round 2, kept to be able to reproduce and diff it
+				if (in_r) q = transform_base<FAST_WRITE>(p[so + j], p[qo + j], prm.quality_offset, prm.lossy, &sidx, &keep);
+#else
 				const u32 cb = in_r ? (u32)p[so + j] : (u32)'A', cq = in_r ? (u32)p[qo + j] : prm.quality_offset + 40u;
 				const u32 qq = transform_base<FAST_WRITE>(cb, cq, prm.quality_offset, prm.lossy, &sidx, &keep);
 				if (in_r) q = qq; else { keep = false; sidx = 0; }
+#endif
 			}
 			const bool k2 = in_r && keep;
 			const u64 km = __ballot(k2);

@@ -27,10 +27,13 @@ def shard_range(n_parts: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_block_stream(block_sizes: List[int], payload: torch.Tensor, group=None) -> Optional[Tuple[List[int], List[torch.Tensor]]]:
+def gather_block_stream(block_sizes: List[int], payload: torch.Tensor, group=None,
+                        recv_bufs: Optional[List[torch.Tensor]] = None) -> Optional[Tuple[List[int], List[torch.Tensor]]]:
     """Gather every rank's (block_sizes, concatenated blocks) to rank 0.
 
     payload: 1-D uint8 tensor holding this rank's blocks back to back (on the device for nccl).
+    recv_bufs: optional, rank 0 only: one pre-allocated uint8 tensor per rank (entry 0 unused) that the peers' streams are
+    received into -- a caller that gathers inside a timed loop allocates them once.
     Returns on rank 0: (all block sizes in archive order, [payload tensor of rank 0, 1, ...]); None elsewhere.
     """
     world = dist.get_world_size(group)
@@ -51,7 +54,11 @@ def gather_block_stream(block_sizes: List[int], payload: torch.Tensor, group=Non
     dist.all_gather(allsz, mine, group=group)
     # 2) payloads: direct send to rank 0
     if rank == 0:
-        bufs = [payload[:total]] + [torch.empty(totals[r], dtype=torch.uint8, device=dev) for r in range(1, world)]
+        if recv_bufs is not None:
+            assert all(recv_bufs[r].numel() >= totals[r] for r in range(1, world)), "receive buffer smaller than a peer's stream"
+            bufs = [payload[:total]] + [recv_bufs[r][: totals[r]] for r in range(1, world)]
+        else:
+            bufs = [payload[:total]] + [torch.empty(totals[r], dtype=torch.uint8, device=dev) for r in range(1, world)]
         ops = [dist.P2POp(dist.irecv, bufs[r], r, group) for r in range(1, world) if totals[r] > 0]
         if ops:
             for w in dist.batch_isend_irecv(ops):

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def gpu():
-    os.environ.pop("DSRC_GPU_LIB", None)
+    if not os.environ.get("DSRC_TEST_KEEP_GPU_LIB"):          # tools/r03_prep_write_repro.sh runs this suite on a variant build
+        os.environ.pop("DSRC_GPU_LIB", None)
     from dsrc_amd import _lib
     _lib._lib = None
     return _lib
@@ -273,3 +274,27 @@ def test_device_synth_matches_host(gpu):
     got = h.dev_download(d, n)
     h.dev_free(d); h.close()
     assert got == synth.illumina_fastq(3000)
+
+
+@pytest.mark.parametrize("d,q,lossy", [(0, 0, False), (3, 2, False), (0, 2, False), (2, 1, True), (0, 0, True)])
+def test_read_lengths_at_wave_boundaries(gpu, oracle, d, q, lossy):
+    """Reads of 1, 63, 64, 65, 127, 128, 129, 255, 256, 257 and 65 535 (2 000 at -q0) bases with hoisted (quality < 7) and kept ambiguity codes in
+    the first, last and 64th lane of a 64-base step: the per-base transform and the stream compaction of k_prep_stats / k_prep_write
+    (LosslessRecordsProcessor::ProcessForward, src/RecordsProcessor.cpp:209-267; lossy :344-408) where a wave's `in the read`
+    mask changes.  (Round 2 saw a GPU-only wrong quality stream from k_prep_write with the transform called under that mask,
+    DESIGN.md section 10; bit-exact blocks over these lengths pin the streams both kernels write.)"""
+    import random
+    rng = random.Random(11 * d + q)
+    amb = b"N" if (d > 0 and not lossy) else b"NRYKMSW"          # lossless order-k DNA takes at most 8 symbols (SURVEY Appendix B)
+    recs = []
+    for rep in range(3):
+        for n in (1, 63, 64, 65, 127, 128, 129, 255, 256, 257, (65535 if q else 2000) if rep == 0 else 300):          # -q0: one Huffman tree per position
+            seq = bytearray(rng.choice(b"ACGT") for _ in range(n))
+            qua = bytearray(33 + rng.randint(8, 40) for _ in range(n))
+            for pos in (0, 62, 63, 64, 65, 126, 127, 128, n - 2, n - 1):
+                if 0 <= pos < n and rng.random() < 0.8:
+                    seq[pos] = rng.choice(amb)
+                    qua[pos] = 33 + (rng.randint(0, 6) if rng.random() < 0.6 else rng.randint(7, 40))          # hoisted / kept
+            recs.append(b"@b.%d.%d len=%d\n%s\n+\n%s" % (rep, n, n, bytes(seq), bytes(qua)))
+    data = b"\n".join(recs)
+    _check(gpu, oracle, Config.from_levels(d, q, lossy), [data, data[: data.index(b"\n@b.1.")]])
