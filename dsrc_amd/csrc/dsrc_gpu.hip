@@ -36,6 +36,7 @@
 #include "k_dec.h"
 #include "k_dec_rc.h"
 #include "k_dec_tags.h"
+#include "k_dec_q0.h"
 
 namespace
 {
@@ -999,7 +1000,12 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(DecDesc) * B, hipMemcpyHostToDevice, s));
 	if (prm.serial_quality) { hipLaunchKernelGGL(k_dec_tags, dim3(B), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), AP<u8>(h, o_fld), prm); KCHK(); }
 	else { hipLaunchKernelGGL(k_dec_tags_wave, dim3(B), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), AP<u8>(h, o_fld), prm); KCHK(); }
-	if (!q_rc) { hipLaunchKernelGGL(k_dec_qhuff, dim3(B), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), prm); KCHK(); }
+	if (!q_rc)
+	{	// -q0: the position schemes through per-position 6-bit tables (k_dec_q0.h), whatever that does not cover (RLE scheme, long reads,
+		// large alphabets) bit by bit (k_dec_qhuff, which skips the blocks the first one has done)
+		if (!prm.serial_quality) { hipLaunchKernelGGL(k_dec_qpos, dim3(B), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), prm); KCHK(); }
+		hipLaunchKernelGGL(k_dec_qhuff, dim3(B), dim3(64), 0, s, io.d_in, d_desc, d_state, rp, d_out, AP<u32>(h, o_nodes), prm); KCHK();
+	}
 
 	if (prm.serial_quality)
 	{	// the one-lane decoder: a slot of the worst-case size per wave, the waves loop over the blocks

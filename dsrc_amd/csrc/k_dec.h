@@ -60,7 +60,8 @@ struct DecState         // device -> host, and device scratch between the stages
 	u32 q_total, d_total;
 	u32 q_scheme, d_scheme;
 	u32 q_cnt;                              // order-context quality: symbols present (the alphabet's presence bitmap)
-	u32 pad[2];
+	u32 q_done;                             // -q0: k_dec_qpos (k_dec_q0.h) has decoded the quality stream, k_dec_qhuff leaves the block alone
+	u32 pad[1];
 };
 
 struct DecField
@@ -888,7 +889,7 @@ __global__ void __launch_bounds__(64) k_dec_qhuff(const u8* in, const DecDesc* d
 	__shared__ u32 s_par[8];
 	const u32 b = blockIdx.x;
 	DecState* S = &st[b];
-	if (S->err) return;                                   // wave-uniform
+	if (S->err || S->q_done) return;                      // wave-uniform
 	const DecDesc d = desc[b];
 	u8* text = out + d.out_off;
 	BitSrc s; s.p = in + d.in_off; s.size = d.in_size; s.err = 0; s.bit = (u64)S->qua_pos * 8;
