@@ -386,7 +386,7 @@ def main():
     ap.add_argument("--qua", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-blocks", type=int, default=int(os.environ.get("DSRC_BENCH_CPU_BLOCKS", "480")), help="8 MiB chunks of the CPU baseline sample (480 = 4 GB)")
-    ap.add_argument("--decode-blocks", type=int, default=int(os.environ.get("DSRC_BENCH_DECODE_BLOCKS", "2400")),
+    ap.add_argument("--decode-blocks", type=int, default=int(os.environ.get("DSRC_BENCH_DECODE_BLOCKS", "3600")),
                     help="blocks of the secondary decompression measurement (0 = skip)")
     ap.add_argument("--check", type=int, default=2, help="blocks of the first sub-batch to verify against the oracle")
     ap.add_argument("--dump-step", default=None, help="N > 1 code path only (tests): rank 0 writes the gathered block stream of the last step as an archive (gathered.dsrc) and the FASTQ text of that step (step.fastq) into this directory")

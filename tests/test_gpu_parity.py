@@ -298,3 +298,30 @@ def test_read_lengths_at_wave_boundaries(gpu, oracle, d, q, lossy):
             recs.append(b"@b.%d.%d len=%d\n%s\n+\n%s" % (rep, n, n, bytes(seq), bytes(qua)))
     data = b"\n".join(recs)
     _check(gpu, oracle, Config.from_levels(d, q, lossy), [data, data[: data.index(b"\n@b.1.")]])
+
+
+@pytest.mark.timeout(1500)
+def test_one_block_of_a_gigabyte(gpu, oracle):
+    """`-b1024` at the order levels (the reference accepts buffer sizes of 1 .. 1024 MB, src/main.cpp:300-305): one chunk of 1 GiB --
+    ~430 M bases and as many qualities per stream, 3.4 GB of 8-byte records per range-coder chain (the 32-bit byte offsets of k_rc
+    reach 4 GiB = 536 M symbols) -- against the oracle, by digest."""
+    import hashlib
+    n = (1 << 30) - (1 << 20)
+    h = gpu.Handle()
+    recs = 2_900_000
+    d = h.dev_alloc(recs * 400)
+    nbytes = h.synth_illumina(1, recs, d, recs * 400)
+    assert nbytes > n
+    text = h.dev_download(d, n + 4096)
+    h.dev_free(d); h.close()
+    end = text.rindex(b"\n@SRRSYN.", 0, n)                 # a record boundary below 1 GiB
+    chunk = text[:end]
+    del text
+    assert len(chunk) > (1 << 30) - (2 << 20)
+    cfg = Config.from_levels(3, 2)
+    h = gpu.Handle(cfg.dna_order, cfg.quality_order)
+    got = h.compress_batch([chunk])[0]
+    h.close()
+    want = oracle.compress_block(cfg, chunk)
+    assert len(got[0]) == len(want[0]) and hashlib.sha256(got[0]).digest() == hashlib.sha256(want[0]).digest()
+    assert got[1] == want[1] and got[2] == want[2]

@@ -6,9 +6,9 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 C=dsrc_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -Wno-unused-result"
-/opt/rocm/bin/hipcc $FLAGS -shared -fPIC -DDSRC_PREP_WRITE_IN_IF -o /tmp/libdsrc_gpu_bad.so $C/dsrc_gpu.hip
+/opt/rocm/bin/hipcc $FLAGS -shared -fPIC -DDSRC_PREP_WRITE_IN_IF=1 -o /tmp/libdsrc_gpu_bad.so $C/dsrc_gpu.hip
 for v in good bad; do
-  D=""; [ $v = bad ] && D="-DDSRC_PREP_WRITE_IN_IF"
+  D=""; [ $v = bad ] && D="-DDSRC_PREP_WRITE_IN_IF=1"
   /opt/rocm/bin/hipcc $FLAGS $D -S --cuda-device-only -o /tmp/all_$v.s $C/dsrc_gpu.hip 2>/dev/null
   awk '/^_Z12k_prep_write/,/\.end_amdhsa_kernel/' /tmp/all_$v.s > gpurun_out/r03_prep_write_$v.s
 done
