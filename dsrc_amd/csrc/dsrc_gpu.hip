@@ -37,6 +37,7 @@
 #include "k_dec_rc.h"
 #include "k_dec_tags.h"
 #include "k_dec_q0.h"
+#include "k_dec_q4.h"
 
 namespace
 {
@@ -1055,11 +1056,34 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 		{
 			const std::vector<DecRound> rounds = plan_rounds(qtabs, region_words);
 			DecTab* d_tabs = AP<DecTab>(h, o_qtabs);
+			// DSRC_GPU_DEC_Q4=1: four streams per wave (k_dec_q4.h); the streams of a wave must have one scheme: inside a round the blocks
+			// are ordered by scheme byte and every run of equal schemes is one launch
+			const bool q4 = getenv("DSRC_GPU_DEC_Q4") != nullptr;
+			if (q4) for (const DecRound& r : rounds)
+				std::stable_sort(qtabs.begin() + r.first, qtabs.begin() + r.first + r.count, [&](const DecTab& a, const DecTab& b2) { return st[a.block].q_scheme < st[b2.block].q_scheme; });
 			HIPCHK(hipMemcpyAsync(d_tabs, qtabs.data(), sizeof(DecTab) * qtabs.size(), hipMemcpyHostToDevice, s));
 			for (const DecRound& r : rounds)
 			{
 				fill_round(d_tabs, qtabs, r); KCHK();
-				hipLaunchKernelGGL(k_dec_qrc, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, d_tabs + r.first, rp, d_out, h->dec_tables, prm); KCHK();
+				if (!q4) { hipLaunchKernelGGL(k_dec_qrc, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, d_tabs + r.first, rp, d_out, h->dec_tables, prm); KCHK(); continue; }
+				for (u32 i = 0; i < r.count; )
+				{
+					const u32 sch = prm.lossy ? 0u : st[qtabs[r.first + i].block].q_scheme;
+					u32 n = 1;
+					while (i + n < r.count && (prm.lossy || st[qtabs[r.first + i + n].block].q_scheme == sch)) ++n;
+					const DecTab* tp = d_tabs + r.first + i;
+					const dim3 grid((n + 3) / 4);
+					switch (qtabs[r.first + i].n)
+					{
+					case 8:   hipLaunchKernelGGL(k_dec_qrc4<8>, grid, dim3(64), 0, s, io.d_in, d_desc, d_state, tp, n, rp, d_out, h->dec_tables, prm, sch); break;
+					case 16:  hipLaunchKernelGGL(k_dec_qrc4<16>, grid, dim3(64), 0, s, io.d_in, d_desc, d_state, tp, n, rp, d_out, h->dec_tables, prm, sch); break;
+					case 32:  hipLaunchKernelGGL(k_dec_qrc4<32>, grid, dim3(64), 0, s, io.d_in, d_desc, d_state, tp, n, rp, d_out, h->dec_tables, prm, sch); break;
+					case 64:  hipLaunchKernelGGL(k_dec_qrc4<64>, grid, dim3(64), 0, s, io.d_in, d_desc, d_state, tp, n, rp, d_out, h->dec_tables, prm, sch); break;
+					default:  hipLaunchKernelGGL(k_dec_qrc4<128>, grid, dim3(64), 0, s, io.d_in, d_desc, d_state, tp, n, rp, d_out, h->dec_tables, prm, sch); break;
+					}
+					KCHK();
+					i += n;
+				}
 			}
 		}
 		hipLaunchKernelGGL(k_dec_dhead, dim3((B + 63) / 64), dim3(64), 0, s, io.d_in, d_desc, d_state, prm); KCHK();

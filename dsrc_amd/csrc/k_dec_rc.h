@@ -461,6 +461,8 @@ __global__ void __launch_bounds__(64) k_dec_dnarc(const u8* in, const DecDesc* d
 	constexpr u32 W = N / 2;                                  // dwords per row
 	constexpr u32 LIM = (1u << 16) - 2 * N;
 	constexpr u32 abits = N == 8 ? 3u : 2u;
+	// a few dozen waves with one long dependent chain each: when another pass's quality stage fills the SIMDs, they go first
+	__builtin_amdgcn_s_setprio(3);
 	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_tabs) return;
 	const DecTab tb = tabs[i];

@@ -243,6 +243,7 @@ __global__ void __launch_bounds__(64) k_dec_tags_wave(const u8* in, const DecDes
 	const u32 b = blockIdx.x;
 	DecState* S = &st[b];
 	if (S->err) return;                                   // wave-uniform
+	__builtin_amdgcn_s_setprio(2);                        // a short stage at the head of a pass: ahead of another pass's quality waves
 	const DecDesc d = desc[b];
 	BitSrc s; s.p = in + d.in_off; s.size = d.in_size; s.err = 0; s.bit = (u64)S->tag_pos * 8;
 	NodePool np; np.w = pool + d.node_off; np.cap = d.node_cap; np.top = 0;
