@@ -160,3 +160,25 @@ def test_wave_decoder_rescale(emu, oracle, d, q, wide):
         recs += [b"@w\n%s\n+\n%s" % (b"C" * 70, bytes(range(33, 103)))]                          # 70 distinct qualities: 128-symbol alphabet
     recs += [b"@h\n%s\n+\n%s" % (b"A" * 200, b"I" * 200) for _ in range(180)]                  # 36 k bases in one DNA context
     check(emu, oracle, Config.from_levels(d, q, False), [b"\n".join(recs)])
+
+
+@pytest.mark.parametrize("d,q,lossy,crc", LEVELS)
+def test_wave_kernels_every_level(emu, oracle, d, q, lossy, crc):
+    """The product's decode kernels (not the one-lane forms most tests here use for speed): k_dec_tags_wave, k_dec_qpos / k_dec_qhuff,
+    k_dec_qrc, k_dec_dnarc, k_dec_dna0 over every level set, on blocks with constant and variable read lengths."""
+    chunks = [TINY, synth.illumina_fastq(60)[:-1]]
+    if lossy or d == 0:
+        chunks.append(synth.iontorrent_fastq(40)[:-1])          # lossless order-k DNA on IUPAC data is undefined in the reference
+    check(emu, oracle, Config.from_levels(d, q, lossy, crc), chunks)
+
+
+@pytest.mark.parametrize("d,q,lossy", [(3, 2, False), (2, 1, True), (1, 1, False)])
+def test_wave_four_streams_per_wave_switch(emu, oracle, d, q, lossy, monkeypatch):
+    """DSRC_GPU_DEC_Q4=1: k_dec_qrc4 (four quality streams per wave, a row of 16 lanes each): blocks of different lengths in one wave
+    (rows end at different times), a batch that does not fill its last wave, and rows hot enough for Rescale()."""
+    import random
+    monkeypatch.setenv("DSRC_GPU_DEC_Q4", "1")
+    rng = random.Random(5 * d + q)
+    hot = b"\n".join([b"@r\nA\n+\n%c" % (73 if rng.random() < 0.97 else 60) for _ in range(42000)] + [b"@h\n%s\n+\n%s" % (b"A" * 100, b"I" * 100) for _ in range(40)])
+    chunks = [synth.illumina_fastq(40)[:-1], hot, synth.illumina_fastq(90, first=500)[:-1], TINY, synth.illumina_fastq(10, first=7)[:-1]]
+    check(emu, oracle, Config.from_levels(d, q, lossy), chunks)
