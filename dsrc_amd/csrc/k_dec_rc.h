@@ -144,6 +144,19 @@ __device__ __forceinline__ u32 qrc_readlane(u32 v, u32 l)
 	return (u32)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)l));
 }
 
+// lane i gets lane i - 1's value, lane 0 gets 0 (wave_shr:1).  The result only ever feeds v_readlane here: a DPP move that the
+// compiler folds into a following SUBTRACTION came out wrong on gfx950 (k_dec_q4.h, q4_shr1)
+__device__ __forceinline__ u32 qrc_up1(u32 v)
+{
+#ifdef DSRC_EMU_BUILD
+	u32 p = __shfl_up(v, 1); if (lane_id() == 0) p = 0; return p;
+#else
+	u32 r = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
+	asm volatile("" : "+v"(r));
+	return r;
+#endif
+}
+
 // element i of a row held one (N <= 64) or two (N == 128: low half = even element) per lane
 template <u32 CPL> __device__ __forceinline__ u32 qrc_elem(u32 cur, u32 i)
 {
@@ -174,6 +187,7 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 	// symbol value of counter i, in the lane that holds counter i (two per lane when N == 128)
 	u32 tr_v = 0;
 	if (translate) tr_v = CPL == 1 ? (live ? (u32)sym_tab[lane] : 0u) : ((u32)sym_tab[2 * lane] | ((u32)sym_tab[2 * lane + 1] << 16));
+	else if (CPL == 1) tr_v = lane;
 
 	const u64 g0 = d.rec_base;
 	const u32 n_recs = S->n_recs;
@@ -195,6 +209,7 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 		u8* q = text + rp.qual_off[g0 + k];
 		u32 hash = 0, sym_buf = 0, j = 0, pctx = 0, rem = 0, ncount = 0, mine = 0;
 		u32 ri = 0;                                                   // row of the symbol being decoded: (hash & mask) * rescale + pctx
+		u32 max_idx = 0, min_r = 0xFFFFFFFFu;
 		// this lane's element(s) of that row; row 0 of a fresh table is 1, 2, .., N (no load: a request pending at the loop's entry would
 		// make the compiler's wait at the top of the loop cover the stores of every later iteration as well)
 		u32 cur = !live ? 0u : CPL == 1 ? lane + 1 : (2 * lane + 1) | ((2 * lane + 2) << 16);
@@ -216,8 +231,8 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 		{
 			// ---- the row has arrived: symbol index ---------------------------------------------------------------------
 			const u32 total = qrc_elem<CPL>(cur, N - 1);
-			u32 r = dec_div(nf, total);
-			if (r == 0) { err |= DEC_ERR_FORMAT; r = 1; }
+			const u32 r = dec_div(nf, total);
+			min_r = min_r < r ? min_r : r;                               // r == 0 (range < total): no valid stream; tested once at the end
 			u32 idx;
 			{
 				const u32 e_hi = CPL == 1 ? cur : cur >> 16, e_lo = cur & 0xFFFFu;
@@ -225,7 +240,7 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 				u64 m0 = CPL == 2 ? __ballot(live && (u64)e_lo * r > rd.buffer) : 0ull;
 				if (m == 0)
 				{	// buffer >= total * r: not a stream the encoder writes; the reference compares with the TRUNCATED quotient
-					const u32 cul = div_u64_u32(rd.buffer, r);
+					const u32 cul = div_u64_u32(rd.buffer, r ? r : 1u);
 					m = __ballot(live && e_hi > cul);
 					if (CPL == 2) m0 = __ballot(live && e_lo > cul);
 				}
@@ -235,7 +250,7 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 					const u32 l = (u32)__ffsll((long long)m) - 1u;
 					idx = CPL == 1 ? l : 2 * l + (((m0 >> l) & 1ull) ? 0u : 1u);
 				}
-				if (idx >= cnt) { err |= DEC_ERR_FORMAT; idx = cnt - 1; }     // a symbol the block's alphabet does not have: no encoder writes it
+				max_idx = max_idx > idx ? max_idx : idx;                    // a symbol the block's alphabet does not have: no encoder writes it; tested once at the end
 			}
 			// ---- request the next row -----------------------------------------------------------------------------------
 			const u32 ri_next = base_next + idx * rescale;
@@ -243,8 +258,13 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 			if (live) nxt = CPL == 1 ? (u32)tab16[(u64)(ri_next ^ swz) * N + lane] : table[(u64)(ri_next ^ swz) * (N / 2) + lane];
 
 			// ---- in its shadow: coder state ------------------------------------------------------------------------------
-			const u32 hi = qrc_elem<CPL>(cur, idx);
-			const u32 lo = idx ? qrc_elem<CPL>(cur, idx - 1) : 0u;
+			u32 hi, lo;
+			if (CPL == 1)
+			{	// the count below the symbol's: the row shifted up by one lane (lane 0 gets 0), read at the same lane
+				hi = (u32)__builtin_amdgcn_readlane((int)cur, (int)idx);
+				lo = (u32)__builtin_amdgcn_readlane((int)qrc_up1(cur), (int)idx);
+			}
+			else { hi = qrc_elem<CPL>(cur, idx); lo = idx ? qrc_elem<CPL>(cur, idx - 1) : 0u; }
 			const u32 f = hi - lo;
 			const u32 rr = lo * r;                                     // uint32 product
 			rd.buffer -= rr; rd.low += rr;
@@ -290,15 +310,31 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 				else if (live && lane >= il) { if (CPL == 1) tab16[(u64)(ri ^ swz) * N + lane] = (u16)cur; else table[(u64)(ri ^ swz) * (N / 2) + lane] = cur; }
 			}
 			// ---- the symbol: lane (j mod 64) keeps it until 64 are together or the record ends ----------------------------
-			u32 qv = idx;
-			if (translate) qv = qrc_elem<CPL>(tr_v, idx);
-			if (lane == (j & 63u)) mine = qv;
-			ncount += q_special(qv, lossy) ? 1u : 0u;
-			++j;
-			if ((j & 63u) == 0 || j == ql)
+			if (CPL == 1)
+			{	// the index; 64 of them are translated, tested for "base lives in the quality stream" and stored at once
+				if (lane == (j & 63u)) mine = idx;
+				++j;
+				if ((j & 63u) == 0 || j == ql)
+				{
+					const u32 base = (j - 1) & ~63u;
+					const bool in = lane < j - base;
+					const u32 qv = (u32)__shfl((int)tr_v, (int)(mine & 63u));
+					if (in) q[base + lane] = (u8)qv;
+					ncount += (u32)__popcll(__ballot(in && q_special(qv, lossy)));
+				}
+			}
+			else
 			{
-				const u32 base = (j - 1) & ~63u;
-				if (lane < j - base) q[base + lane] = (u8)mine;
+				u32 qv = idx;
+				if (translate) qv = qrc_elem<CPL>(tr_v, idx);
+				if (lane == (j & 63u)) mine = qv;
+				ncount += q_special(qv, lossy) ? 1u : 0u;
+				++j;
+				if ((j & 63u) == 0 || j == ql)
+				{
+					const u32 base = (j - 1) & ~63u;
+					if (lane < j - base) q[base + lane] = (u8)mine;
+				}
 			}
 			// a row that is visited twice in a row was requested before it was written
 			if (ri_next == ri) nxt = cur;
@@ -322,6 +358,7 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 			QRC_PREP();
 		}
 #undef QRC_PREP
+		if (min_r == 0 || max_idx >= cnt) err |= DEC_ERR_FORMAT;
 	}
 	s.bit = uw_pos(win) * 8;
 	if (s.bit > (u64)s.size * 8) s.err |= DEC_ERR_TRUNC;
