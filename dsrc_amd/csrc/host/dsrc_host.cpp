@@ -732,18 +732,22 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 
 		const uint64 nBlocks = rd.BlockCount();
 		// A decoding pass is a chain per block: it takes about as long for 1000 blocks as for 10, so
-		// passes are LARGE -- up to 1024 blocks, 3 GiB of archive -- and few handles run at a time: with an order model every block
-		// in flight holds a model table of up to 64 MiB, two handles per device share the HBM for them.  (Still larger passes decode
+		// passes are LARGE -- up to 1600 blocks, 5 GiB of archive -- and few handles run at a time: with an order model every block
+		// in flight holds a model table of up to 64 MiB, three handles per device share the HBM for them (38.5 GB set: 18.3 s with
+		// two handles and 1024-block passes, 15.4 s with three, 18.2 s with four).  (Still larger passes decode
 		// faster on the device -- two concurrent passes of 3600 blocks: 6.8 GB/s, of 1024: < 4 -- but then nothing overlaps the
 		// 19 GB a pass copies into the mapped output: 38.5 GB set, batches of 2300 blocks 16.9 s, of 1024 blocks 15.2 s.)
 		const std::vector<int> devs = args.devices.empty() ? std::vector<int>(1, args.device) : args.devices;
 		const bool tables = rd.Settings().dnaOrder > 0 || rd.Settings().qualityOrder > 0;
-		const uint32 perDev = std::min<uint32>(std::max(1u, args.threadNum), tables ? 2u : 4u);
+		const char* envInst = getenv("DSRC_HOST_DEC_INSTANCES");          // experiments: decoding handles per device
+		const uint32 perDev = envInst ? std::max(1, atoi(envInst)) : std::min<uint32>(std::max(1u, args.threadNum), tables ? 3u : 4u);
 		const uint32 wanted = perDev * (uint32)devs.size();
 		std::vector<std::pair<uint64, uint64> > batches;
 		{
-			const uint64 maxBlocks = args.batchBlocks ? args.batchBlocks : std::max<uint64>(1, std::min<uint64>(1024, (nBlocks + wanted - 1) / wanted));
-			const uint64 budget = 3072ull << 20;
+			// as few rounds of `wanted` concurrent passes as passes of <= 1600 blocks allow, all of one size
+			const uint64 rounds = std::max<uint64>(1, (nBlocks + (uint64)wanted * 1600 - 1) / ((uint64)wanted * 1600));
+			const uint64 maxBlocks = args.batchBlocks ? args.batchBlocks : std::max<uint64>(1, (nBlocks + wanted * rounds - 1) / (wanted * rounds));
+			const uint64 budget = 5120ull << 20;
 			uint64 lo = 0, bytes = 0;
 			for (uint64 i = 0; i < nBlocks; ++i)
 			{
