@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(64) k_dec_qpos(const u8* in, const DecDesc* de
 	for (u32 i = threadIdx.x; i < maxl; i += blockDim.x)
 		s_cdir[i] = (u16)(__hip_atomic_load(np.w + dir + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - first);
 	__syncthreads();
-	// per position and 6-bit prefix: symbol | length << 8, or 0x8000 | the node reached after 6 bits
+	// per position and 6-bit prefix: character | length << 8 | special << 11, or 0x8000 | the node reached after 6 bits
 	for (u32 e = threadIdx.x; e < maxl * 64; e += blockDim.x)
 	{
 		const u32 base = s_cdir[e >> 6], bits = e & 63u;
@@ -78,7 +78,12 @@ __global__ void __launch_bounds__(64) k_dec_qpos(const u8* in, const DecDesc* de
 		{
 			const u32 c = s_cn[base + node];
 			const u32 child = ((bits >> (6 - k)) & 1u) ? c >> 8 : c & 0xFFu;
-			if (child & 0x80u) { const u32 x = child & 0x7Fu; val = (x < n ? (u32)s_sym[x] : 255u) | (k << 8); break; }      // the CHARACTER: one read per symbol
+			if (child & 0x80u)
+			{	// the CHARACTER, the code length and whether the base lives in the quality stream: one read per symbol
+				const u32 x = child & 0x7Fu, qv = x < n ? (u32)s_sym[x] : 255u;
+				val = qv | (k << 8) | (q_special(qv, lossy) ? 0x800u : 0u);
+				break;
+			}
 			node = child;
 			if (k == 6) val = 0x8000u | node;
 		}
@@ -102,41 +107,41 @@ __global__ void __launch_bounds__(64) k_dec_qpos(const u8* in, const DecDesc* de
 		const u64 g = g0 + k;
 		const u32 ql = nql; u8* q = text + nqo;
 		if (k + 1 < n_recs) { nql = rp.len[g + 1]; nqo = rp.qual_off[g + 1]; }
-		u32 th = ql, ncount = 0, pk = 0;
+		u32 th = ql, ncount = 0;
 		if (truncated && sw_bits(w, 1)) th = sw_bits(w, variable ? dec_bit_length(ql) : max_bits);
 		if (th > ql || th > maxl) { err |= DEC_ERR_FORMAT; break; }
-		for (u32 j = 0; j < ql; ++j)
+		// one symbol: table entry for the next 6 bits; a code longer than that goes on bit by bit from the node it has reached
+		auto one = [&](u32 j) -> u32
 		{
-			u32 qv = hash_sym;
-			if (j < th)
+			sw_refill(w);
+			u32 e = s_fast[j * 64 + (u32)(w.w >> 58)];
+			if (!(e & 0x8000u)) { const u32 len = (e >> 8) & 7u; w.w <<= len; w.n -= len; return e; }
+			u32 node = e & 0x7FFFu;
+			w.w <<= 6; w.n -= 6;
+			const u32 base = s_cdir[j];
+			u32 x = 0xFFFFu;
+			for (u32 guard = 0; guard < 130; ++guard)
 			{
-				sw_refill(w);
-				const u32 e = s_fast[j * 64 + (u32)(w.w >> 58)];
-				if (!(e & 0x8000u)) { qv = e & 0xFFu; const u32 len = e >> 8; w.w <<= len; w.n -= len; }
-				else
-				{	// a code longer than 6 bits: on from the node it has reached
-					u32 node = e & 0x7FFFu;
-					w.w <<= 6; w.n -= 6;
-					const u32 base = s_cdir[j];
-					u32 x = 0xFFFFu;
-					for (u32 guard = 0; guard < 130; ++guard)
-					{
-						if (w.n == 0) sw_refill(w);
-						const u32 c = s_cn[base + node];
-						const u32 child = (w.w >> 63) ? c >> 8 : c & 0xFFu;
-						w.w <<= 1; w.n -= 1;
-						if (child & 0x80u) { x = child & 0x7Fu; break; }
-						node = child;
-					}
-					if (x == 0xFFFFu) { err |= DEC_ERR_FORMAT; x = 0; }
-					qv = x < n ? s_sym[x] : 255u;
-				}
+				if (w.n == 0) sw_refill(w);
+				const u32 c = s_cn[base + node];
+				const u32 child = (w.w >> 63) ? c >> 8 : c & 0xFFu;
+				w.w <<= 1; w.n -= 1;
+				if (child & 0x80u) { x = child & 0x7Fu; break; }
+				node = child;
 			}
-			ncount += q_special(qv, lossy) ? 1u : 0u;
-			pk |= qv << (8 * (j & 3u));
-			if ((j & 3u) == 3u) { *(dec_u32_unaligned*)(q + j - 3) = pk; pk = 0; }
+			if (x == 0xFFFFu) { err |= DEC_ERR_FORMAT; x = 0; }
+			const u32 qv = x < n ? (u32)s_sym[x] : 255u;
+			return qv | (q_special(qv, lossy) ? 0x800u : 0u);
+		};
+		u32 j = 0;
+		for (; j + 4 <= th; j += 4)
+		{	// four characters per store
+			const u32 e0 = one(j), e1 = one(j + 1), e2 = one(j + 2), e3 = one(j + 3);
+			*(dec_u32_unaligned*)(q + j) = (e0 & 0xFFu) | ((e1 & 0xFFu) << 8) | ((e2 & 0xFFu) << 16) | (e3 << 24);
+			ncount += ((e0 >> 11) & 1u) + ((e1 >> 11) & 1u) + ((e2 >> 11) & 1u) + ((e3 >> 11) & 1u);
 		}
-		for (u32 t = 0; t < (ql & 3u); ++t) q[(ql & ~3u) + t] = (u8)(pk >> (8 * t));
+		for (; j < th; ++j) { const u32 e = one(j); q[j] = (u8)e; ncount += (e >> 11) & 1u; }
+		for (; j < ql; ++j) q[j] = (u8)hash_sym;               // the truncated tail (never a base that lives in the quality stream)
 		rp.kept[g] = (u16)(ql - ncount); rp.d_off[g] = d_total; d_total += ql - ncount;
 	}
 	S->d_total = d_total;
