@@ -182,3 +182,12 @@ def test_wave_four_streams_per_wave_switch(emu, oracle, d, q, lossy, monkeypatch
     hot = b"\n".join([b"@r\nA\n+\n%c" % (73 if rng.random() < 0.97 else 60) for _ in range(42000)] + [b"@h\n%s\n+\n%s" % (b"A" * 100, b"I" * 100) for _ in range(40)])
     chunks = [synth.illumina_fastq(40)[:-1], hot, synth.illumina_fastq(90, first=500)[:-1], TINY, synth.illumina_fastq(10, first=7)[:-1]]
     check(emu, oracle, Config.from_levels(d, q, lossy), chunks)
+
+
+def test_wave_rle_scheme(emu, oracle):
+    """The RLE scheme of -q0 (QualityRLEModeler::Decode) through k_dec_qpos's tables: 4-, 20- and 45-symbol alphabets, runs longer
+    than 255 that cross record boundaries, and runs the records do not consume."""
+    from tests.cases import rle_chunks
+    chunks = [c[: c.index(b"\n@r.400 ")] for c in rle_chunks()]          # the first 400 records of each
+    for lossy in (False, True):
+        check(emu, oracle, Config.from_levels(0, 0, lossy, True), chunks)
