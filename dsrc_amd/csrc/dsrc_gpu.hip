@@ -1065,7 +1065,18 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 			for (const DecRound& r : rounds)
 			{
 				fill_round(d_tabs, qtabs, r); KCHK();
-				if (!q4) { hipLaunchKernelGGL(k_dec_qrc, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, d_tabs + r.first, rp, d_out, h->dec_tables, prm); KCHK(); continue; }
+				if (!q4)
+				{	// one launch per alphabet size the round contains
+					u32 sizes_present = 0;
+					for (u32 i = 0; i < r.count; ++i) sizes_present |= qtabs[r.first + i].n;          // 8, 16, 32, 64, 128: one bit each
+					const DecTab* tp = d_tabs + r.first;
+					if (sizes_present & 8u)   { hipLaunchKernelGGL(k_dec_qrc<8>, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, tp, rp, d_out, h->dec_tables, prm); KCHK(); }
+					if (sizes_present & 16u)  { hipLaunchKernelGGL(k_dec_qrc<16>, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, tp, rp, d_out, h->dec_tables, prm); KCHK(); }
+					if (sizes_present & 32u)  { hipLaunchKernelGGL(k_dec_qrc<32>, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, tp, rp, d_out, h->dec_tables, prm); KCHK(); }
+					if (sizes_present & 64u)  { hipLaunchKernelGGL(k_dec_qrc<64>, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, tp, rp, d_out, h->dec_tables, prm); KCHK(); }
+					if (sizes_present & 128u) { hipLaunchKernelGGL(k_dec_qrc<128>, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, tp, rp, d_out, h->dec_tables, prm); KCHK(); }
+					continue;
+				}
 				for (u32 i = 0; i < r.count; )
 				{
 					const u32 sch = prm.lossy ? 0u : st[qtabs[r.first + i].block].q_scheme;

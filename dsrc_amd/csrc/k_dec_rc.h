@@ -381,7 +381,10 @@ __device__ __forceinline__ bool qrc_scheme(u32 quality_order, u32 lossy, u32 sch
 	return true;
 }
 
-// wave per block of the round; tabs[blockIdx.x] names the block and its table
+// wave per block of the round; tabs[blockIdx.x] names the block and its table.  One kernel per alphabet size (the host launches the
+// sizes a round contains; a wave whose block has another size leaves at once): the five decoders in one kernel cost the common
+// ones registers they do not need.
+template <u32 NSEL>
 __global__ void __launch_bounds__(64) k_dec_qrc(const u8* in, const DecDesc* desc, DecState* st, const DecTab* tabs, RecPools rp, u8* out, u32* tables, DecParams prm)
 {
 	__shared__ u8 s_sym[256];
@@ -390,6 +393,10 @@ __global__ void __launch_bounds__(64) k_dec_qrc(const u8* in, const DecDesc* des
 	const u32 b = tb.block;
 	DecState* S = &st[b];
 	if (S->err) return;                                   // wave-uniform
+	{
+		QrcScheme q0;
+		if (qrc_scheme(prm.quality_order, prm.lossy, S->q_scheme, &q0) && q0.n != NSEL) return;      // another launch's
+	}
 	const DecDesc d = desc[b];
 	BitSrc s; s.p = in + d.in_off; s.size = d.in_size; s.err = 0; s.bit = (u64)S->qua_pos * 8;
 	if (threadIdx.x == 0)
@@ -422,14 +429,7 @@ __global__ void __launch_bounds__(64) k_dec_qrc(const u8* in, const DecDesc* des
 	{
 		u32* table = tables + tb.off;
 		u8* text = out + d.out_off;
-		switch (qs.n)
-		{
-		case 8:   qrc_decode<8>(s, table, qs.ord, qs.rescale, cnt, swz_seed, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
-		case 16:  qrc_decode<16>(s, table, qs.ord, qs.rescale, cnt, swz_seed, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
-		case 32:  qrc_decode<32>(s, table, qs.ord, qs.rescale, cnt, swz_seed, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
-		case 64:  qrc_decode<64>(s, table, qs.ord, qs.rescale, cnt, swz_seed, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
-		default:  qrc_decode<128>(s, table, qs.ord, qs.rescale, cnt, swz_seed, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text); break;
-		}
+		qrc_decode<NSEL>(s, table, qs.ord, qs.rescale, cnt, swz_seed, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text);
 	}
 	if (threadIdx.x == 0)
 	{
@@ -532,7 +532,9 @@ __global__ void __launch_bounds__(64) k_dec_dnarc(const u8* in, const DecDesc* d
 	for (u32 w = 0; w < W; ++w) cur[w] = 0x00010001u;
 	u64 pack = 0;
 	dec_vm_drain();                                           // nothing pending at the loop's entry: the waits inside it then count only its own requests
-	for (u32 t = 0; t < total && !err; ++t)
+	// One symbol.  touch_new / touch_old: see below; two variables taken in turns by the two calls of the loop body, because a
+	// copy from one to the other would have to wait for the data.
+	auto step = [&](const u32 t, u32& touch_new, const u32 touch_old) __attribute__((always_inline))
 	{
 		// the N candidate rows of the next symbol are consecutive and known before this symbol is
 		const u32 nbase = (hash << abits) & mask;
@@ -542,6 +544,12 @@ __global__ void __launch_bounds__(64) k_dec_dnarc(const u8* in, const DecDesc* d
 		for (u32 w = 0; w < N * W / 2; ++w) cand[w] = cp[w];
 		const u32 wl_pos = win.nx + 8;
 		const u64 wl = lw_load(win.p, win.size, wl_pos);
+		// ... and the N * N candidate rows of the symbol after that are one 128-byte line (N = 4): touching it now, one symbol
+		// before its rows are requested, takes a symbol's time off that request's latency.  The value is not used; it is
+		// "consumed" at the end of the NEXT symbol, when the wave's in-order returns have long delivered it.  (An LDS-DMA
+		// request instead, which needs no register, makes the compiler wait with vmcnt(0) everywhere; hidden from it in inline
+		// assembly it makes every wait that counts younger requests one too strict.)
+		if (N == 4) touch_new = tab[(u64)((nbase << abits) & mask) * W];
 		u32 c[N], a[N];
 #pragma unroll
 		for (u32 k = 0; k < N; ++k) c[k] = (cur[k / 2] >> (16 * (k & 1))) & 0xFFFFu;
@@ -625,6 +633,16 @@ __global__ void __launch_bounds__(64) k_dec_dnarc(const u8* in, const DecDesc* d
 		}
 		hash = nh;
 		win.wp = wl; win.wp_pos = wl_pos;
+#ifndef DSRC_EMU_BUILD
+		if (N == 4) asm volatile("" :: "v"(touch_old));
+#else
+		(void)touch_old;
+#endif
+	};
+	{
+		u32 ta = 0, tb = 0, t = 0;
+		for (; t + 1 < total && !err; t += 2) { step(t, ta, tb); step(t + 1, tb, ta); }
+		if (t < total && !err) step(t, ta, tb);
 	}
 	if (total & 7u)
 	{	// d_base is 64-byte aligned and the stream's allocation is padded: the last, partial group is stored whole

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--lossy", action="store_true")
     ap.add_argument("--passes", type=int, default=2)
     ap.add_argument("--check", type=int, default=2, help="decoded blocks compared with the chunk text")
+    ap.add_argument("--inst", type=int, default=1, help="decoding instances run concurrently (threads, one handle each)")
+    ap.add_argument("--stagger", type=float, default=1.5, help="seconds between the starts of the instances")
     a = ap.parse_args()
 
     h = Handle(3 * a.d, a.q, lossy=a.lossy, quality_offset=33)
@@ -57,6 +59,29 @@ def main():
         assert sum(t_sizes) == text_bytes, (sum(t_sizes), text_bytes)
         print(json.dumps({"pass": p, "blocks": a.blocks, "text_bytes": text_bytes, "s": round(dt, 4), "gpu_ms": round(h.last_timing()[0], 1),
                           "MB_per_s": round(text_bytes / dt / 1e6, 1)}), flush=True)
+    if a.inst > 1:
+        import threading
+        hs = [h] + [Handle(3 * a.d, a.q, lossy=a.lossy, quality_offset=33) for _ in range(a.inst - 1)]
+        txts = [d_txt] + [x.dev_alloc(text_bytes + 4096) for x in hs[1:]]
+        for x, t in zip(hs[1:], txts[1:]):
+            x.decompress_batch_device(d_blk, offs, szs, t, text_bytes + 4096, verify=False)       # warm-up: arena, table region
+
+        def work(i):
+            for _ in range(a.passes):
+                hs[i].decompress_batch_device(d_blk, offs, szs, txts[i], text_bytes + 4096, verify=False)
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(a.inst)]
+        t0 = time.perf_counter()
+        for i, t in enumerate(ths):
+            t.start()
+            if i + 1 < a.inst:
+                time.sleep(a.stagger)
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"instances": a.inst, "passes_each": a.passes, "blocks": a.blocks, "s": round(dt, 3),
+                          "MB_per_s": round(text_bytes * a.inst * a.passes / dt / 1e6, 1)}), flush=True)
+        for x, t in zip(hs[1:], txts[1:]):
+            x.dev_free(t); x.close()
     step = max(1, a.blocks // max(1, a.check))
     for i in list(range(0, a.blocks, step))[:a.check] + [a.blocks - 1]:
         src = h.dev_download(d_in + int(starts[i % n]), int(sizes[i % n]))
