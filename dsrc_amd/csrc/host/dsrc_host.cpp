@@ -1,4 +1,7 @@
 // Host side of the MI355X DSRC compressor (see dsrc_host.h).  Plain C++17, links libdsrc_gpu.so.
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE            // O_DIRECT
+#endif
 #include "dsrc_host.h"
 
 #include <algorithm>
@@ -374,7 +377,7 @@ void DsrcCompressorGPU::LogSizes(const ArchiveWriter& writer)
 bool DsrcCompressorGPU::Process(const InputParameters& args)
 {
 	if (args.useFastqStdIo) return ProcessStream(args, stdin);
-	int fd = -1;
+	int fd = -1, fdDirect = -1;
 	dsrcgpu_chain* chain = nullptr;
 	std::vector<std::thread> workers, readers;
 	Pipeline pl;
@@ -395,6 +398,13 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 		fd = open(args.inputFilename.c_str(), O_RDONLY);
 		struct stat sb;
 		if (fd < 0 || fstat(fd, &sb) != 0) throw DsrcException("Cannot open file to read:" + args.inputFilename);
+		if (getenv("DSRC_HOST_DIRECT_IO") && S_ISREG(sb.st_mode))
+		{	// the batches are read once, in order, by threads that copy into page-locked or 2 MiB-aligned buffers: on a fast NVMe
+			// set the page cache is a second copy and an eviction cost.  Off by default; tmpfs and some overlays refuse O_DIRECT.
+			fdDirect = open(args.inputFilename.c_str(), O_RDONLY | O_DIRECT);
+			if (fdDirect < 0 && args.verboseLog) fprintf(stderr, "[dsrc-amd] DSRC_HOST_DIRECT_IO: this file system refuses O_DIRECT, reading through the page cache\n");
+			else if (getenv("DSRC_HOST_TRACE")) fprintf(stderr, "[dsrc-amd] direct reads: %s\n", fdDirect >= 0 ? "on" : "refused");
+		}
 		if (!S_ISREG(sb.st_mode))
 		{	// pipes and devices go through the stream reader
 			close(fd); fd = -1;
@@ -534,7 +544,9 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 								Pinned* buf = pl.freeIn.back(); pl.freeIn.pop_back();
 								const uint32 n = (uint32)j->sizes.size();
 								j->at.resize(n); j->inBytes = 0;
-								for (uint32 i = 0; i < n; ++i) { j->at[i] = j->inBytes; j->inBytes += (j->sizes[i] + 4096) & ~(uint64)4095; }
+								// a chunk sits in its slot as far behind a 4 KiB boundary as it does in the file, so that a direct read
+								// (aligned file offset, aligned address, whole sectors) can deliver it in place
+								for (uint32 i = 0; i < n; ++i) { j->at[i] = j->inBytes + (j->fileOff[i] & 4095u); j->inBytes += (j->sizes[i] + 2 * 4096) & ~(uint64)4095; }
 								j->in = buf; j->nextPart = n; j->chunksLeft = n;          // parts are handed out once the buffer exists
 								pl.reading.push_back(j);
 								g.unlock();
@@ -551,6 +563,21 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 					for (uint32 i = lo; i < hi; ++i)
 					{
 						uint64 got = 0;
+						if (fdDirect >= 0)
+						{	// the sectors that cover the chunk, past the page cache (DSRC_HOST_DIRECT_IO=1); whatever a direct read does
+							// not deliver (end of file inside a sector, a file system that balks) comes through the ordinary descriptor
+							const uint64 a0 = job->fileOff[i] & ~(uint64)4095, lead = job->fileOff[i] - a0;
+							const uint64 a1 = (job->fileOff[i] + job->sizes[i] + 4095) & ~(uint64)4095;
+							uchar* dst = job->in->p + job->at[i] - lead;
+							uint64 have = 0;
+							while (have < a1 - a0 && ((uintptr_t)(dst + have) & 4095u) == 0)
+							{
+								const ssize_t r = pread(fdDirect, dst + have, a1 - a0 - have, (off_t)(a0 + have));
+								if (r <= 0) break;
+								have += (uint64)r;
+							}
+							got = have > lead ? std::min<uint64>(have - lead, job->sizes[i]) : 0;
+						}
 						while (got < job->sizes[i])
 						{
 							const ssize_t r = pread(fd, job->in->p + job->at[i] + got, job->sizes[i] - got, (off_t)(job->fileOff[i] + got));
@@ -638,6 +665,7 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 	for (auto& kv : pl.ready) delete kv.second;
 	if (chain) dsrcgpu_chain_destroy(chain);
 	if (fd >= 0) close(fd);
+	if (fdDirect >= 0) close(fdDirect);
 	return !IsError();
 }
 

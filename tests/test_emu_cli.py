@@ -67,3 +67,26 @@ def test_round_trip_and_errors(cli, tmp_path, oracle, flags):
     assert r.returncode != 0 and b"Invalid archive" in r.stderr
     r = subprocess.run([cli, "c", "-d7", str(src), str(arc)], capture_output=True)
     assert r.returncode != 0 and b"invalid DNA compression mode" in r.stderr
+
+
+def test_direct_io_reader_writes_the_same_archive(cli, tmp_path):
+    """DSRC_HOST_DIRECT_IO=1: the batches are read with O_DIRECT (whole sectors around every chunk, the chunk in place behind the
+    sector's head); chunks that start and end inside sectors, the end of the file inside a sector.  Where the file system refuses
+    O_DIRECT (tmpfs) the switch falls back to ordinary reads -- the archive is the same either way."""
+    a = G["small"]
+    data = state_dependent_fastq(a["n_per_region"])
+    got = {}
+    for where in (tmp_path, os.path.join(ROOT, "tests", "emu")):      # pytest's tmp (often tmpfs) and the repository's file system
+        src = os.path.join(str(where), "direct_io_state.fastq"); arc = os.path.join(str(where), "direct_io_state.dsrc")
+        try:
+            with open(src, "wb") as f:
+                f.write(data)
+            r = subprocess.run([cli, "c", *a["flags"], "-b1", "-n1", "-t2", src, arc], env=dict(os.environ, DSRC_HOST_DIRECT_IO="1", DSRC_HOST_TRACE="1"),
+                               capture_output=True, check=True)
+            got[str(where)] = b"direct reads: on" in r.stderr
+            assert (os.path.getsize(arc), md5(arc)) == (a["size"], a["md5"])
+        finally:
+            for p in (src, arc):
+                if os.path.exists(p):
+                    os.unlink(p)
+    assert len(got) == 2
