@@ -1008,13 +1008,22 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 				}
 			}
 			catch (const std::exception& e) { std::lock_guard<std::mutex> g(m); if (error.empty()) error = e.what(); cv.notify_all(); }
-			if (h) dsrcgpu_destroy(h);
+			// a command-line process that is about to leave keeps its handles: freeing ~100 GB of arenas and tables takes seconds
+			if (h && !args.exitWhenDone) dsrcgpu_destroy(h);
 		};
 		for (uint32 i = 0; i < instances; ++i) workers.emplace_back(work, i);
 		for (auto& t : workers) t.join();
 		workers.clear();
+		mark(0, batches.size(), "all decoded");
 		for (auto& t : faulters) t.join();
 		faulters.clear();
+		if (args.exitWhenDone && error.empty() && !mapBroken && out != stdout)
+		{	// the text is in the page cache (through the mapping or pwrite); unmapping, closing and the HIP teardown are the
+			// kernel's job at exit, where nobody waits for them one after the other
+			if (args.verboseLog) fputs(GetLog().c_str(), stderr);
+			fflush(nullptr);
+			_exit(0);
+		}
 		if (map)
 		{
 			munmap(map, mapBytes); map = nullptr;
