@@ -218,17 +218,29 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 		// Where the row of the symbol AFTER the one being decoded is, up to that symbol itself: position context, and the hash with
 		// its low slot still empty.  It is prepared one symbol ahead (in the shadow of the previous request), so that between
 		// "row arrives" and "next row requested" there is only the symbol search.
+		// The loop is cut into SEGMENTS so that the body of a symbol carries no test of where in the record it is: a segment ends at
+		// a multiple of 64 symbols (they are stored), one symbol before the record's end (the row after the LAST symbol is the next
+		// record's first: position context 0 -- QRC_LAST() turns the prepared row into that one) and at the record's end.
 		u32 pn, rem2, nb, hpre, base_next;
+		// the position context advances by rescale / ql per symbol: quotient and remainder per record, no loop per symbol
+		u32 step_q = rescale / ql, step_r = rescale - step_q * ql;
+#define QRC_STEP() do { step_q = rescale / ql; step_r = rescale - step_q * ql; } while (0)
+#define QRC_POS() do { rem2 = rem + step_r; const u32 c_ = rem2 >= ql ? 1u : 0u; pn = pctx + step_q + c_; rem2 -= c_ ? ql : 0u; } while (0)
 #define QRC_PREP() do { \
-			pn = 0; rem2 = 0; \
-			if (j + 1 != ql) { pn = pctx; rem2 = rem + rescale; while (rem2 >= ql) { rem2 -= ql; ++pn; } } \
+			QRC_POS(); \
 			const u32 h2_ = hash << abits; \
 			nb = (h2_ >> bits_lo) & sym_mask; \
 			hpre = (h2_ & swap_mask) | (((nb + sym_buf) >> 1) << bits_lo); \
 			base_next = (hpre & hash_mask) * rescale + pn; } while (0)
+#define QRC_LAST() do { base_next -= pn; pn = 0; rem2 = 0; } while (0)
 		QRC_PREP();
 		for (;;)
 		{
+			u32 stop = (j | 63u) + 1u;
+			if (j + 1 < ql) { if (stop > ql - 1) stop = ql - 1; }
+			else { stop = ql; QRC_LAST(); }
+			do
+			{
 			// ---- the row has arrived: symbol index ---------------------------------------------------------------------
 			const u32 total = qrc_elem<CPL>(cur, N - 1);
 			const u32 r = dec_div(nf, total);
@@ -255,7 +267,9 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 			// ---- request the next row -----------------------------------------------------------------------------------
 			const u32 ri_next = base_next + idx * rescale;
 			u32 nxt = 0;
-			if (live) nxt = CPL == 1 ? (u32)tab16[(u64)(ri_next ^ swz) * N + lane] : table[(u64)(ri_next ^ swz) * (N / 2) + lane];
+			// every lane asks (lanes past the row for an element of the row again: the same line, and their copy is never used): no
+			// change of the execution mask around the request
+			nxt = CPL == 1 ? (u32)tab16[(u64)(ri_next ^ swz) * N + (lane & (LANES - 1))] : table[(u64)(ri_next ^ swz) * (N / 2) + (lane & (LANES - 1))];
 
 			// ---- in its shadow: coder state ------------------------------------------------------------------------------
 			u32 hi, lo;
@@ -311,17 +325,8 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 			}
 			// ---- the symbol: lane (j mod 64) keeps it until 64 are together or the record ends ----------------------------
 			if (CPL == 1)
-			{	// the index; 64 of them are translated, tested for "base lives in the quality stream" and stored at once
+			{	// the index; 64 of them are translated, tested for "base lives in the quality stream" and stored at once (below)
 				if (lane == (j & 63u)) mine = idx;
-				++j;
-				if ((j & 63u) == 0 || j == ql)
-				{
-					const u32 base = (j - 1) & ~63u;
-					const bool in = lane < j - base;
-					const u32 qv = (u32)__shfl((int)tr_v, (int)(mine & 63u));
-					if (in) q[base + lane] = (u8)qv;
-					ncount += (u32)__popcll(__ballot(in && q_special(qv, lossy)));
-				}
 			}
 			else
 			{
@@ -329,17 +334,26 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 				if (translate) qv = qrc_elem<CPL>(tr_v, idx);
 				if (lane == (j & 63u)) mine = qv;
 				ncount += q_special(qv, lossy) ? 1u : 0u;
-				++j;
-				if ((j & 63u) == 0 || j == ql)
-				{
-					const u32 base = (j - 1) & ~63u;
-					if (lane < j - base) q[base + lane] = (u8)mine;
-				}
 			}
 			// a row that is visited twice in a row was requested before it was written
 			if (ri_next == ri) nxt = cur;
 			cur = nxt; ri = ri_next;
 			hash = hpre | idx; sym_buf = nb; pctx = pn; rem = rem2;
+			QRC_PREP();
+			} while (++j < stop);
+			// ---- the segment's end ------------------------------------------------------------------------------------------
+			if ((j & 63u) == 0 || j == ql)
+			{
+				const u32 base = (j - 1) & ~63u;
+				const bool in = lane < j - base;
+				if (CPL == 1)
+				{
+					const u32 qv = (u32)__shfl((int)tr_v, (int)(mine & 63u));
+					if (in) q[base + lane] = (u8)qv;
+					ncount += (u32)__popcll(__ballot(in && q_special(qv, lossy)));
+				}
+				else if (in) q[base + lane] = (u8)mine;
+			}
 			if (j == ql)
 			{
 				if (lane == 0) { rp.kept[g0 + k] = (u16)(ql - ncount); rp.d_off[g0 + k] = d_total; }
@@ -353,11 +367,18 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 				if (k == n_recs) break;
 				q = text + rp.qual_off[g0 + k];
 				j = 0; ncount = 0;
+				// the row prepared at the end of the body was for position 1 of a record of the OLD length; the first symbol's own row
+				// (position 0) is the one QRC_LAST() made, so only what follows it is prepared again, with the new length
+				pctx = 0; rem = 0;
+				QRC_STEP();
+				QRC_PREP();
 			}
 			if (err) break;
-			QRC_PREP();
 		}
 #undef QRC_PREP
+#undef QRC_LAST
+#undef QRC_POS
+#undef QRC_STEP
 		if (min_r == 0 || max_idx >= cnt) err |= DEC_ERR_FORMAT;
 	}
 	s.bit = uw_pos(win) * 8;
