@@ -248,8 +248,11 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 			u32 idx;
 			{
 				const u32 e_hi = CPL == 1 ? cur : cur >> 16, e_lo = cur & 0xFFFFu;
-				u64 m = __ballot(live && (u64)e_hi * r > rd.buffer);
-				u64 m0 = CPL == 2 ? __ballot(live && (u64)e_lo * r > rd.buffer) : 0ull;
+				// no `live &&`: a lane past the row holds 0, a copy of one of the row's counts (it asks for the row like the others), that
+				// copy + 2, or the row's total (after Rescale()) -- never more than the total in lane LANES - 1, so whenever such a lane
+				// answers yes, lane LANES - 1 does too, and the lowest yes is a lane of the row
+				u64 m = __ballot((u64)e_hi * r > rd.buffer);
+				u64 m0 = CPL == 2 ? __ballot((u64)e_lo * r > rd.buffer) : 0ull;
 				if (m == 0)
 				{	// buffer >= total * r: not a stream the encoder writes; the reference compares with the TRUNCATED quotient
 					const u32 cul = div_u64_u32(rd.buffer, r ? r : 1u);
