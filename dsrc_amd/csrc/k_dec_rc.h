@@ -286,7 +286,10 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 			const u32 rr = lo * r;                                     // uint32 product
 			rd.buffer -= rr; rd.low += rr;
 			rd.range = r * f;
-			while (rd.range <= 0x00FFFFFFu)
+			// (if + do-while with the hint: the compiler keeps the renormalisation out of the straight path; as a plain while loop the
+			// symbol that shifts nothing in -- two of three -- still took three jumps through the loop's header)
+			if (__builtin_expect(rd.range <= 0x00FFFFFFu, 0))
+			do
 			{
 				if ((rd.low ^ (rd.low + rd.range)) & 0xFF00000000000000ull)
 				{
@@ -296,7 +299,7 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 				rd.buffer = (rd.buffer << 8) + uw_byte(win);
 				rd.low <<= 8; rd.range <<= 8;
 				if (rd.range == 0) { err |= DEC_ERR_FORMAT; rd.range = 0xFFFFFFFFu; break; }
-			}
+			} while (rd.range <= 0x00FFFFFFu);
 			nf = dec_div_prep(rd.range);
 			// ---- the row: +2 on the symbol = +2 on every cumulative count from it on; Rescale() now instead of at the next visit
 			{
