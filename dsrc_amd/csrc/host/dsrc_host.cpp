@@ -866,6 +866,8 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 			if (trace) fprintf(stderr, "[dsrc-amd d] worker %u batch %llu %-10s %8.1f ms\n", idx, (unsigned long long)k, what,
 							   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 		};
+		// experiments: the first pass of worker i starts i * DSRC_HOST_DEC_STAGGER_MS late (passes that run in step meet in the same stage)
+		const uint32 staggerMs = getenv("DSRC_HOST_DEC_STAGGER_MS") ? (uint32)atoi(getenv("DSRC_HOST_DEC_STAGGER_MS")) : 0u;
 		auto work = [&](uint32 idx)
 		{
 			dsrcgpu_handle* h = nullptr;
@@ -917,6 +919,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 						if (rd.BlockSizes()[lo - 1] >= 16 && pread(rd.Fd(), hb, 16, (off_t)rd.BlockOffset(lo - 1)) == 16) { before = (uint32)GetBE(hb + 12, 4); haveBefore = true; }
 					}
 					mark(idx, k, "read");
+					if (staggerMs && k < instances) std::this_thread::sleep_for(std::chrono::milliseconds((long long)staggerMs * (long long)k));
 					int rc = DSRCGPU_OK;
 					if (map && !mapBroken)
 					{
