@@ -517,6 +517,9 @@ __device__ __forceinline__ u32 lw_byte(LWin& w)
 }
 __device__ __forceinline__ u32 lw_pos(const LWin& w) { return w.nx - w.left; }
 
+#ifndef DNA_WL_EVERY
+#define DNA_WL_EVERY 2u
+#endif
 // ---- DNA, order-k range coder: one LANE per block ----------------------------------------------------------------------------
 template <u32 N>
 __global__ void __launch_bounds__(64) k_dec_dnarc(const u8* in, const DecDesc* desc, DecState* st, const DecTab* tabs, u32 n_tabs,
@@ -569,8 +572,14 @@ __global__ void __launch_bounds__(64) k_dec_dnarc(const u8* in, const DecDesc* d
 		uint2 cand[N * W / 2];
 #pragma unroll
 		for (u32 w = 0; w < N * W / 2; ++w) cand[w] = cp[w];
-		const u32 wl_pos = win.nx + 8;
-		const u64 wl = lw_load(win.p, win.size, wl_pos);
+		// the 8 bytes behind the window: requested every DNA_WL_EVERY-th symbol (t is the same in all lanes: a uniform branch).  A
+		// symbol consumes 0-3 bytes, typically a quarter of one, so the copy is there long before the window has moved 8 bytes on;
+		// when it is not (wp_pos stale), the refill below does not happen and the reference's loop fetches its bytes itself.  Every
+		// symbol asking cost 0.4 s of a 2400-block pass (64 lanes = 64 lines and pages per request, in front of the look-ahead
+		// touch); measured at -d3 -q0, 64 / 2400 blocks: every symbol 1.69 / 3.47 s, every 2nd 1.66 / 3.11, 4th 1.88 / 3.24, 8th 1.80 / 3.18.
+		const bool wl_now = (t & (DNA_WL_EVERY - 1u)) == 0;
+		u32 wl_pos = 0; u64 wl = 0;
+		if (wl_now) { wl_pos = win.nx + 8; wl = lw_load(win.p, win.size, wl_pos); }
 		// ... and the N * N candidate rows of the symbol after that are one 128-byte line (N = 4): touching it now, one symbol
 		// before its rows are requested, takes a symbol's time off that request's latency.  The value is not used; it is
 		// "consumed" at the end of the NEXT symbol, when the wave's in-order returns have long delivered it.  (An LDS-DMA
@@ -659,7 +668,7 @@ __global__ void __launch_bounds__(64) k_dec_dnarc(const u8* in, const DecDesc* d
 			for (u32 w = 0; w < R2; ++w) { cur[2 * w] = sel[w].x; cur[2 * w + 1] = sel[w].y; }
 		}
 		hash = nh;
-		win.wp = wl; win.wp_pos = wl_pos;
+		if (wl_now) { win.wp = wl; win.wp_pos = wl_pos; }
 #ifndef DSRC_EMU_BUILD
 		if (N == 4) asm volatile("" :: "v"(touch_old));
 #else
