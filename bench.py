@@ -180,7 +180,7 @@ class StepGates:
             self.gathered.add(s); self.cv.notify_all()
 
 
-def measure_decode(lanes, cfg, n_blocks, last_step, n_inst=int(os.environ.get("DSRC_BENCH_DECODE_INST", "2")), passes=2):
+def measure_decode(lanes, cfg, n_blocks, last_step, n_inst=int(os.environ.get("DSRC_BENCH_DECODE_INST", "2")), passes=int(os.environ.get("DSRC_BENCH_DECODE_PASSES", "3"))):
     """Secondary line: the same blocks back through the GPU decompressor (dsrcgpu_decompress_batch_device), everything in
     HBM.  The blocks are the ones instance 0 wrote in its last sub-batch, taken as many times as needed to make
     `n_blocks` per pass (every copy is decoded into its own text; the decoder's work does not depend on the data being distinct).
