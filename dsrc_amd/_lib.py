@@ -22,7 +22,7 @@ EXPORTS = [
     "dsrcgpu_host_free", "dsrcgpu_selftest", "dsrcgpu_set_record_layout",
     "dsrcgpu_decompress_block", "dsrcgpu_decompress_batch", "dsrcgpu_decompress_batch_device",
     "dsrcgpu_title_fields", "dsrcgpu_fields_capacity_after", "dsrcgpu_set_fields_capacity", "dsrcgpu_get_fields_capacity",
-    "dsrcgpu_chain_seed", "dsrcgpu_last_stage_timing", "dsrcgpu_try_collect", "dsrcgpu_prepare", "dsrcgpu_set_table_budget", "dsrcgpu_device_memory",
+    "dsrcgpu_chain_seed", "dsrcgpu_last_stage_timing", "dsrcgpu_try_collect", "dsrcgpu_prepare", "dsrcgpu_set_table_budget", "dsrcgpu_device_memory", "dsrcgpu_release_memory",
 ]
 
 
@@ -242,6 +242,10 @@ class Handle:
         n = C.c_uint32(1)
         self._chk(self.L.dsrcgpu_selftest(self.h, C.byref(n)))
         return n.value
+
+    def release_memory(self):
+        """Hands the batch arena and the table region back to the device (they are allocated again on demand)."""
+        self._chk(self.L.dsrcgpu_release_memory(self.h))
 
     def last_timing(self):
         ms = C.c_float(); rc_ms = C.c_float(); n = C.c_uint32()

@@ -1696,6 +1696,18 @@ int dsrcgpu_host_alloc(uint64_t bytes, void** out)
 	return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable) == hipSuccess ? DSRCGPU_OK : DSRCGPU_E_NOMEM;
 }
 
+int dsrcgpu_release_memory(dsrcgpu_handle* h)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	HIPCHK(hipSetDevice(h->device));
+	HIPCHK(hipStreamSynchronize(h->stream));
+	if (h->rc_stream) HIPCHK(hipStreamSynchronize(h->rc_stream));
+	if (h->arena.base) { HIPCHK(hipFree(h->arena.base)); h->arena.base = nullptr; h->arena.cap = 0; h->arena.top = 0; }
+	if (h->dec_tables) { HIPCHK(hipFree(h->dec_tables)); h->dec_tables = nullptr; h->dec_tables_cap = 0; }
+	h->last_d_out = nullptr;
+	return DSRCGPU_OK;
+}
+
 int dsrcgpu_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? DSRCGPU_OK : DSRCGPU_E_HIP; }
 
 int dsrcgpu_last_timing(const dsrcgpu_handle* h, float* batch_ms, float* rc_ms, uint32_t* rc_launches)

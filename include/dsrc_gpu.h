@@ -179,6 +179,11 @@ int dsrcgpu_set_record_layout(dsrcgpu_handle* h, uint32_t n, const uint32_t* chu
  * handles on one device give each its share: dsrcgpu_set_table_budget(h, bytes) (0 = automatic again). */
 int dsrcgpu_set_table_budget(dsrcgpu_handle* h, uint64_t bytes);
 int dsrcgpu_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);
+/* A handle keeps its batch arena and its table region between calls (tens of GB after a large pass).  A host that moves on to
+ * another phase on the same device (other handles, other batch sizes) hands them back with dsrcgpu_release_memory; the next call
+ * allocates again.  Not to be called while a call on this handle is in flight (queue form: after the last collect).  No
+ * counterpart in the reference: its workers' buffers live as long as the workers. */
+int dsrcgpu_release_memory(dsrcgpu_handle* h);
 
 /* Optional: brings up the HIP runtime and the device context (the first HIP call of a process costs 0.3-1 s); call it on a
  * side thread while the host opens its files. */

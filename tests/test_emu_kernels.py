@@ -450,3 +450,23 @@ def test_capacity_failure_leaves_the_block_to_block_state(emu, oracle):
     got = [r[0] for r in h.compress_batch(chunks)]
     h.close()
     assert got == want
+
+
+def test_release_memory_between_phases(emu, oracle):
+    """dsrcgpu_release_memory hands the arena and the table region back; the next call allocates again and the block-to-block
+    state (TagStats::fields capacity) is what it was."""
+    chunks = [synth.illumina_fastq(60, first=1 + 60 * k)[:-1] for k in range(3)]
+    cfg = Config.from_levels(2, 2, False, True)
+    want = [b[0] for b in oracle.compress_blocks_state(cfg, chunks + chunks)]
+    h = emu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
+    try:
+        got = [g[0] for g in h.compress_batch(chunks)]
+        h.release_memory()
+        got += [g[0] for g in h.compress_batch(chunks)]
+        assert got == want
+        h.release_memory(); h.release_memory()
+        texts = h.decompress_batch(got[:3])
+        h.release_memory()
+        assert texts == h.decompress_batch(got[:3]) == [c + b"\n" for c in chunks]
+    finally:
+        h.close()

@@ -72,6 +72,25 @@ def test_tiny_and_illumina(gpu, oracle, d, q, lossy, crc):
     check(gpu, oracle, cfg, [synth.illumina_fastq(20000)[:-1], synth.illumina_fastq(3000, first=777)[:-1]])
 
 
+def test_release_memory_between_phases(gpu, oracle):
+    """dsrcgpu_release_memory: arena and table region go back to the device, the next call allocates again; the block-to-block
+    state of the compressor survives."""
+    chunks = [synth.illumina_fastq(3000, first=1 + 3000 * k)[:-1] for k in range(3)]
+    cfg = Config.from_levels(3, 2, False, True)
+    want = [b[0] for b in oracle.compress_blocks_state(cfg, chunks + chunks)]
+    h = gpu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
+    try:
+        got = [g[0] for g in h.compress_batch(chunks)]
+        h.release_memory()
+        got += [g[0] for g in h.compress_batch(chunks)]
+        assert got == want
+        texts = h.decompress_batch(got[:3])
+        h.release_memory(); h.release_memory()
+        assert texts == h.decompress_batch(got[:3]) == [c + b"\n" for c in chunks]
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("d,q,lossy,crc", [(2, 1, True, False), (0, 0, False, False), (0, 2, False, False), (0, 1, False, True)])
 def test_iontorrent(gpu, oracle, d, q, lossy, crc):
     check(gpu, oracle, Config.from_levels(d, q, lossy, crc), [synth.iontorrent_fastq(5000)[:-1]])
