@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(64) k_dec_qrc4(const u8* in, const DecDesc* de
 	__syncthreads();
 	s.bit = ((u64)s_par[g][1] << 32) | s_par[g][0];
 	u32 err = s_par[g][2];
-	QrcScheme qs;
+	QrcScheme qs = {0u, 0u, 0u, 0u};
 	if (!qrc_scheme(prm.quality_order, prm.lossy, scheme, &qs) || qs.n != N) err |= DEC_ERR_FORMAT;
 	const u32 cnt = prm.lossy ? 8u : S->q_cnt;
 	if (active && (cnt == 0 || cnt > N || (!prm.lossy && S->q_scheme != scheme))) err |= DEC_ERR_FORMAT;

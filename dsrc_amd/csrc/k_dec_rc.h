@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(64) k_dec_qrc(const u8* in, const DecDesc* des
 	}
 	__syncthreads();
 	s.bit = ((u64)s_par[1] << 32) | s_par[0]; s.err = s_par[2];
-	QrcScheme qs;
+	QrcScheme qs = {0u, 0u, 0u, 0u};
 	if (!qrc_scheme(prm.quality_order, prm.lossy, S->q_scheme, &qs)) s.err |= DEC_ERR_FORMAT;
 	const u32 cnt = prm.lossy ? 8u : S->q_cnt;
 	if (cnt == 0 || cnt > qs.n) s.err |= DEC_ERR_FORMAT;
