@@ -37,7 +37,6 @@
 #include "k_dec_rc.h"
 #include "k_dec_tags.h"
 #include "k_dec_q0.h"
-#include "k_dec_q4.h"
 
 namespace
 {
@@ -1056,45 +1055,19 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 		{
 			const std::vector<DecRound> rounds = plan_rounds(qtabs, region_words);
 			DecTab* d_tabs = AP<DecTab>(h, o_qtabs);
-			// DSRC_GPU_DEC_Q4=1: four streams per wave (k_dec_q4.h); the streams of a wave must have one scheme: inside a round the blocks
-			// are ordered by scheme byte and every run of equal schemes is one launch
-			const bool q4 = getenv("DSRC_GPU_DEC_Q4") != nullptr;
-			if (q4) for (const DecRound& r : rounds)
-				std::stable_sort(qtabs.begin() + r.first, qtabs.begin() + r.first + r.count, [&](const DecTab& a, const DecTab& b2) { return st[a.block].q_scheme < st[b2.block].q_scheme; });
 			HIPCHK(hipMemcpyAsync(d_tabs, qtabs.data(), sizeof(DecTab) * qtabs.size(), hipMemcpyHostToDevice, s));
 			for (const DecRound& r : rounds)
 			{
 				fill_round(d_tabs, qtabs, r); KCHK();
-				if (!q4)
-				{	// one launch per alphabet size the round contains
-					u32 sizes_present = 0;
-					for (u32 i = 0; i < r.count; ++i) sizes_present |= qtabs[r.first + i].n;          // 8, 16, 32, 64, 128: one bit each
-					const DecTab* tp = d_tabs + r.first;
-					if (sizes_present & 8u)   { hipLaunchKernelGGL(k_dec_qrc<8>, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, tp, rp, d_out, h->dec_tables, prm); KCHK(); }
-					if (sizes_present & 16u)  { hipLaunchKernelGGL(k_dec_qrc<16>, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, tp, rp, d_out, h->dec_tables, prm); KCHK(); }
-					if (sizes_present & 32u)  { hipLaunchKernelGGL(k_dec_qrc<32>, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, tp, rp, d_out, h->dec_tables, prm); KCHK(); }
-					if (sizes_present & 64u)  { hipLaunchKernelGGL(k_dec_qrc<64>, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, tp, rp, d_out, h->dec_tables, prm); KCHK(); }
-					if (sizes_present & 128u) { hipLaunchKernelGGL(k_dec_qrc<128>, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, tp, rp, d_out, h->dec_tables, prm); KCHK(); }
-					continue;
-				}
-				for (u32 i = 0; i < r.count; )
-				{
-					const u32 sch = prm.lossy ? 0u : st[qtabs[r.first + i].block].q_scheme;
-					u32 n = 1;
-					while (i + n < r.count && (prm.lossy || st[qtabs[r.first + i + n].block].q_scheme == sch)) ++n;
-					const DecTab* tp = d_tabs + r.first + i;
-					const dim3 grid((n + 3) / 4);
-					switch (qtabs[r.first + i].n)
-					{
-					case 8:   hipLaunchKernelGGL(k_dec_qrc4<8>, grid, dim3(64), 0, s, io.d_in, d_desc, d_state, tp, n, rp, d_out, h->dec_tables, prm, sch); break;
-					case 16:  hipLaunchKernelGGL(k_dec_qrc4<16>, grid, dim3(64), 0, s, io.d_in, d_desc, d_state, tp, n, rp, d_out, h->dec_tables, prm, sch); break;
-					case 32:  hipLaunchKernelGGL(k_dec_qrc4<32>, grid, dim3(64), 0, s, io.d_in, d_desc, d_state, tp, n, rp, d_out, h->dec_tables, prm, sch); break;
-					case 64:  hipLaunchKernelGGL(k_dec_qrc4<64>, grid, dim3(64), 0, s, io.d_in, d_desc, d_state, tp, n, rp, d_out, h->dec_tables, prm, sch); break;
-					default:  hipLaunchKernelGGL(k_dec_qrc4<128>, grid, dim3(64), 0, s, io.d_in, d_desc, d_state, tp, n, rp, d_out, h->dec_tables, prm, sch); break;
-					}
-					KCHK();
-					i += n;
-				}
+				// one launch per alphabet size the round contains
+				u32 sizes_present = 0;
+				for (u32 i = 0; i < r.count; ++i) sizes_present |= qtabs[r.first + i].n;          // 8, 16, 32, 64, 128: one bit each
+				const DecTab* tp = d_tabs + r.first;
+				if (sizes_present & 8u)   { hipLaunchKernelGGL(k_dec_qrc<8>, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, tp, rp, d_out, h->dec_tables, prm); KCHK(); }
+				if (sizes_present & 16u)  { hipLaunchKernelGGL(k_dec_qrc<16>, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, tp, rp, d_out, h->dec_tables, prm); KCHK(); }
+				if (sizes_present & 32u)  { hipLaunchKernelGGL(k_dec_qrc<32>, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, tp, rp, d_out, h->dec_tables, prm); KCHK(); }
+				if (sizes_present & 64u)  { hipLaunchKernelGGL(k_dec_qrc<64>, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, tp, rp, d_out, h->dec_tables, prm); KCHK(); }
+				if (sizes_present & 128u) { hipLaunchKernelGGL(k_dec_qrc<128>, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, tp, rp, d_out, h->dec_tables, prm); KCHK(); }
 			}
 		}
 		hipLaunchKernelGGL(k_dec_dhead, dim3((B + 63) / 64), dim3(64), 0, s, io.d_in, d_desc, d_state, prm); KCHK();
@@ -1672,16 +1645,17 @@ int dsrcgpu_device_memory(int device, uint64_t* free_bytes, uint64_t* total_byte
 
 // Every scheduler instance drives two HIP streams, and the HIP runtime multiplexes streams onto 4 hardware queues unless
 // GPU_MAX_HW_QUEUES says otherwise: unrelated instances then wait behind each other's range coder (7.7 instead of 12.9 GB/s,
-// DESIGN section 3).  The runtime reads the variable when it starts, i.e. at the process's first HIP call: it is set (when the
-// embedding process has not chosen a value) as soon as this library is loaded, and again by dsrcgpu_prepare for hosts that load
-// the library late; a process that has already used HIP keeps what it started with.
-#ifndef DSRC_EMU_BUILD
-__attribute__((constructor)) static void dsrcgpu_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
-#endif
+// DESIGN section 3).  The runtime reads the variable when it starts, i.e. at the process's first HIP call.  The library does NOT
+// touch the environment on its own when it is loaded (an embedding application's queue configuration is its own business):
+// dsrcgpu_prepare is the opt-in -- a host that calls it before its first HIP call (dsrc-amd, pydsrc, bench.py do) gets 24 queues
+// unless the process has already chosen a value; everybody else exports the variable themselves.
 
 int dsrcgpu_prepare(int device)
 {
-	setenv("GPU_MAX_HW_QUEUES", "24", 0);
+	{	// once per process, never over a value the process has chosen; hosts call this from several threads (one per device)
+		static std::once_flag once;
+		std::call_once(once, []() { if (!getenv("GPU_MAX_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", "24", 0); });
+	}
 	// first touch of a device: the HIP runtime loads the code objects and creates the context (0.3-1 s); hosts call this
 	// on a side thread while they open files, so that dsrcgpu_create finds the device ready
 	if (hipSetDevice(device) != hipSuccess) return DSRCGPU_E_HIP;

@@ -757,6 +757,10 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 		rd.Open(args.inputFilename);
 		if (args.useFastqStdIo) out = stdout;
 		else { out = fopen(args.outputFilename.c_str(), "w+b"); if (!out) throw DsrcException("Cannot open file to write:" + args.outputFilename); }      // readable too: the output is mapped
+		// Only a regular file can be sized, mapped and written at positions; anything else that was named as the output (a pipe,
+		// /dev/stdout, a process substitution) gets its bytes in batch order through fwrite, like stdout and like the reference
+		bool regular = false;
+		if (out != stdout) { struct stat sb; regular = fstat(fileno(out), &sb) == 0 && S_ISREG(sb.st_mode); }
 
 		const uint64 nBlocks = rd.BlockCount();
 		// A decoding pass is a chain per block: it takes about as long for 1000 blocks as for 10, so
@@ -767,8 +771,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 		// 19 GB a pass copies into the mapped output: 38.5 GB set, batches of 2300 blocks 16.9 s, of 1024 blocks 15.2 s.)
 		const std::vector<int> devs = args.devices.empty() ? std::vector<int>(1, args.device) : args.devices;
 		const bool tables = rd.Settings().dnaOrder > 0 || rd.Settings().qualityOrder > 0;
-		const char* envInst = getenv("DSRC_HOST_DEC_INSTANCES");          // experiments: decoding handles per device
-		const uint32 perDev = envInst ? std::max(1, atoi(envInst)) : std::min<uint32>(std::max(1u, args.threadNum), tables ? 3u : 4u);
+		const uint32 perDev = std::min<uint32>(std::max(1u, args.threadNum), tables ? 3u : 4u);
 		const uint32 wanted = perDev * (uint32)devs.size();
 		std::vector<std::pair<uint64, uint64> > batches;
 		{
@@ -808,7 +811,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 			std::vector<std::thread>& th; uchar*& p; uint64& n;
 			~MapGuard() { for (auto& t : th) if (t.joinable()) t.join(); if (p) munmap(p, n); p = nullptr; }
 		} mapGuard{faulters, map, mapBytes};
-		if (out != stdout && !getenv("DSRC_HOST_NO_MMAP") && nBlocks)
+		if (regular && !getenv("DSRC_HOST_NO_MMAP") && nBlocks)
 		{
 			std::vector<uint32> words(nBlocks); std::vector<uint64_t> bsz(nBlocks);
 			bool ok = true;
@@ -834,7 +837,9 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 					mapAt[k] = total;
 					for (uint64 i = batches[k].first; i < batches[k].second; ++i) { mapCaps[k].push_back((uint64)words[i] + 1); total += (uint64)words[i] + 1; }
 				}
-				if (total && ftruncate(fileno(out), (off_t)total) == 0)
+				// the space is reserved, not just declared: a full disk shows here (and the buffered path reports it) instead of as a
+				// SIGBUS in the middle of a copy into the mapping; a file system without fallocate takes the buffered path as well
+				if (total && fallocate(fileno(out), 0, 0, (off_t)total) == 0)
 				{
 					void* q = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fileno(out), 0);
 					if (q != MAP_FAILED)
@@ -856,6 +861,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 					}
 					else if (ftruncate(fileno(out), 0) != 0) throw DsrcException("Error writing FASTQ output");
 				}
+				else if (total && ftruncate(fileno(out), 0) != 0) throw DsrcException("Error writing FASTQ output");
 			}
 		}
 
@@ -866,15 +872,19 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 			if (trace) fprintf(stderr, "[dsrc-amd d] worker %u batch %llu %-10s %8.1f ms\n", idx, (unsigned long long)k, what,
 							   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 		};
-		// experiments: the first pass of worker i starts i * DSRC_HOST_DEC_STAGGER_MS late (passes that run in step meet in the same stage)
-		const uint32 staggerMs = getenv("DSRC_HOST_DEC_STAGGER_MS") ? (uint32)atoi(getenv("DSRC_HOST_DEC_STAGGER_MS")) : 0u;
+		// one handle per worker, kept across the two rounds of an archive whose mapped attempt is abandoned: a second set of
+		// instances would claim the arenas and the model-table share a second time
+		std::vector<dsrcgpu_handle*> handles(instances, nullptr);
 		auto work = [&](uint32 idx)
 		{
-			dsrcgpu_handle* h = nullptr;
+			dsrcgpu_handle*& h = handles[idx];
 			try
 			{
-				h = CreateDecodeInstance(devs[idx % devs.size()], rd.Settings(), rd.Type());
-				mark(idx, 0, "instance");
+				if (!h)
+				{
+					h = CreateDecodeInstance(devs[idx % devs.size()], rd.Settings(), rd.Type());
+					mark(idx, 0, "instance");
+				}
 				if (tableShare) dsrcgpu_set_table_budget(h, tableShare);
 				Pinned in, text;
 				for (;;)
@@ -919,7 +929,6 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 						if (rd.BlockSizes()[lo - 1] >= 16 && pread(rd.Fd(), hb, 16, (off_t)rd.BlockOffset(lo - 1)) == 16) { before = (uint32)GetBE(hb + 12, 4); haveBefore = true; }
 					}
 					mark(idx, k, "read");
-					if (staggerMs && k < instances) std::this_thread::sleep_for(std::chrono::milliseconds((long long)staggerMs * (long long)k));
 					int rc = DSRCGPU_OK;
 					if (map && !mapBroken)
 					{
@@ -959,7 +968,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 						if (!error.empty()) break;
 						// a file: the batch claims its range (that needs the sizes of the batches before it, not their bytes) and
 						// passes the turn on at once; a pipe: the bytes go out in turn
-						if (out != stdout) { fileAt = outPos; outPos += total; ++writeTurn; cv.notify_all(); }
+						if (regular) { fileAt = outPos; outPos += total; ++writeTurn; cv.notify_all(); }
 					}
 					// texts are laid out back to back; they are contiguous whenever every block fills its reservation
 					std::vector<std::pair<uint64, uint64> > runs;           // (offset in text.p, length)
@@ -970,7 +979,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 						if (len) runs.emplace_back(offs[i], len);
 						i = j + 1;
 					}
-					if (out == stdout)
+					if (!regular)
 					{
 						for (const auto& r : runs)
 							if (fwrite(text.p + r.first, 1, r.second, out) != r.second) throw DsrcException("Error writing FASTQ output (disk full?)");
@@ -1011,16 +1020,20 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 				}
 			}
 			catch (const std::exception& e) { std::lock_guard<std::mutex> g(m); if (error.empty()) error = e.what(); cv.notify_all(); }
-			// a command-line process that is about to leave keeps its handles: freeing ~100 GB of arenas and tables takes seconds
-			if (h && !args.exitWhenDone) dsrcgpu_destroy(h);
 		};
+		// a command-line process that is about to leave keeps its handles: freeing ~100 GB of arenas and tables takes seconds
+		struct HandleGuard
+		{
+			std::vector<dsrcgpu_handle*>& hs; std::vector<std::thread>& th; bool keep;
+			~HandleGuard() { for (auto& t : th) if (t.joinable()) t.join(); if (!keep) for (auto*& h : hs) if (h) { dsrcgpu_destroy(h); h = nullptr; } }
+		} handleGuard{handles, workers, args.exitWhenDone};
 		for (uint32 i = 0; i < instances; ++i) workers.emplace_back(work, i);
 		for (auto& t : workers) t.join();
 		workers.clear();
 		mark(0, batches.size(), "all decoded");
 		for (auto& t : faulters) t.join();
 		faulters.clear();
-		if (args.exitWhenDone && error.empty() && !mapBroken && out != stdout)
+		if (args.exitWhenDone && error.empty() && !mapBroken && regular)
 		{	// the text is in the page cache (through the mapping or pwrite); unmapping, closing and the HIP teardown are the
 			// kernel's job at exit, where nobody waits for them one after the other
 			if (args.verboseLog) fputs(GetLog().c_str(), stderr);

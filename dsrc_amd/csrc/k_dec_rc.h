@@ -145,7 +145,7 @@ __device__ __forceinline__ u32 qrc_readlane(u32 v, u32 l)
 }
 
 // lane i gets lane i - 1's value, lane 0 gets 0 (wave_shr:1).  The result only ever feeds v_readlane here: a DPP move that the
-// compiler folds into a following SUBTRACTION came out wrong on gfx950 (k_dec_q4.h, q4_shr1)
+// compiler folds into a following SUBTRACTION came out wrong on gfx950 (round 3's four-streams-per-wave experiment, removed in round 4: git show 36bc838)
 __device__ __forceinline__ u32 qrc_up1(u32 v)
 {
 #ifdef DSRC_EMU_BUILD

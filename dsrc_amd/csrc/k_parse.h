@@ -494,25 +494,11 @@ __global__ void __launch_bounds__(WG) k_prep_write(const u8* in, const BlkDesc* 
 			u32 sidx = 0, q = 0; bool keep = false;
 			{	// every lane evaluates the (branch-free) transform, lanes past the end of the read on a harmless stand-in: with the call
 				// inside `if (in_r)` this kernel gave a wrong quality stream on the GPU once dna_index had become selects (DESIGN.md
-				// section 10) -- the emulator build, the function on its own and k_prep_stats with the same call were all right
-#ifdef DSRC_PREP_WRITE_IN_IF          // tools/r03_prep_write_repro.sh: the form that miscompared in round 2, kept to be able to reproduce and diff it
-#if DSRC_PREP_WRITE_IN_IF == 2         // bisection: the lossy branch compiled out
-				if (in_r) q = transform_base<FAST_WRITE>(p[so + j], p[qo + j], prm.quality_offset, 0u, &sidx, &keep);
-#elif DSRC_PREP_WRITE_IN_IF == 3       // bisection: keep carried as an integer
-				u32 keep_i = 0;
-				if (in_r) { bool kk = false; q = transform_base<FAST_WRITE>(p[so + j], p[qo + j], prm.quality_offset, prm.lossy, &sidx, &kk); keep_i = kk ? 1u : 0u; }
-				keep = keep_i != 0;
-#elif DSRC_PREP_WRITE_IN_IF == 4       // bisection: the loads hoisted out of the call
-				const u32 cb = in_r ? (u32)p[so + j] : 0u, cq = in_r ? (u32)p[qo + j] : 0u;
-				if (in_r) q = transform_base<FAST_WRITE>(cb, cq, prm.quality_offset, prm.lossy, &sidx, &keep);
-#else
-				if (in_r) q = transform_base<FAST_WRITE>(p[so + j], p[qo + j], prm.quality_offset, prm.lossy, &sidx, &keep);
-#endif
-#else
+				// section 10; both forms as a stand-alone kernel: tools/prep_write_repro.hip) -- the emulator build, the function on its own and
+				// k_prep_stats with the same call were all right
 				const u32 cb = in_r ? (u32)p[so + j] : (u32)'A', cq = in_r ? (u32)p[qo + j] : prm.quality_offset + 40u;
 				const u32 qq = transform_base<FAST_WRITE>(cb, cq, prm.quality_offset, prm.lossy, &sidx, &keep);
 				if (in_r) q = qq; else { keep = false; sidx = 0; }
-#endif
 			}
 			const bool k2 = in_r && keep;
 			const u64 km = __ballot(k2);

@@ -186,7 +186,9 @@ int dsrcgpu_device_memory(int device, uint64_t* free_bytes, uint64_t* total_byte
 int dsrcgpu_release_memory(dsrcgpu_handle* h);
 
 /* Optional: brings up the HIP runtime and the device context (the first HIP call of a process costs 0.3-1 s); call it on a
- * side thread while the host opens its files. */
+ * side thread while the host opens its files.  It is also the opt-in for the queue setting several handles per device need:
+ * when the process has not set GPU_MAX_HW_QUEUES, the first call sets it to 24 -- effective only if this is the process's first
+ * HIP call (the runtime reads the variable when it starts).  The library never touches the environment otherwise. */
 int dsrcgpu_prepare(int device);
 
 /* Page-locked host memory for chunk / block buffers: host<->device copies from it run at PCIe speed and

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the test processes run several scheduler instances per GPU: their own choice of HIP hardware queues (INTEGRATION.md section 4;
+# the library does not touch the environment on load)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

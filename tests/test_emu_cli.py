@@ -90,3 +90,27 @@ def test_direct_io_reader_writes_the_same_archive(cli, tmp_path):
                 if os.path.exists(p):
                     os.unlink(p)
     assert len(got) == 2
+
+
+def test_decompress_into_a_pipe_and_a_crlf_archive(cli, tmp_path):
+    """Outputs that are not regular files (stdout by name -- /dev/stdout, /proc/self/fd/1 --, a named pipe) get their bytes in batch order through the in-turn
+    fwrite path -- they can be neither sized nor mapped nor written at positions (the reference fwrites in order).  An archive of
+    CRLF text decodes shorter than its blocks declare: the mapped attempt is abandoned and the same handles decode it again
+    through the buffered path (one `instance` line per worker in the trace, not two)."""
+    data = synth.illumina_fastq(300)
+    src = tmp_path / "a.fastq"; src.write_bytes(data)
+    arc = tmp_path / "a.dsrc"
+    subprocess.check_call([cli, "c", "-d1", "-q1", "-b1", str(src), str(arc)])
+    r = subprocess.run("%s d -t2 -n1 %s /proc/self/fd/1 | cat" % (cli, arc), shell=True, capture_output=True, check=True)
+    assert r.stdout == data
+    fifo = tmp_path / "out.fifo"; os.mkfifo(fifo)
+    reader = subprocess.Popen(["cat", str(fifo)], stdout=subprocess.PIPE)
+    subprocess.check_call([cli, "d", "-t2", "-n1", str(arc), str(fifo)])
+    assert reader.communicate(timeout=60)[0] == data
+    # CRLF input: same records, line ends dropped by the block format
+    crlf = tmp_path / "c.fastq"; crlf.write_bytes(synth.illumina_fastq(300, crlf=True))
+    arc2 = tmp_path / "c.dsrc"; back = tmp_path / "c.out"
+    subprocess.check_call([cli, "c", "-d1", "-q1", "-b1", str(crlf), str(arc2)])
+    r = subprocess.run([cli, "d", "-t2", "-n1", str(arc2), str(back)], env=dict(os.environ, DSRC_HOST_TRACE="1"), capture_output=True, check=True)
+    assert back.read_bytes() == data
+    assert r.stderr.count(b"instance") <= 2

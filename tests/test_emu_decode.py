@@ -173,11 +173,10 @@ def test_wave_kernels_every_level(emu, oracle, d, q, lossy, crc):
 
 
 @pytest.mark.parametrize("d,q,lossy", [(3, 2, False), (2, 1, True), (1, 1, False)])
-def test_wave_four_streams_per_wave_switch(emu, oracle, d, q, lossy, monkeypatch):
-    """DSRC_GPU_DEC_Q4=1: k_dec_qrc4 (four quality streams per wave, a row of 16 lanes each): blocks of different lengths in one wave
-    (rows end at different times), a batch that does not fill its last wave, and rows hot enough for Rescale()."""
+def test_wave_kernels_mixed_lengths_and_hot_rows(emu, oracle, d, q, lossy):
+    """k_dec_qrc / k_dec_dnarc on a batch of blocks of very different lengths (the lanes of k_dec_dnarc end at different times),
+    and rows hot enough for Rescale()."""
     import random
-    monkeypatch.setenv("DSRC_GPU_DEC_Q4", "1")
     rng = random.Random(5 * d + q)
     hot = b"\n".join([b"@r\nA\n+\n%c" % (73 if rng.random() < 0.97 else 60) for _ in range(42000)] + [b"@h\n%s\n+\n%s" % (b"A" * 100, b"I" * 100) for _ in range(40)])
     chunks = [synth.illumina_fastq(40)[:-1], hot, synth.illumina_fastq(90, first=500)[:-1], TINY, synth.illumina_fastq(10, first=7)[:-1]]
