@@ -29,6 +29,7 @@
 #include "k_common.h"
 #include "k_parse.h"
 #include "k_rc.h"
+#include "k_bucket.h"
 #include "k_huff.h"
 #include "k_tags.h"
 #include "k_block.h"
@@ -569,6 +570,47 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			}
 		}
 	}
+	// Bucketed path (k_bucket.h): per job the bucket digit, the key mixing and its words of the `bk` pool; per launch group (the
+	// streams of one alphabet size inside a slice) a fallback list that k_part fills with the streams it hands back to k_sort / k_replay
+	struct BkGroup { u32 lo, hi, fb; };
+	std::vector<std::vector<BkGroup> > bk_groups(slice_lo.size());
+	static const bool bk_enabled = getenv("DSRC_GPU_BUCKETS") && atoi(getenv("DSRC_GPU_BUCKETS")) != 0;      // off by default while it is slower than k_sort / k_replay (profiles/r04_ks_*)
+	static const u32 bk_min = getenv("DSRC_GPU_BUCKETS_MIN") ? (u32)atoi(getenv("DSRC_GPU_BUCKETS_MIN")) : 16384u;   // shorter streams: a bucket per workgroup does not pay
+	static const bool bk_binned = !(getenv("DSRC_GPU_BUCKETS_BINNED") && atoi(getenv("DSRC_GPU_BUCKETS_BINNED")) == 0);
+	const bool use_bk = bk_enabled && NJ > 0;
+	size_t o_bk = 0, bk_zero_words = 0;
+	if (use_bk)
+	{
+		u32 cur = NJ;                                            // [0, NJ): the jobs' fallback flags
+		for (size_t sl = 0; sl + 1 < slice_lo.size(); ++sl)
+			for (u32 lo = slice_lo[sl]; lo < slice_lo[sl + 1];)
+			{
+				u32 hi = lo;
+				while (hi < slice_lo[sl + 1] && jobs[hi].n_alpha == jobs[lo].n_alpha) ++hi;
+				bk_groups[sl].push_back({lo, hi, cur});
+				for (u32 i = lo; i < hi; ++i) jobs[i].bk_fb = cur;
+				cur += 1 + (hi - lo);
+				lo = hi;
+			}
+		for (u32 i = 0; i < NJ; ++i)
+		{
+			CtxJob& j = jobs[i];
+			j.jid = i;
+			const u32 n_bins = (j.n + BK_BIN - 1) >> BK_TB;
+			j.bk_binned = bk_binned ? 1u : 0u;
+			j.bk_on = (j.n >= bk_min && n_bins <= BK_MAX_BINS && j.key_bits <= BK_MAX_HB + BK_MAX_LB) ? 1u : 0u;
+			// bucket digit: ~2048 elements per bucket on average, at most 1024 buckets, at most BK_MAX_LB key bits left for the LDS sort
+			u32 hb = 0; while (hb < BK_MAX_HB && ((u64)2048 << hb) < j.n) ++hb;
+			hb = std::min(hb, j.key_bits);
+			if (j.key_bits > BK_MAX_LB) hb = std::max(hb, j.key_bits - BK_MAX_LB);
+			j.bk_hb = hb; j.bk_lb = j.key_bits - hb;
+			j.bk_mul = BK_HASH_MUL; j.bk_kmask = (u32)((1ull << j.key_bits) - 1ull);
+			j.bk_fill = cur; cur += j.bk_on ? n_bins : 0u;
+		}
+		bk_zero_words = cur;
+		for (u32 i = 0; i < NJ; ++i) { jobs[i].bk_boff = cur; cur += jobs[i].bk_on ? (1u << jobs[i].bk_hb) + 1u : 0u; }
+		o_bk = A.alloc((size_t)cur * 4 + 64);
+	}
 	const size_t o_jobs = A.alloc(sizeof(CtxJob) * std::max(1u, NJ)), o_chains = A.alloc(sizeof(RcChain) * std::max(1u, NJ));
 	const size_t o_fin = A.alloc(sizeof(RcFin) * std::max(1u, NJ));
 	if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (phase 3b): batch needs > %zu bytes of HBM scratch", A.top);
@@ -668,10 +710,59 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		const u32 nq = (u32)qjobs.size(), nd = (u32)djobs.size();
 		const bool sort_atomic = h->sort_atomic;
 		hipLaunchKernelGGL(k_rc_headers, dim3((NJ + 63) / 64), dim3(64), 0, s, d_jobs, NJ, d_state, wpool); KCHK();
+		u32* d_bk = use_bk ? AP<u32>(h, o_bk) : nullptr;
+		if (use_bk) HIPCHK(hipMemsetAsync(d_bk, 0, bk_zero_words * 4, s));
+		static const u32 max_parts = getenv("DSRC_GPU_REPLAY_PARTS") ? (u32)atoi(getenv("DSRC_GPU_REPLAY_PARTS")) : 2048u;   // tuning knob of k_replay
 		for (size_t sl = 0; sl + 1 < slice_lo.size(); ++sl)
 		{
 			const u32 s_lo = slice_lo[sl], s_hi = slice_lo[sl + 1];
 			stage_mark(0);
+			if (use_bk)
+			{	// k_bucket.h: partition, finish in LDS, place -- and behind them k_sort / k_replay for the streams k_part handed back
+				if (sort_atomic) hipLaunchKernelGGL((k_part<true>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk);
+				else hipLaunchKernelGGL((k_part<false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk);
+				KCHK();
+				stage_mark(0); stage_mark(1);
+				u32 slice_bins = 0;
+				for (const BkGroup& g : bk_groups[sl])
+				{
+					u32 hb = 0; bool any = false;
+					for (u32 i = g.lo; i < g.hi; ++i) if (jobs[i].bk_on) { any = true; hb = std::max(hb, jobs[i].bk_hb); slice_bins = std::max(slice_bins, (jobs[i].n + BK_BIN - 1) >> BK_TB); }
+					if (!any) continue;
+					const dim3 fgrid(1u << hb, g.hi - g.lo);
+#define BK_FINISH(NN) { if (sort_atomic) hipLaunchKernelGGL((k_finish<NN, true>), fgrid, dim3(BK_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
+						else hipLaunchKernelGGL((k_finish<NN, false>), fgrid, dim3(BK_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); }
+					switch (jobs[g.lo].n_alpha)
+					{
+					case 4: BK_FINISH(4) break; case 8: BK_FINISH(8) break; case 16: BK_FINISH(16) break;
+					case 32: BK_FINISH(32) break; case 64: BK_FINISH(64) break; default: BK_FINISH(128) break;
+					}
+#undef BK_FINISH
+					KCHK();
+				}
+				if (bk_binned && slice_bins) { hipLaunchKernelGGL(k_place, dim3(slice_bins, s_hi - s_lo), dim3(PLACE_WG), 0, s, d_jobs + s_lo, AP<RcPack>(h, 0), d_bk); KCHK(); }
+				for (const BkGroup& g : bk_groups[sl])
+				{	// the group's fallback list (usually empty: the workgroups find a zero count and leave)
+					const u32 cnt = g.hi - g.lo;
+					const u32* fb = d_bk + g.fb;
+					if (sort_atomic) hipLaunchKernelGGL((k_sort<0, true>), dim3(std::min(cnt, 16u)), dim3(SORT_WG), 0, s, d_jobs, lpool, d_d, d_q, d_qp, d_state, fb);
+					else hipLaunchKernelGGL((k_sort<0, false>), dim3(std::min(cnt, 16u)), dim3(SORT_WG), 0, s, d_jobs, lpool, d_d, d_q, d_qp, d_state, fb);
+					u32 mxn = 1; for (u32 i = g.lo; i < g.hi; ++i) mxn = std::max(mxn, jobs[i].n);
+					const u32 parts = std::max(1u, std::min(max_parts, mxn / 1024u));
+					const dim3 rgrid(parts * std::min(cnt, 4u));
+#define BK_REPLAY(NN) { hipLaunchKernelGGL(k_replay_seams<NN>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs, const_cast<u64*>(lpool), parts, cnt, fb); \
+						hipLaunchKernelGGL((k_replay<NN, 0>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs, lpool, AP<RcPack>(h, 0), parts, cnt, fb); }
+					switch (jobs[g.lo].n_alpha)
+					{
+					case 4: BK_REPLAY(4) break; case 8: BK_REPLAY(8) break; case 16: BK_REPLAY(16) break;
+					case 32: BK_REPLAY(32) break; case 64: BK_REPLAY(64) break; default: BK_REPLAY(128) break;
+					}
+#undef BK_REPLAY
+					KCHK();
+				}
+				stage_mark(1);
+				continue;
+			}
 #ifdef DSRC_SORT_PROBE
 			{	// timing experiments (not a product path): what each phase of k_sort costs, first slice of the first batches
 				static int shots = 0;
@@ -679,15 +770,15 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 				{
 					++shots;
 					hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-#define PROBE_RUN(M) { hipEventRecord(e0, s); if (sort_atomic) hipLaunchKernelGGL((k_sort<M, true>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state); else hipLaunchKernelGGL((k_sort<M, false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state); \
+#define PROBE_RUN(M) { hipEventRecord(e0, s); if (sort_atomic) hipLaunchKernelGGL((k_sort<M, true>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, nullptr); else hipLaunchKernelGGL((k_sort<M, false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, nullptr); \
 					hipEventRecord(e1, s); hipEventSynchronize(e1); float ms = 0; hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[probe] k_sort<%u> %u streams: %.2f ms\n", (unsigned)M, s_hi - s_lo, ms); }
 					PROBE_RUN(0) PROBE_RUN(0) PROBE_RUN(128) PROBE_RUN(129) PROBE_RUN(130) PROBE_RUN(132) PROBE_RUN(134) PROBE_RUN(136) PROBE_RUN(144) PROBE_RUN(160) PROBE_RUN(192) PROBE_RUN(255)
 					hipEventDestroy(e0); hipEventDestroy(e1);
 				}
 			}
 #endif
-			if (sort_atomic) hipLaunchKernelGGL((k_sort<0, true>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state);
-			else hipLaunchKernelGGL((k_sort<0, false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state);
+			if (sort_atomic) hipLaunchKernelGGL((k_sort<0, true>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, nullptr);
+			else hipLaunchKernelGGL((k_sort<0, false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, nullptr);
 			KCHK();
 			stage_mark(0); stage_mark(1);
 			for (u32 lo = s_lo; lo < s_hi;)
@@ -700,7 +791,6 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 				// chain have to meet in the memory-side cache before their line is evicted, and with several scheduler instances
 				// streaming through that cache the time a chain is open counts (one instance, 512 DNA chains: 32 parts 164 ms,
 				// 512 parts 71 ms; five instances: 256 parts 21.4, 512 23.3, 1024 24.3, 2048 24.7, 3200 23.2 GB/s)
-				static const u32 max_parts = getenv("DSRC_GPU_REPLAY_PARTS") ? (u32)atoi(getenv("DSRC_GPU_REPLAY_PARTS")) : 2048u;   // tuning knob
 				const u32 parts = std::max(1u, std::min(max_parts, mxn / 1024u));
 				const dim3 rgrid(parts * cnt);                           // replay_slot
 #ifdef DSRC_SORT_PROBE
@@ -710,9 +800,9 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 					{
 						++shots;
 						hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-#define RPROBE_RUN(NN, M) { hipEventRecord(e0, s); hipLaunchKernelGGL((k_replay<NN, M>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt); \
+#define RPROBE_RUN(NN, M) { hipEventRecord(e0, s); hipLaunchKernelGGL((k_replay<NN, M>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt, nullptr); \
 						hipEventRecord(e1, s); hipEventSynchronize(e1); float ms = 0; hipEventElapsedTime(&ms, e0, e1); fprintf(stderr, "[probe] k_replay<%d,%d> %u streams x %u parts: %.2f ms\n", NN, M, cnt, parts, ms); }
-						hipLaunchKernelGGL(k_replay_seams<32>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt);
+						hipLaunchKernelGGL(k_replay_seams<32>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt, nullptr);
 						if (jobs[lo].n_alpha == 32) { RPROBE_RUN(32, 0) RPROBE_RUN(32, 0) RPROBE_RUN(32, 1) RPROBE_RUN(32, 2) RPROBE_RUN(32, 8) RPROBE_RUN(32, 16) }
 						else { RPROBE_RUN(4, 0) RPROBE_RUN(4, 0) RPROBE_RUN(4, 1) RPROBE_RUN(4, 2) RPROBE_RUN(4, 8) RPROBE_RUN(4, 16) }
 						hipEventDestroy(e0); hipEventDestroy(e1);
@@ -721,12 +811,12 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 #endif
 				switch (jobs[lo].n_alpha)
 				{
-				case 4:   hipLaunchKernelGGL(k_replay_seams<4>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<4, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt); break;
-				case 8:   hipLaunchKernelGGL(k_replay_seams<8>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<8, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt); break;
-				case 16:  hipLaunchKernelGGL(k_replay_seams<16>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<16, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt); break;
-				case 32:  hipLaunchKernelGGL(k_replay_seams<32>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<32, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt); break;
-				case 64:  hipLaunchKernelGGL(k_replay_seams<64>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<64, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt); break;
-				default:  hipLaunchKernelGGL(k_replay_seams<128>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt); hipLaunchKernelGGL((k_replay<128, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt); break;
+				case 4:   hipLaunchKernelGGL(k_replay_seams<4>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt, nullptr); hipLaunchKernelGGL((k_replay<4, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt, nullptr); break;
+				case 8:   hipLaunchKernelGGL(k_replay_seams<8>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt, nullptr); hipLaunchKernelGGL((k_replay<8, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt, nullptr); break;
+				case 16:  hipLaunchKernelGGL(k_replay_seams<16>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt, nullptr); hipLaunchKernelGGL((k_replay<16, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt, nullptr); break;
+				case 32:  hipLaunchKernelGGL(k_replay_seams<32>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt, nullptr); hipLaunchKernelGGL((k_replay<32, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt, nullptr); break;
+				case 64:  hipLaunchKernelGGL(k_replay_seams<64>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt, nullptr); hipLaunchKernelGGL((k_replay<64, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt, nullptr); break;
+				default:  hipLaunchKernelGGL(k_replay_seams<128>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, const_cast<u64*>(lpool), parts, cnt, nullptr); hipLaunchKernelGGL((k_replay<128, DSRC_REPLAY_WHATIF>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs + lo, lpool, AP<RcPack>(h, 0), parts, cnt, nullptr); break;
 				}
 				KCHK();
 				lo = hi;
@@ -749,8 +839,16 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 
 	// ---- sizes -> output layout -> assembly -----------------------------------------------------------------------
 	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
+	std::vector<u32> bk_flags;
+	if (use_bk && getenv("DSRC_GPU_DEBUG")) { bk_flags.resize(NJ); HIPCHK(hipMemcpyAsync(bk_flags.data(), AP<u32>(h, o_bk), NJ * 4, hipMemcpyDeviceToHost, s)); }
 	HIPCHK(hipStreamSynchronize(s));
 	mark("S4");
+	if (!bk_flags.empty())
+	{
+		u32 on = 0, back = 0;
+		for (u32 i = 0; i < NJ; ++i) { on += jobs[i].bk_on; back += bk_flags[i] && jobs[i].bk_on; }
+		fprintf(stderr, "[dsrc_gpu] bucketed path: %u of %u streams tried, %u handed back to k_sort / k_replay\n", on, NJ, back);
+	}
 	u64 total = 0;
 	for (u32 b = 0; b < B; ++b)
 	{

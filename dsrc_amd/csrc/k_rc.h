@@ -49,7 +49,15 @@ struct CtxJob     // one (block, stream)
 	u32 n_alpha;        // alphabet size (replay template selector)
 	u32 qlen;           // quality: read length if every read of the block has the same one (then qp_stream does not exist), else 0
 	u32 qm_lo, qm_hi;   // ceil(2^48 / qlen) for exact_div
-	u32 pad0;
+	u32 jid;            // index of the job in the batch's job array (per-job words of the `bk` pool, fallback lists)
+	// bucketed path (k_bucket.h); bk_on = 0: the stream goes through k_sort / k_replay
+	u32 bk_on, bk_binned;
+	u32 bk_hb, bk_lb;   // bucket digit bits / key bits sorted in LDS (bk_hb + bk_lb = key_bits)
+	u32 bk_mul, bk_kmask; // key = (ctx * bk_mul) & bk_kmask
+	u32 bk_boff;        // bk index of the stream's 2^bk_hb + 1 bucket offsets
+	u32 bk_fb;          // bk index of the fallback list of the stream's launch group: count, then job ids
+	u32 bk_fill;        // bk index of the stream's time-bin fill counters
+	u32 pad0, pad1;
 };
 
 typedef u64 __attribute__((aligned(1))) u64_unaligned;
@@ -196,8 +204,9 @@ __device__ __forceinline__ u32 ctx_digit0(const CtxJob& j, const u8* s, const u8
 // tile position p to dst[tile + p]; 1 no digit-0 histogram, 2 no ranking, 4 no per-tile scan, 8 nothing leaves the registers,
 // 16 no global store, 32 elements made up instead of loaded / computed, 64 no next-digit histogram
 template <u32 PROBE, bool ATOMIC>
-__global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SORT_OCC, SORT_OCC))) k_sort(const CtxJob* jobs, u64* pool, const u8* d_stream, const u8* q_stream, const u8* qp_stream, BlkState* st)
-{
+__global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SORT_OCC, SORT_OCC))) k_sort(const CtxJob* jobs, u64* pool, const u8* d_stream, const u8* q_stream, const u8* qp_stream, BlkState* st, const u32* fb)
+{	// fb == nullptr: workgroup i sorts jobs[i].  Otherwise fb = {count, job ids ...} (the streams k_part handed back, k_bucket.h) and
+	// the workgroups of the launch share the list.
 	__shared__ u32 s_base[SORT_MAX_BINS];                 // where the next element of a digit goes (index into dst)
 	__shared__ u32 s_next[SORT_MAX_BINS];
 	__shared__ u32 s_delta[SORT_MAX_BINS];                // tile position p of an element with digit d -> dst index s_delta[d] + p
@@ -206,7 +215,10 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 	__shared__ u64 s_tile[SORT_WG * SORT_ITEMS];          // the tile in digit order.  102 KB in all: one workgroup per CU, next to a k_rc workgroup's 53 KB
 	__shared__ u32 s_ws[SORT_WAVES];
 	__shared__ u8 s_rank[256];
-	const CtxJob j = jobs[blockIdx.x];
+	const u32 n_f = fb ? fb[0] : gridDim.x;
+	for (u32 f_i = blockIdx.x; f_i < n_f; f_i += gridDim.x)
+	{
+	const CtxJob j = jobs[fb ? fb[1 + f_i] : f_i];
 	const u32 n = j.n, bins = 1u << j.dbits;
 	const u32 wv = wave_id(), lane = lane_id();
 	constexpr u32 nw = SORT_WAVES;                           // always launched with SORT_WG threads
@@ -393,6 +405,7 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 		for (u32 i = threadIdx.x; i < bins; i += blockDim.x) s_base[i] = s_next[i];
 		__syncthreads();
 	}
+	}
 }
 
 // ceil(2^48 / d) for 2 <= d < 2^16 without a 64-bit integer division (a ~100-instruction sequence on this machine):
@@ -546,12 +559,9 @@ __device__ __forceinline__ u32 replay_snap(const u64* src, u32 b, u32 n, bool* i
 }
 
 template <int N>
-__global__ void __launch_bounds__(REPLAY_WG) k_replay_seams(const CtxJob* jobs, u64* pool, u32 parts, u32 n_streams)
+__device__ __forceinline__ void replay_seams_part(const CtxJob& j, u64* pool, u32 parts, u32 part)
 {
-	u32 part, stream;
-	if (!replay_slot(parts, n_streams, &part, &stream)) return;
 	constexpr int BITS = N <= 4 ? 2 : N <= 8 ? 3 : N <= 16 ? 4 : N <= 32 ? 5 : N <= 64 ? 6 : 7;
-	const CtxJob j = jobs[stream];
 	const u64* src = pool + (j.sorted_in_b ? j.elems_b : j.elems);
 	u32* seams = (u32*)(pool + (j.sorted_in_b ? j.elems : j.elems_b));
 	const u32 n = j.n;
@@ -628,16 +638,27 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay_seams(const CtxJob* jobs, 
 	}
 }
 
+// Launch forms of k_replay_seams / k_replay: fb == nullptr: workgroup id -> (stream, part) of jobs[0 .. n_streams) (replay_slot);
+// otherwise fb = {count, job ids ...} (k_bucket.h: the streams k_part handed back) and gridDim.x / parts streams are in flight at a time.
+template <int N>
+__global__ void __launch_bounds__(REPLAY_WG) k_replay_seams(const CtxJob* jobs, u64* pool, u32 parts, u32 n_streams, const u32* fb)
+{
+	if (!fb)
+	{
+		u32 part, stream;
+		if (replay_slot(parts, n_streams, &part, &stream)) replay_seams_part<N>(jobs[stream], pool, parts, part);
+		return;
+	}
+	const u32 n_f = fb[0], part = blockIdx.x % parts;
+	for (u32 f = blockIdx.x / parts; f < n_f; f += gridDim.x / parts) replay_seams_part<N>(jobs[fb[1 + f]], pool, parts, part);
+}
+
 // PROBE != 0: timing experiments only (-DDSRC_SORT_PROBE): 1 no record store, 2 records stored in sorted order (no scatter),
 // 8 / 16 scatter inside an 8 MB / 128 KB window
-template <int N, int PROBE = 0>
-__global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const u64* pool, RcPack* rec_pool, u32 parts, u32 n_streams)
+template <int N, int PROBE>
+__device__ __forceinline__ void replay_part(const CtxJob& j, const u64* pool, RcPack* rec_pool, u32 parts, u32 part, u32 (*s_tail)[128])
 {
-	u32 part, stream;
-	if (!replay_slot(parts, n_streams, &part, &stream)) return;
 	constexpr int BITS = N <= 4 ? 2 : N <= 8 ? 3 : N <= 16 ? 4 : N <= 32 ? 5 : N <= 64 ? 6 : 7;
-	__shared__ u32 s_tail[REPLAY_WG / 64][128];
-	const CtxJob j = jobs[stream];
 	const u64* src = pool + (j.sorted_in_b ? j.elems_b : j.elems);
 	RcPack* recs = rec_pool + j.trip;
 	const u32 n = j.n;
@@ -780,6 +801,20 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 		pos = npos;
 		if (last) break;
 	}
+}
+
+template <int N, int PROBE = 0>
+__global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const u64* pool, RcPack* rec_pool, u32 parts, u32 n_streams, const u32* fb)
+{
+	__shared__ u32 s_tail[REPLAY_WG / 64][128];
+	if (!fb)
+	{
+		u32 part, stream;
+		if (replay_slot(parts, n_streams, &part, &stream)) replay_part<N, PROBE>(jobs[stream], pool, rec_pool, parts, part, s_tail);
+		return;
+	}
+	const u32 n_f = fb[0], part = blockIdx.x % parts;
+	for (u32 f = blockIdx.x / parts; f < n_f; f += gridDim.x / parts) replay_part<N, PROBE>(jobs[fb[1 + f]], pool, rec_pool, parts, part, s_tail);
 }
 
 // ---- range coder: one lane = one stream ---------------------------------------------------------
