@@ -574,10 +574,10 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	// streams of one alphabet size inside a slice) a fallback list that k_part fills with the streams it hands back to k_sort / k_replay
 	struct BkGroup { u32 lo, hi, fb; };
 	std::vector<std::vector<BkGroup> > bk_groups(slice_lo.size());
-	static const bool bk_enabled = getenv("DSRC_GPU_BUCKETS") && atoi(getenv("DSRC_GPU_BUCKETS")) != 0;      // off by default while it is slower than k_sort / k_replay (profiles/r04_ks_*)
+	static const bool bk_enabled = !(getenv("DSRC_GPU_BUCKETS") && atoi(getenv("DSRC_GPU_BUCKETS")) == 0);
 	static const u32 bk_min = getenv("DSRC_GPU_BUCKETS_MIN") ? (u32)atoi(getenv("DSRC_GPU_BUCKETS_MIN")) : 16384u;   // shorter streams: a bucket per workgroup does not pay
 	static const bool bk_binned = !(getenv("DSRC_GPU_BUCKETS_BINNED") && atoi(getenv("DSRC_GPU_BUCKETS_BINNED")) == 0);
-	const bool use_bk = bk_enabled && NJ > 0;
+	const bool use_bk = bk_enabled && NJ > 0 && h->sort_atomic;      // k_model stands on the LDS applying atomics in lane order (k_lds_order_test)
 	size_t o_bk = 0, bk_zero_words = 0;
 	if (use_bk)
 	{
@@ -719,8 +719,9 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			stage_mark(0);
 			if (use_bk)
 			{	// k_bucket.h: partition, finish in LDS, place -- and behind them k_sort / k_replay for the streams k_part handed back
-				if (sort_atomic) hipLaunchKernelGGL((k_part<true>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk);
-				else hipLaunchKernelGGL((k_part<false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk);
+				static const bool part_stage = getenv("DSRC_GPU_PART_STAGE") && atoi(getenv("DSRC_GPU_PART_STAGE")) != 0;
+				if (part_stage) hipLaunchKernelGGL((k_part<true, true>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk);
+				else hipLaunchKernelGGL((k_part<true, false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk);
 				KCHK();
 				stage_mark(0); stage_mark(1);
 				u32 slice_bins = 0;
@@ -729,9 +730,11 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 					u32 hb = 0; bool any = false;
 					for (u32 i = g.lo; i < g.hi; ++i) if (jobs[i].bk_on) { any = true; hb = std::max(hb, jobs[i].bk_hb); slice_bins = std::max(slice_bins, (jobs[i].n + BK_BIN - 1) >> BK_TB); }
 					if (!any) continue;
-					const dim3 fgrid(1u << hb, g.hi - g.lo);
-#define BK_FINISH(NN) { if (sort_atomic) hipLaunchKernelGGL((k_finish<NN, true>), fgrid, dim3(BK_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
-						else hipLaunchKernelGGL((k_finish<NN, false>), fgrid, dim3(BK_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); }
+					u32 lbm = 0; for (u32 i = g.lo; i < g.hi; ++i) if (jobs[i].bk_on) lbm = std::max(lbm, jobs[i].bk_lb);
+					const dim3 fgrid(((1u << hb) + MD_WAVES - 1) / MD_WAVES, g.hi - g.lo);
+#define BK_FINISH(NN) { if ((1u << lbm) <= MD_ROW_BYTES / (4 * NN)) hipLaunchKernelGGL((k_model<NN, 0>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
+						else if (lbm <= 10) hipLaunchKernelGGL((k_model<NN, 10>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
+						else hipLaunchKernelGGL((k_model<NN, BK_MAX_LB>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); }
 					switch (jobs[g.lo].n_alpha)
 					{
 					case 4: BK_FINISH(4) break; case 8: BK_FINISH(8) break; case 16: BK_FINISH(16) break;
