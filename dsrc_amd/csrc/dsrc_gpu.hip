@@ -719,7 +719,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			stage_mark(0);
 			if (use_bk)
 			{	// k_bucket.h: partition, finish in LDS, place -- and behind them k_sort / k_replay for the streams k_part handed back
-				static const bool part_stage = getenv("DSRC_GPU_PART_STAGE") && atoi(getenv("DSRC_GPU_PART_STAGE")) != 0;
+				static const bool part_stage = !(getenv("DSRC_GPU_PART_STAGE") && atoi(getenv("DSRC_GPU_PART_STAGE")) == 0);
 				if (part_stage) hipLaunchKernelGGL((k_part<true, true>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk);
 				else hipLaunchKernelGGL((k_part<true, false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk);
 				KCHK();
@@ -732,9 +732,11 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 					if (!any) continue;
 					u32 lbm = 0; for (u32 i = g.lo; i < g.hi; ++i) if (jobs[i].bk_on) lbm = std::max(lbm, jobs[i].bk_lb);
 					const dim3 fgrid(((1u << hb) + MD_WAVES - 1) / MD_WAVES, g.hi - g.lo);
-#define BK_FINISH(NN) { if ((1u << lbm) <= MD_ROW_BYTES / (4 * NN)) hipLaunchKernelGGL((k_model<NN, 0>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
-						else if (lbm <= 10) hipLaunchKernelGGL((k_model<NN, 10>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
-						else hipLaunchKernelGGL((k_model<NN, BK_MAX_LB>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); }
+					// rows by key where a bucket's keys fit (in as little LDS as they need), else handed out on first use through a map
+#define BK_FINISH(NN) { if ((1u << lbm) * 4 * NN <= 4096) hipLaunchKernelGGL((k_model<NN, 0, 4096>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
+						else if ((1u << lbm) * 4 * NN <= MD_ROW_BYTES) hipLaunchKernelGGL((k_model<NN, 0, MD_ROW_BYTES>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
+						else if (lbm <= 10) hipLaunchKernelGGL((k_model<NN, 10, MD_ROW_BYTES>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
+						else hipLaunchKernelGGL((k_model<NN, BK_MAX_LB, MD_ROW_BYTES>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); }
 					switch (jobs[g.lo].n_alpha)
 					{
 					case 4: BK_FINISH(4) break; case 8: BK_FINISH(8) break; case 16: BK_FINISH(16) break;

@@ -49,6 +49,53 @@ __device__ __forceinline__ void bk_fallback(const CtxJob& j, u32* bk)
 	bk[j.bk_fb + 1 + k] = j.jid;
 }
 
+// Elements of EIGHT consecutive symbols t0 .. t0+7 (t0 >= 16, t0 + 7 < n): their contexts overlap in all but one symbol, so the
+// windows are loaded (and, for qualities, translated to ranks) once -- 2 table look-ups per symbol instead of order + 2, three
+// 8-byte loads per eight symbols instead of two per symbol.  Same values as ctx_elem_dna / ctx_elem_qua followed by bk_rekey.
+__device__ __forceinline__ bool bk_fast8(const CtxJob& j) { return j.is_dna ? (j.alpha_bits == 2 && j.order <= 9) : j.order <= 4; }
+
+__device__ __forceinline__ void bk_elems8_dna(const CtxJob& j, const u8* s, u32 t0, u64* el, bool* bad)
+{
+	const u64 wa = *(const u64_unaligned*)(s + t0 - 9), wb = *(const u64_unaligned*)(s + t0 - 1), wc = *(const u64_unaligned*)(s + t0);
+	if ((wa | wc) & 0xFCFCFCFCFCFCFCFCull) *bad = true;
+	const u32 P = (pack2x8(__builtin_bswap64(wa)) << 16) | pack2x8(__builtin_bswap64(wb));      // s[t0-9] on top, s[t0+6] at the bottom
+	const u32 cmask = (u32)((1ull << (2 * j.order)) - 1ull);
+#pragma unroll
+	for (u32 i = 0; i < 8; ++i)
+	{
+		const u32 ctx = (P >> (14 - 2 * i)) & cmask;
+		const u32 key = (ctx * j.bk_mul) & j.bk_kmask;
+		el[i] = ((u64)key << ELEM_CTX_SHIFT) | ((u64)((u32)(wc >> (8 * i)) & 3u) << ELEM_SYM_SHIFT) | (t0 + i);
+	}
+}
+
+__device__ __forceinline__ void bk_elems8_qua(const CtxJob& j, const u8* s, const u8* qp, const u8* rank, u32 t0, u64* el)
+{
+	const u32 ab = j.alpha_bits, order = j.order, half = order / 2;
+	const u64 w0 = *(const u64_unaligned*)(s + t0 - 8), w1 = *(const u64_unaligned*)(s + t0);
+	u32 r[16];                                              // r[m] = rank of s[t0 - 8 + m]
+#pragma unroll
+	for (u32 m = 0; m < 8; ++m) { r[m] = rank[(u32)(w0 >> (8 * m)) & 0xFFu]; r[8 + m] = rank[(u32)(w1 >> (8 * m)) & 0xFFu]; }
+	u32 pos = j.qlen ? t0 - exact_div(t0, j.qm_lo, j.qm_hi) * j.qlen : 0u;
+#pragma unroll
+	for (u32 i = 0; i < 8; ++i)
+	{	// v[k] = rank of s[t-1-k] = r[7 + i - k]
+		u32 h = 0;
+#pragma unroll
+		for (u32 k = 4; k >= 1; --k)
+			if (k <= order)
+			{
+				const u32 slot = k - 1;
+				const u32 x = (slot < half || order == 1) ? r[7 + i - slot] : ((r[7 + i - slot] + r[6 + i - slot]) >> 1);
+				h = (h << ab) | x;
+			}
+		const u32 pctx = (j.qlen ? exact_div(pos * 128u, j.qm_lo, j.qm_hi) : (u32)qp[t0 + i]) >> j.rescale_shift;
+		const u32 key = ((((h << ab) | pctx)) * j.bk_mul) & j.bk_kmask;
+		el[i] = ((u64)key << ELEM_CTX_SHIFT) | ((u64)(r[8 + i] & ((1u << ab) - 1u)) << ELEM_SYM_SHIFT) | (t0 + i);
+		pos = pos + 1 == j.qlen ? 0u : pos + 1;
+	}
+}
+
 // ---- k_part: stable partition by the top digit of the mixed key ------------------------------------------------------------------
 // One workgroup per stream, tiles of SORT_WG * SORT_ITEMS elements, ranking as in k_sort (one LDS atomic per element on the
 // wave's packed counter pair, or ballots where the device failed k_lds_order_test).
@@ -79,62 +126,22 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 	{	// bucket sizes
 		bool bad = false;
 		u32 i_from = 0;
-		if (j.is_dna && j.alpha_bits == 2 && j.order <= 9 && n >= 32)
-		{	// 2-bit bases: the contexts of four consecutive symbols t..t+3 are 2*order-bit fields of the twelve symbols s[t-9 .. t+2],
-			// which come out of two 8-byte windows
-			const u32 cmask = (u32)((1ull << (2 * j.order)) - 1ull);
-			const u32 n4 = (n - 12) / 4;                                  // groups starting at t = 12, 16, ...
-			for (u32 g = threadIdx.x; g < n4; g += blockDim.x)
+		if (bk_fast8(j) && n >= 64)
+		{
+			const u32 n8 = (n - 24) / 8;                                  // groups starting at t0 = 16, 24, ... (the last one ends before n - 8)
+			for (u32 g = threadIdx.x; g < n8; g += blockDim.x)
 			{
-				const u32 t = 12 + 4 * g;
-				const u64 wa = *(const u64_unaligned*)(sym_src + t - 9), wb = *(const u64_unaligned*)(sym_src + t - 5);
-				if (((wa | wb) & 0xFCFCFCFCFCFCFCFCull) || sym_src[t + 3] >= 4) bad = true;
-				const u32 R = (pack2x8(__builtin_bswap64(wa)) << 8) | (pack2x8(__builtin_bswap64(wb)) & 0xFFu);     // s[t-9] on top, s[t+2] at the bottom
+				u64 e8[8];
+				if (j.is_dna) bk_elems8_dna(j, sym_src, 16 + 8 * g, e8, &bad); else bk_elems8_qua(j, sym_src, qp, s_rank, 16 + 8 * g, e8);
 #pragma unroll
-				for (u32 k = 0; k < 4; ++k)
-				{
-					const u32 ctx = (R >> (6 - 2 * k)) & cmask;
-					atomicAdd(&s_base[((ctx * j.bk_mul) & j.bk_kmask) >> lb], 1u);
-				}
+				for (u32 k = 0; k < 8; ++k) atomicAdd(&s_base[(u32)(e8[k] >> (ELEM_CTX_SHIFT + lb))], 1u);
 			}
-			i_from = 12 + 4 * n4;
-			for (u32 i = threadIdx.x; i < 12; i += blockDim.x)
-				atomicAdd(&s_base[(u32)(bk_rekey(j, ctx_elem_dna(j, sym_src, i, &bad)) >> (ELEM_CTX_SHIFT + lb))], 1u);
-		}
-		if (!j.is_dna && j.order <= 4 && n >= 32)
-		{	// quality: the contexts of four consecutive symbols t0..t0+3 are made of the ranks of s[t0-5 .. t0+2]: one 8-byte window,
-			// eight table look-ups instead of sixteen to twenty, one division for the position inside the read
-			const u32 ab = j.alpha_bits, order = j.order, half = order / 2;
-			const u32 n4 = (n - 8) / 4;                                   // groups starting at t0 = 8, 12, ...
-			for (u32 g = threadIdx.x; g < n4; g += blockDim.x)
+			i_from = 16 + 8 * n8;
+			for (u32 i = threadIdx.x; i < 16; i += blockDim.x)
 			{
-				const u32 t0 = 8 + 4 * g;
-				const u64 w = *(const u64_unaligned*)(sym_src + t0 - 5);
-				u32 r[8];
-#pragma unroll
-				for (u32 m = 0; m < 8; ++m) r[m] = s_rank[(u32)(w >> (8 * m)) & 0xFFu];
-				u32 pos = j.qlen ? t0 - exact_div(t0, j.qm_lo, j.qm_hi) * j.qlen : 0u;
-#pragma unroll
-				for (u32 i = 0; i < 4; ++i)
-				{	// v[k] = rank of s[t-1-k] = r[4 + i - k]
-					u32 h = 0;
-#pragma unroll
-					for (u32 k = 4; k >= 1; --k)
-						if (k <= order)
-						{
-							const u32 slot = k - 1;
-							const u32 x = (slot < half || order == 1) ? r[4 + i - slot] : ((r[4 + i - slot] + r[3 + i - slot]) >> 1);
-							h = (h << ab) | x;
-						}
-					const u32 pctx = (j.qlen ? exact_div(pos * 128u, j.qm_lo, j.qm_hi) : (u32)qp[t0 + i]) >> j.rescale_shift;
-					const u32 ctx = (h << ab) | pctx;
-					atomicAdd(&s_base[((ctx * j.bk_mul) & j.bk_kmask) >> lb], 1u);
-					pos = pos + 1 == j.qlen ? 0u : pos + 1;
-				}
+				const u64 el = j.is_dna ? ctx_elem_dna(j, sym_src, i, &bad) : ctx_elem_qua(j, sym_src, qp, s_rank, i);
+				atomicAdd(&s_base[(u32)(bk_rekey(j, el) >> (ELEM_CTX_SHIFT + lb))], 1u);
 			}
-			i_from = 8 + 4 * n4;
-			for (u32 i = threadIdx.x; i < 8; i += blockDim.x)
-				atomicAdd(&s_base[(u32)(bk_rekey(j, ctx_elem_qua(j, sym_src, qp, s_rank, i)) >> (ELEM_CTX_SHIFT + lb))], 1u);
 		}
 		for (u32 i = i_from + threadIdx.x; i < n; i += blockDim.x)
 		{
@@ -164,17 +171,35 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 
 	u64* dst = pool + j.elems;
 	const u32 shift = ELEM_CTX_SHIFT + lb;
+	const bool fast8 = bk_fast8(j);
 	for (u32 tile = 0; tile < n; tile += tile_elems)
 	{
 		u64 el[SORT_ITEMS]; u32 rk[SORT_ITEMS];
 		const u32 wbase = tile + wv * 64 * SORT_ITEMS;
 		bool bad = false;
+		if (STAGE && SORT_ITEMS == 8 && fast8 && tile > 0 && tile + tile_elems + 8 <= n)
+		{	// an inner tile: every lane makes the elements of eight consecutive symbols, and the wave's 512 elements change places
+			// through its strip of s_tile (unused until the tile is ranked) so that lane l holds elements l, l + 64, ...: the order
+			// the ranking needs
+			u64* strip = s_tile + wv * 64 * SORT_ITEMS;
+			u64 e8[8];
+			if (j.is_dna) bk_elems8_dna(j, sym_src, wbase + 8 * lane, e8, &bad); else bk_elems8_qua(j, sym_src, qp, s_rank, wbase + 8 * lane, e8);
 #pragma unroll
-		for (u32 k = 0; k < SORT_ITEMS; ++k)
+			for (u32 k = 0; k < 8; ++k) strip[8 * lane + k] = e8[k];
+			wave_fence();
+#pragma unroll
+			for (u32 k = 0; k < 8; ++k) el[k] = strip[64 * k + lane];
+			wave_fence();
+		}
+		else
 		{
-			const u32 i = wbase + k * 64 + lane;
-			el[k] = 0;
-			if (i < n) el[k] = bk_rekey(j, j.is_dna ? ctx_elem_dna(j, sym_src, i, &bad) : ctx_elem_qua(j, sym_src, qp, s_rank, i));
+#pragma unroll
+			for (u32 k = 0; k < SORT_ITEMS; ++k)
+			{
+				const u32 i = wbase + k * 64 + lane;
+				el[k] = 0;
+				if (i < n) el[k] = bk_rekey(j, j.is_dna ? ctx_elem_dna(j, sym_src, i, &bad) : ctx_elem_qua(j, sym_src, qp, s_rank, i));
+			}
 		}
 #pragma unroll
 		for (u32 k = 0; k < SORT_ITEMS; ++k)
@@ -249,7 +274,7 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 					dst[s_delta[(u32)(e >> shift)] + p] = e;
 				}
 			}
-			// no barrier here: the next tile touches s_delta / s_tile only behind its own first two barriers
+			if (fast8) __syncthreads();                        // the next tile's strips are s_tile
 		}
 		else
 		{
@@ -327,15 +352,17 @@ template <> struct MdMapT<false> { typedef u16 T; static constexpr u32 NONE = 0x
 
 // Grid: x = bucket / MD_WAVES, y = stream of the launch group (one alphabet size).  MAPBITS = 0: every stream of the group has at
 // most ROWS keys per bucket, key k owns row k; otherwise MAPBITS >= the group's largest bk_lb and rows are handed out on first use.
-template <int N, int MAPBITS>
+// ROW_BYTES: LDS per wave for the rows (the fewer, the more buckets a CU works on at a time).
+#define MD_AHEAD 3                     // windows between a run's reservation (a global atomic) and the store that needs it
+template <int N, int MAPBITS, int ROW_BYTES>
 __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* pool, RcPack* rec_pool, u32* bk)
 {
 	constexpr int B = N <= 4 ? 2 : N <= 8 ? 3 : N <= 16 ? 4 : N <= 32 ? 5 : N <= 64 ? 6 : 7;
-	constexpr u32 ROWS = MD_ROW_BYTES / (4 * N);
+	constexpr u32 ROWS = ROW_BYTES / (4 * N);
 	typedef MdMapT<(ROWS <= 64)> Map;
 	typedef typename Map::T map_t;
 	__shared__ map_t s_map[MD_WAVES][1 << MAPBITS];
-	__shared__ u32 s_rows[MD_WAVES][MD_ROW_BYTES / 4];
+	__shared__ u32 s_rows[MD_WAVES][ROW_BYTES / 4];
 	static_assert(N + 2 * BK_LIMIT < (1 << 16) - 2 * N, "a row of a bucket must stay below the rescale threshold");
 	const CtxJob j = jobs[blockIdx.y];
 	const u32 w = wave_id(), lane = lane_id();
@@ -350,9 +377,10 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 	const bool binned = j.bk_binned != 0;
 	map_t* map = s_map[w]; u32* rows = s_rows[w];
 
-	// the first two windows are on their way while the rows are set up
-	u64 el_cur = lane < nb ? src[lane] : 0ull;
-	u64 el_nxt = 64 + lane < nb ? src[64 + lane] : 0ull;
+	// the first windows are on their way while the rows are set up
+	u64 elq[MD_AHEAD + 2];                                  // elq[k]: the elements of window p / 64 + k
+#pragma unroll
+	for (u32 k = 0; k < MD_AHEAD + 2; ++k) elq[k] = 64 * k + lane < nb ? src[64 * k + lane] : 0ull;
 	if (MAPBITS) for (u32 i = lane; i < keys; i += 64) map[i] = (map_t)Map::NONE;
 	for (u32 i = lane; i < (MAPBITS ? ROWS : keys) * N; i += 64)
 	{	// every counter 1: a half of a level-l word covers 2^(B-1-l) symbols
@@ -363,20 +391,29 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 	wave_fence();
 
 	// A run of equal bins takes its place in the bin's region of the record array with one global atomic on the bin's fill counter,
-	// issued one window ahead: it is back by the time the window's records exist.
-	u32 bin, hl, run, base = 0;
-	md_runs((u32)el_cur, lane < nb, &bin, &hl, &run);
-	if (binned && run) base = atomicAdd(&fill[bin], run);
+	// issued MD_AHEAD windows ahead: it is back by the time the window's records exist.
+	u32 binq[MD_AHEAD + 1], hlq[MD_AHEAD + 1], baseq[MD_AHEAD + 1];
+#pragma unroll
+	for (u32 k = 0; k < MD_AHEAD; ++k)
+	{
+		u32 run;
+		md_runs((u32)elq[k], 64 * k + lane < nb, &binq[k], &hlq[k], &run);
+		baseq[k] = 0;
+		if (binned && run) baseq[k] = atomicAdd(&fill[binq[k]], run);
+	}
 	u32 n_rows = 0;
 	for (u32 p = 0; p < nb; p += 64)
 	{
-		const u64 el = el_cur;
+		const u64 el = elq[0];
 		const u32 i = p + lane;
 		const bool valid = i < nb;
-		const u64 el_nn = i + 128 < nb ? src[i + 128] : 0ull;
-		u32 bin_n, hl_n, run_n, base_n = 0;
-		md_runs((u32)el_nxt, i + 64 < nb, &bin_n, &hl_n, &run_n);
-		if (binned && run_n) base_n = atomicAdd(&fill[bin_n], run_n);
+		const u64 el_new = i + 64 * (MD_AHEAD + 2) < nb ? src[i + 64 * (MD_AHEAD + 2)] : 0ull;
+		{
+			u32 run;
+			md_runs((u32)elq[MD_AHEAD], i + 64 * MD_AHEAD < nb, &binq[MD_AHEAD], &hlq[MD_AHEAD], &run);
+			baseq[MD_AHEAD] = 0;
+			if (binned && run) baseq[MD_AHEAD] = atomicAdd(&fill[binq[MD_AHEAD]], run);
+		}
 
 		const u32 key = (u32)(el >> ELEM_CTX_SHIFT) & kmask, sym = (u32)(el >> ELEM_SYM_SHIFT) & (u32)(N - 1), t = (u32)el;
 		u32 rid = key;
@@ -385,7 +422,7 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 			rid = valid ? (u32)map[key] : 0u;
 			const bool need = valid && rid == Map::NONE;
 			if (__ballot(need))
-			{	// contexts met for the first time: one lane of each (the last the LDS applies: the highest) takes the next row
+			{	// contexts met for the first time: one lane of each (whichever store the LDS applies last) takes the next row
 				if (need) map[key] = (map_t)(Map::CLAIM | lane);
 				wave_fence();
 				const bool leader = need && (u32)map[key] == (Map::CLAIM | lane);
@@ -405,14 +442,18 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 		}
 		u64 rec = 0;
 		if (valid) rec = md_code<N>(rows + rid * N, sym);
-		const u32 at = __shfl(base, (int)hl) + (lane - hl);
+		const u32 hl = hlq[0];
+		const u32 at = __shfl(baseq[0], (int)hl) + (lane - hl);
 		if (valid)
 		{
-			if (binned) recs[(bin << BK_TB) + at] = rec | ((u64)(t & (BK_BIN - 1u)) << 48);
+			if (binned) recs[(binq[0] << BK_TB) + at] = rec | ((u64)(t & (BK_BIN - 1u)) << 48);
 			else recs[t] = rec;
 		}
-		el_cur = el_nxt; el_nxt = el_nn;
-		bin = bin_n; hl = hl_n; run = run_n; base = base_n;
+#pragma unroll
+		for (u32 k = 0; k < MD_AHEAD + 1; ++k) elq[k] = elq[k + 1];
+		elq[MD_AHEAD + 1] = el_new;
+#pragma unroll
+		for (u32 k = 0; k < MD_AHEAD; ++k) { binq[k] = binq[k + 1]; hlq[k] = hlq[k + 1]; baseq[k] = baseq[k + 1]; }
 	}
 }
 

@@ -898,7 +898,9 @@ __device__ inline void rc_step_exact(RcState& s, const RcRec& e, u8* xb, u32& nb
 	const u32 r = rc_div(s.range, e.m_lo, e.mf >> 16);
 	u64 low = s.low + (u64)r * e.cum;
 	u32 range = r * (e.mf & 0xFFFFu);
-	while (range <= 0x00FFFFFFu)
+	// a valid record (freq >= 1, total <= 2^16) leaves range >= 2^8: at most two bytes go out.  The bound keeps a record that is
+	// not one (a front-end bug) from spinning here for ever; the stream is then wrong and the block fails its check instead.
+	for (u32 guard = 0; range <= 0x00FFFFFFu && guard < 8; ++guard)
 	{
 		if ((low ^ (low + range)) & 0xFF00000000000000ull) { const u32 rr = (u32)low; range = (rr | 0x00FFFFFFu) - rr; }
 		if (nb < RC_XB) xb[nb] = (u8)(low >> 56);
