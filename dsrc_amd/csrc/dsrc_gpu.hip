@@ -114,6 +114,7 @@ struct dsrcgpu_handle
 	std::vector<hipEvent_t> stage_ev; std::vector<u32> stage_kind; u32 stage_used = 0;       // kind: 0 sort, 1 replay
 	float sort_ms = 0.f, replay_ms = 0.f, decode_stream_ms = 0.f;
 	bool sort_atomic = false;        // k_sort ranks with LDS atomics (device passed k_lds_order_test), else with ballots
+	bool lds64_ordered = false;      // ... and k_lds_order_test64: the bucketed path (k_part / k_model) may run
 	u64 dec_table_budget = 0;        // dsrcgpu_set_table_budget: HBM a decoding pass may take for model tables (0 = automatic)
 	u32* dec_tables = nullptr; u64 dec_tables_cap = 0;     // model tables of the range-decoded levels (bytes), kept between passes
 };
@@ -577,7 +578,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	static const bool bk_enabled = !(getenv("DSRC_GPU_BUCKETS") && atoi(getenv("DSRC_GPU_BUCKETS")) == 0);
 	static const u32 bk_min = getenv("DSRC_GPU_BUCKETS_MIN") ? (u32)atoi(getenv("DSRC_GPU_BUCKETS_MIN")) : 16384u;   // shorter streams: a bucket per workgroup does not pay
 	static const bool bk_binned = !(getenv("DSRC_GPU_BUCKETS_BINNED") && atoi(getenv("DSRC_GPU_BUCKETS_BINNED")) == 0);
-	const bool use_bk = bk_enabled && NJ > 0 && h->sort_atomic;      // k_model stands on the LDS applying atomics in lane order (k_lds_order_test)
+	const bool use_bk = bk_enabled && NJ > 0 && h->lds64_ordered;      // k_model stands on the LDS applying atomics in lane order (k_lds_order_test)
 	size_t o_bk = 0, bk_zero_words = 0;
 	if (use_bk)
 	{
@@ -733,8 +734,8 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 					u32 lbm = 0; for (u32 i = g.lo; i < g.hi; ++i) if (jobs[i].bk_on) lbm = std::max(lbm, jobs[i].bk_lb);
 					const dim3 fgrid(((1u << hb) + MD_WAVES - 1) / MD_WAVES, g.hi - g.lo);
 					// rows by key where a bucket's keys fit (in as little LDS as they need), else handed out on first use through a map
-#define BK_FINISH(NN) { if ((1u << lbm) * 4 * NN <= 4096) hipLaunchKernelGGL((k_model<NN, 0, 4096>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
-						else if ((1u << lbm) * 4 * NN <= MD_ROW_BYTES) hipLaunchKernelGGL((k_model<NN, 0, MD_ROW_BYTES>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
+#define BK_FINISH(NN) { if ((1u << lbm) * 4 * MdRow<NN>::STRIDE <= 4096) hipLaunchKernelGGL((k_model<NN, 0, 4096>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
+						else if ((1u << lbm) * 4 * MdRow<NN>::STRIDE <= MD_ROW_BYTES) hipLaunchKernelGGL((k_model<NN, 0, MD_ROW_BYTES>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
 						else if (lbm <= 10) hipLaunchKernelGGL((k_model<NN, 10, MD_ROW_BYTES>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
 						else hipLaunchKernelGGL((k_model<NN, BK_MAX_LB, MD_ROW_BYTES>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); }
 					switch (jobs[g.lo].n_alpha)
@@ -1369,16 +1370,20 @@ int dsrcgpu_create(const dsrcgpu_settings* settings, const dsrcgpu_dataset* data
 			HIPCHK(hipMemsetAsync(d_bad, 0, 4, h->stream));
 			#ifdef DSRC_EMU_BUILD
 			hipLaunchKernelGGL(k_lds_order_test, dim3(1), dim3(256), 0, h->stream, d_bad, 20u); KCHK();       // the CPU emulator runs lanes in order anyway
+			hipLaunchKernelGGL(k_lds_order_test64, dim3(1), dim3(256), 0, h->stream, d_bad, 20u); KCHK();
 #else
 			hipLaunchKernelGGL(k_lds_order_test, dim3(256), dim3(256), 0, h->stream, d_bad, 4096u); KCHK();   // 4 M wave patterns, < 1 ms
+			hipLaunchKernelGGL(k_lds_order_test64, dim3(256), dim3(256), 0, h->stream, d_bad, 4096u); KCHK();
 #endif
 			HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, h->stream));
 			HIPCHK(hipStreamSynchronize(h->stream));
 			HIPCHK(hipFree(d_bad));
-			k = bad ? 2 : 1;
-			if (bad && getenv("DSRC_GPU_DEBUG")) fprintf(stderr, "[dsrc_gpu] LDS atomics are not applied in lane order on device %d: k_sort ranks with ballots\n", device);
+			k = 1 + (int)bad;                                        // bit 0: 32-bit atomics out of order, bit 1: 64-bit ones
+			if ((bad & 1u) && getenv("DSRC_GPU_DEBUG")) fprintf(stderr, "[dsrc_gpu] LDS atomics are not applied in lane order on device %d: k_sort ranks with ballots\n", device);
+			if ((bad & 2u) && getenv("DSRC_GPU_DEBUG")) fprintf(stderr, "[dsrc_gpu] 64-bit LDS atomics are not applied in lane order on device %d: no bucketed path (k_model)\n", device);
 		}
-		h->sort_atomic = k == 1 && !getenv("DSRC_GPU_SORT_BALLOT");
+		h->sort_atomic = !((k - 1) & 1) && !getenv("DSRC_GPU_SORT_BALLOT");
+		h->lds64_ordered = !((k - 1) & 2) && h->sort_atomic;
 	}
 	if (arena_bytes) { rc = ensure_arena(h, (size_t)arena_bytes); if (rc) return rc; }
 	return DSRCGPU_OK;

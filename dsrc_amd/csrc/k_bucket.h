@@ -54,9 +54,19 @@ __device__ __forceinline__ void bk_fallback(const CtxJob& j, u32* bk)
 // 8-byte loads per eight symbols instead of two per symbol.  Same values as ctx_elem_dna / ctx_elem_qua followed by bk_rekey.
 __device__ __forceinline__ bool bk_fast8(const CtxJob& j) { return j.is_dna ? (j.alpha_bits == 2 && j.order <= 9) : j.order <= 4; }
 
-__device__ __forceinline__ void bk_elems8_dna(const CtxJob& j, const u8* s, u32 t0, u64* el, bool* bad)
+// the windows of eight consecutive symbols: DNA s[t0-9 ..], s[t0-1 ..], s[t0 ..]; quality s[t0-8 ..], s[t0 ..] (8 bytes each)
+struct BkWin { u64 a, b, c; };
+__device__ __forceinline__ BkWin bk_load8(const CtxJob& j, const u8* s, u32 t0)
 {
-	const u64 wa = *(const u64_unaligned*)(s + t0 - 9), wb = *(const u64_unaligned*)(s + t0 - 1), wc = *(const u64_unaligned*)(s + t0);
+	BkWin w;
+	if (j.is_dna) { w.a = *(const u64_unaligned*)(s + t0 - 9); w.b = *(const u64_unaligned*)(s + t0 - 1); w.c = *(const u64_unaligned*)(s + t0); }
+	else { w.a = *(const u64_unaligned*)(s + t0 - 8); w.b = 0; w.c = *(const u64_unaligned*)(s + t0); }
+	return w;
+}
+
+__device__ __forceinline__ void bk_elems8_dna(const CtxJob& j, const BkWin& w, u32 t0, u64* el, bool* bad)
+{
+	const u64 wa = w.a, wb = w.b, wc = w.c;
 	if ((wa | wc) & 0xFCFCFCFCFCFCFCFCull) *bad = true;
 	const u32 P = (pack2x8(__builtin_bswap64(wa)) << 16) | pack2x8(__builtin_bswap64(wb));      // s[t0-9] on top, s[t0+6] at the bottom
 	const u32 cmask = (u32)((1ull << (2 * j.order)) - 1ull);
@@ -69,10 +79,10 @@ __device__ __forceinline__ void bk_elems8_dna(const CtxJob& j, const u8* s, u32 
 	}
 }
 
-__device__ __forceinline__ void bk_elems8_qua(const CtxJob& j, const u8* s, const u8* qp, const u8* rank, u32 t0, u64* el)
+__device__ __forceinline__ void bk_elems8_qua(const CtxJob& j, const BkWin& w, const u8* qp, const u8* rank, u32 t0, u64* el)
 {
 	const u32 ab = j.alpha_bits, order = j.order, half = order / 2;
-	const u64 w0 = *(const u64_unaligned*)(s + t0 - 8), w1 = *(const u64_unaligned*)(s + t0);
+	const u64 w0 = w.a, w1 = w.c;
 	u32 r[16];                                              // r[m] = rank of s[t0 - 8 + m]
 #pragma unroll
 	for (u32 m = 0; m < 8; ++m) { r[m] = rank[(u32)(w0 >> (8 * m)) & 0xFFu]; r[8 + m] = rank[(u32)(w1 >> (8 * m)) & 0xFFu]; }
@@ -129,10 +139,14 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 		if (bk_fast8(j) && n >= 64)
 		{
 			const u32 n8 = (n - 24) / 8;                                  // groups starting at t0 = 16, 24, ... (the last one ends before n - 8)
+			BkWin wn = bk_load8(j, sym_src, 16 + 8 * (threadIdx.x < n8 ? threadIdx.x : 0u));
 			for (u32 g = threadIdx.x; g < n8; g += blockDim.x)
 			{
+				const BkWin w = wn;
+				const u32 gn = g + blockDim.x < n8 ? g + blockDim.x : g;       // the next group's windows are on their way while this one is counted
+				wn = bk_load8(j, sym_src, 16 + 8 * gn);
 				u64 e8[8];
-				if (j.is_dna) bk_elems8_dna(j, sym_src, 16 + 8 * g, e8, &bad); else bk_elems8_qua(j, sym_src, qp, s_rank, 16 + 8 * g, e8);
+				if (j.is_dna) bk_elems8_dna(j, w, 16 + 8 * g, e8, &bad); else bk_elems8_qua(j, w, qp, s_rank, 16 + 8 * g, e8);
 #pragma unroll
 				for (u32 k = 0; k < 8; ++k) atomicAdd(&s_base[(u32)(e8[k] >> (ELEM_CTX_SHIFT + lb))], 1u);
 			}
@@ -172,6 +186,9 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 	u64* dst = pool + j.elems;
 	const u32 shift = ELEM_CTX_SHIFT + lb;
 	const bool fast8 = bk_fast8(j);
+	// inner tiles (every lane makes eight consecutive elements): their windows are requested one tile ahead
+	BkWin wnext; wnext.a = wnext.b = wnext.c = 0;
+	if (STAGE && fast8 && 2 * tile_elems + 8 <= n) wnext = bk_load8(j, sym_src, tile_elems + wv * 64 * SORT_ITEMS + 8 * lane);
 	for (u32 tile = 0; tile < n; tile += tile_elems)
 	{
 		u64 el[SORT_ITEMS]; u32 rk[SORT_ITEMS];
@@ -183,7 +200,9 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 			// the ranking needs
 			u64* strip = s_tile + wv * 64 * SORT_ITEMS;
 			u64 e8[8];
-			if (j.is_dna) bk_elems8_dna(j, sym_src, wbase + 8 * lane, e8, &bad); else bk_elems8_qua(j, sym_src, qp, s_rank, wbase + 8 * lane, e8);
+			const BkWin w = wnext;
+			if (tile + 2 * tile_elems + 8 <= n) wnext = bk_load8(j, sym_src, wbase + tile_elems + 8 * lane);
+			if (j.is_dna) bk_elems8_dna(j, w, wbase + 8 * lane, e8, &bad); else bk_elems8_qua(j, w, qp, s_rank, wbase + 8 * lane, e8);
 #pragma unroll
 			for (u32 k = 0; k < 8; ++k) strip[8 * lane + k] = e8[k];
 			wave_fence();
@@ -294,12 +313,12 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 // ---- k_model: a bucket's model statistics on counter rows in LDS -------------------------------------------------------------------
 // One WAVE per bucket, no barriers.  The bucket's elements arrive in stream order (k_part is stable); 64 at a time, lane i takes
 // element i.  A context met for the first time gets the next free counter row of the wave's LDS (key -> row through a map).  A row
-// is the N counters of TSymbolCoderRC<N> kept as a binary trie of pair words: word (2^l - 1 + p) of level l holds, for the symbols
-// whose top l bits are p, the sum of the counters with next bit 0 (low half) and with next bit 1 (high half).  Coding symbol s then
-// is ONE returning LDS atomic per level -- add 2 to the half s falls in -- and what comes back gives everything the range coder
-// needs as of this element: total = both halves of level 0, cum = the low halves of the levels where s goes right, freq = its own
-// half at the last level.  The LDS applies the lanes of one atomic instruction that meet in a word in lane order (k_lds_order_test
-// measures exactly that before this path is ever used), and a wave's instructions in program order: lane order is stream order.
+// is the N counters of TSymbolCoderRC<N> kept as a radix-4 trie: a 64-bit word per node with the four 16-bit sums of the counters
+// under its children (MdRow).  Coding symbol s then is ONE returning LDS atomic per level -- add 2 to the field s falls in -- and what
+// comes back gives everything the range coder needs as of this element: total = the four fields of the root, cum = the fields
+// below s's own at every level, freq = its own field at the last level (2-bit bases: one atomic per symbol, 32 quality values: three).
+// The LDS applies the lanes of one atomic instruction that meet in a word in lane order (k_lds_order_test / k_lds_order_test64
+// measure exactly that before this path is ever used), and a wave's instructions in program order: lane order is stream order.
 // Rescale() (a row's total reaches 2^16 - 2N, src/SymbolCoderRC.h:67-90) cannot happen here: a bucket holds at most BK_LIMIT
 // symbols, so no row's total gets past N + 2 * BK_LIMIT (streams with larger buckets take the k_sort / k_replay path, which
 // replays epochs).
@@ -310,22 +329,51 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 #define MD_ROW_BYTES 8192              // counter rows per wave: 64 rows of a 32-symbol alphabet
 #define MD_NONE 0xFFFFFFFFu
 
+// A row: the N counters of TSymbolCoderRC<N> as a radix-4 trie of 64-bit words with four 16-bit sums each (sums of the counters
+// under each of the four children), plus a last level of 32-bit pair words when log2(N) is odd.
+template <int N> struct MdRow
+{
+	static constexpr int B = N <= 4 ? 2 : N <= 8 ? 3 : N <= 16 ? 4 : N <= 32 ? 5 : N <= 64 ? 6 : 7;
+	static constexpr int L4 = B / 2;                          // radix-4 levels
+	static constexpr bool R2 = (B & 1) != 0;
+	static constexpr u32 W64 = ((1u << (2 * L4)) - 1u) / 3u;  // 64-bit words of the radix-4 levels: 1 + 4 + 16
+	static constexpr u32 STRIDE = 2 * W64 + (R2 ? N / 2 : 0); // row pitch in u32 (a multiple of 2: rows stay 8-byte aligned)
+};
+
+// every counter 1
+template <int N> __device__ __forceinline__ u32 md_init_word(u32 x)
+{
+	typedef MdRow<N> G;
+	if (x >= 2 * G::W64) return 0x00010001u;                 // pair words: two counters
+	const u32 w = x >> 1;                                    // 64-bit word: level l holds words (4^l - 1) / 3 ..; a field covers N / 4^(l+1) counters
+	const u32 l = w >= 5 ? 2u : w >= 1 ? 1u : 0u;
+	const u32 v = (u32)N >> (2 * (l + 1));
+	return v | (v << 16);
+}
+
 // one symbol on its row: returns freq | cum << 16 | total << 32
 template <int N> __device__ __forceinline__ u64 md_code(u32* row, u32 sym)
 {
-	constexpr int B = N <= 4 ? 2 : N <= 8 ? 3 : N <= 16 ? 4 : N <= 32 ? 5 : N <= 64 ? 6 : 7;
-	u32 old[B];
+	typedef MdRow<N> G;
+	unsigned long long* r64 = (unsigned long long*)row;
+	u32 cum = 0, tot = 0, f = 0;
 #pragma unroll
-	for (int l = 0; l < B; ++l)
+	for (int l = 0; l < G::L4; ++l)
 	{
-		const u32 bit = (sym >> (B - 1 - l)) & 1u;
-		old[l] = atomicAdd(&row[(1u << l) - 1u + (sym >> (B - l))], bit ? (2u << 16) : 2u);
+		const u32 q = (sym >> (G::B - 2 * l - 2)) & 3u;
+		const u32 wi = ((1u << (2 * l)) - 1u) / 3u + (l ? sym >> (G::B - 2 * l) : 0u);
+		const u64 old = atomicAdd(&r64[wi], 2ull << (16 * q));
+		const u64 below = old & ((1ull << (16 * q)) - 1ull);
+		cum += ((u32)below & 0xFFFFu) + ((u32)below >> 16) + ((u32)(below >> 32) & 0xFFFFu);
+		if (l == 0) tot = ((u32)old & 0xFFFFu) + ((u32)old >> 16) + ((u32)(old >> 32) & 0xFFFFu) + (u32)(old >> 48);
+		f = (u32)(old >> (16 * q)) & 0xFFFFu;
 	}
-	u32 cum = 0;
-#pragma unroll
-	for (int l = 0; l < B; ++l) cum += ((sym >> (B - 1 - l)) & 1u) ? (old[l] & 0xFFFFu) : 0u;
-	const u32 tot = (old[0] & 0xFFFFu) + (old[0] >> 16);
-	const u32 f = (sym & 1u) ? (old[B - 1] >> 16) : (old[B - 1] & 0xFFFFu);
+	if (G::R2)
+	{
+		const u32 old = atomicAdd(&row[2 * G::W64 + (sym >> 1)], (sym & 1u) ? (2u << 16) : 2u);
+		cum += (sym & 1u) ? (old & 0xFFFFu) : 0u;
+		f = (sym & 1u) ? (old >> 16) : (old & 0xFFFFu);
+	}
 	return (u64)f | ((u64)cum << 16) | ((u64)tot << 32);
 }
 
@@ -357,12 +405,12 @@ template <> struct MdMapT<false> { typedef u16 T; static constexpr u32 NONE = 0x
 template <int N, int MAPBITS, int ROW_BYTES>
 __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* pool, RcPack* rec_pool, u32* bk)
 {
-	constexpr int B = N <= 4 ? 2 : N <= 8 ? 3 : N <= 16 ? 4 : N <= 32 ? 5 : N <= 64 ? 6 : 7;
-	constexpr u32 ROWS = ROW_BYTES / (4 * N);
-	typedef MdMapT<(ROWS <= 64)> Map;
+	constexpr u32 STRIDE = MdRow<N>::STRIDE;
+	constexpr u32 ROWS = ROW_BYTES / (4 * STRIDE);
+	typedef MdMapT<(ROWS <= 127)> Map;
 	typedef typename Map::T map_t;
 	__shared__ map_t s_map[MD_WAVES][1 << MAPBITS];
-	__shared__ u32 s_rows[MD_WAVES][ROW_BYTES / 4];
+	__shared__ unsigned long long s_rows[MD_WAVES][ROW_BYTES / 8];
 	static_assert(N + 2 * BK_LIMIT < (1 << 16) - 2 * N, "a row of a bucket must stay below the rescale threshold");
 	const CtxJob j = jobs[blockIdx.y];
 	const u32 w = wave_id(), lane = lane_id();
@@ -375,19 +423,14 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 	u32* fill = bk + j.bk_fill;
 	const u32 keys = 1u << j.bk_lb, kmask = keys - 1u;
 	const bool binned = j.bk_binned != 0;
-	map_t* map = s_map[w]; u32* rows = s_rows[w];
+	map_t* map = s_map[w]; u32* rows = (u32*)s_rows[w];
 
 	// the first windows are on their way while the rows are set up
 	u64 elq[MD_AHEAD + 2];                                  // elq[k]: the elements of window p / 64 + k
 #pragma unroll
 	for (u32 k = 0; k < MD_AHEAD + 2; ++k) elq[k] = 64 * k + lane < nb ? src[64 * k + lane] : 0ull;
 	if (MAPBITS) for (u32 i = lane; i < keys; i += 64) map[i] = (map_t)Map::NONE;
-	for (u32 i = lane; i < (MAPBITS ? ROWS : keys) * N; i += 64)
-	{	// every counter 1: a half of a level-l word covers 2^(B-1-l) symbols
-		const u32 x = i & (N - 1u);
-		const u32 v = 1u << (B - 1 - (31 - __clz((int)(x + 1u))));
-		rows[i] = x == N - 1u ? 0u : v | (v << 16);
-	}
+	for (u32 i = lane; i < (MAPBITS ? ROWS : keys) * STRIDE; i += 64) rows[i] = md_init_word<N>(i % STRIDE);      // every counter 1
 	wave_fence();
 
 	// A run of equal bins takes its place in the bin's region of the record array with one global atomic on the bin's fill counter,
@@ -441,7 +484,7 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 			}
 		}
 		u64 rec = 0;
-		if (valid) rec = md_code<N>(rows + rid * N, sym);
+		if (valid) rec = md_code<N>(rows + rid * STRIDE, sym);
 		const u32 hl = hlq[0];
 		const u32 at = __shfl(baseq[0], (int)hl) + (lane - hl);
 		if (valid)

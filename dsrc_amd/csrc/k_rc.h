@@ -453,6 +453,35 @@ __global__ void __launch_bounds__(256) k_lds_order_test(u32* bad, u32 rounds)
 	if (wrong) atomicOr(bad, 1u);
 }
 
+// The same question for the 64-bit form (ds_add_rtn_u64, four 16-bit fields per word): k_model (k_bucket.h) codes a symbol with one
+// such atomic per radix-4 level of its counter row and needs what comes back to be the state as of the lanes below.  bad bit 1.
+__global__ void __launch_bounds__(256) k_lds_order_test64(u32* bad, u32 rounds)
+{
+	__shared__ unsigned long long s_c[4][SORT_MAX_BINS / 4];
+	const u32 wv = wave_id(), lane = lane_id();
+	u32 wrong = 0;
+	for (u32 round = 0; round < rounds; ++round)
+	{
+		for (u32 i = lane; i < SORT_MAX_BINS / 4; i += 64) s_c[wv][i] = 0;
+		wave_fence();
+		const u32 mask = (2u << (round % SORT_DIGIT_BITS)) - 1u;
+		u32 x = (blockIdx.x * 4 + wv) * 0x9E3779B9u + round * 0x85EBCA6Bu + lane * 0xC2B2AE35u;
+		x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+		const u32 d = (round & 64) ? (x & mask & ~3u) | (lane & 3u) : x & mask;     // also patterns where neighbours share a word
+		const bool valid = (round & 128) ? ((x >> 20) & 3u) != 0 : true;
+		u64 peers = __ballot(valid);
+#pragma unroll
+		for (u32 b = 0; b < SORT_DIGIT_BITS; ++b) { const u64 m = __ballot((d >> b) & 1u); peers &= ((d >> b) & 1u) ? m : ~m; }
+		const u32 expect = (u32)__popcll(peers & lanemask_lt());
+		const u32 sh = (d & 3u) * 16u;
+		unsigned long long old = 0;
+		if (valid) old = atomicAdd(&s_c[wv][d >> 2], 1ull << sh);
+		if (valid && ((u32)(old >> sh) & 0xFFFFu) != expect) wrong = 1;
+		wave_fence();
+	}
+	if (wrong) atomicOr(bad, 2u);
+}
+
 // device self-test (dsrcgpu_selftest): recip48 against the integer division for every divisor, and rc_div against
 // the hardware division on a spread of numerators
 __device__ __forceinline__ u32 rc_div(u32 range, u32 m_lo, u32 m_hi);
