@@ -579,7 +579,8 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	static const u32 bk_min = getenv("DSRC_GPU_BUCKETS_MIN") ? (u32)atoi(getenv("DSRC_GPU_BUCKETS_MIN")) : 16384u;   // shorter streams: a bucket per workgroup does not pay
 	static const bool bk_binned = !(getenv("DSRC_GPU_BUCKETS_BINNED") && atoi(getenv("DSRC_GPU_BUCKETS_BINNED")) == 0);
 	const bool use_bk = bk_enabled && NJ > 0 && h->lds64_ordered;      // k_model stands on the LDS applying atomics in lane order (k_lds_order_test)
-	size_t o_bk = 0, bk_zero_words = 0;
+	size_t o_bk = 0, bk_zero_words = 0, o_bcnt = 0;
+	static_assert(BK_BIN % (SORT_WG * SORT_ITEMS) == 0, "a time bin is a whole number of k_part tiles");
 	if (use_bk)
 	{
 		u32 cur = NJ;                                            // [0, NJ): the jobs' fallback flags
@@ -606,11 +607,22 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			if (j.key_bits > BK_MAX_LB) hb = std::max(hb, j.key_bits - BK_MAX_LB);
 			j.bk_hb = hb; j.bk_lb = j.key_bits - hb;
 			j.bk_mul = BK_HASH_MUL; j.bk_kmask = (u32)((1ull << j.key_bits) - 1ull);
-			j.bk_fill = cur; cur += j.bk_on ? n_bins : 0u;
 		}
 		bk_zero_words = cur;
 		for (u32 i = 0; i < NJ; ++i) { jobs[i].bk_boff = cur; cur += jobs[i].bk_on ? (1u << jobs[i].bk_hb) + 1u : 0u; }
 		o_bk = A.alloc((size_t)cur * 4 + 64);
+		// per (tile, bucket) element counts of k_part (u16); k_binoff turns the first row of every time bin into the buckets' offsets
+		size_t cnt_words = 0;
+		for (u32 i = 0; i < NJ; ++i)
+			if (jobs[i].bk_on)
+			{
+				if (cnt_words >= (1ull << 32)) return fail(h, DSRCGPU_E_NOMEM, "batch too large for the bucket count table");
+				jobs[i].bk_cnt = (u32)cnt_words;
+				const size_t n_tiles = (jobs[i].n + (size_t)SORT_WG * SORT_ITEMS - 1) / ((size_t)SORT_WG * SORT_ITEMS);
+				const size_t tpb = BK_BIN / (SORT_WG * SORT_ITEMS);
+				cnt_words += ((n_tiles + tpb - 1) / tpb * tpb) << jobs[i].bk_hb;
+			}
+		o_bcnt = A.alloc(cnt_words * 2 + 64);
 	}
 	const size_t o_jobs = A.alloc(sizeof(CtxJob) * std::max(1u, NJ)), o_chains = A.alloc(sizeof(RcChain) * std::max(1u, NJ));
 	const size_t o_fin = A.alloc(sizeof(RcFin) * std::max(1u, NJ));
@@ -712,6 +724,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		const bool sort_atomic = h->sort_atomic;
 		hipLaunchKernelGGL(k_rc_headers, dim3((NJ + 63) / 64), dim3(64), 0, s, d_jobs, NJ, d_state, wpool); KCHK();
 		u32* d_bk = use_bk ? AP<u32>(h, o_bk) : nullptr;
+		u16* d_bcnt = use_bk ? AP<u16>(h, o_bcnt) : nullptr;
 		if (use_bk) HIPCHK(hipMemsetAsync(d_bk, 0, bk_zero_words * 4, s));
 		static const u32 max_parts = getenv("DSRC_GPU_REPLAY_PARTS") ? (u32)atoi(getenv("DSRC_GPU_REPLAY_PARTS")) : 2048u;   // tuning knob of k_replay
 		for (size_t sl = 0; sl + 1 < slice_lo.size(); ++sl)
@@ -721,23 +734,25 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			if (use_bk)
 			{	// k_bucket.h: partition, finish in LDS, place -- and behind them k_sort / k_replay for the streams k_part handed back
 				static const bool part_stage = !(getenv("DSRC_GPU_PART_STAGE") && atoi(getenv("DSRC_GPU_PART_STAGE")) == 0);
-				if (part_stage) hipLaunchKernelGGL((k_part<true, true>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk);
-				else hipLaunchKernelGGL((k_part<true, false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk);
+				if (part_stage) hipLaunchKernelGGL((k_part<true, true>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk, d_bcnt);
+				else hipLaunchKernelGGL((k_part<true, false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk, d_bcnt);
 				KCHK();
 				stage_mark(0); stage_mark(1);
 				u32 slice_bins = 0;
+				for (u32 i = s_lo; i < s_hi; ++i) if (jobs[i].bk_on) slice_bins = std::max(slice_bins, (jobs[i].n + BK_BIN - 1) >> BK_TB);
+				if (bk_binned && slice_bins) { hipLaunchKernelGGL(k_binoff, dim3(slice_bins, s_hi - s_lo), dim3(256), 0, s, d_jobs + s_lo, d_bcnt, d_bk, (u32)(SORT_WG * SORT_ITEMS)); KCHK(); }
 				for (const BkGroup& g : bk_groups[sl])
 				{
 					u32 hb = 0; bool any = false;
-					for (u32 i = g.lo; i < g.hi; ++i) if (jobs[i].bk_on) { any = true; hb = std::max(hb, jobs[i].bk_hb); slice_bins = std::max(slice_bins, (jobs[i].n + BK_BIN - 1) >> BK_TB); }
+					for (u32 i = g.lo; i < g.hi; ++i) if (jobs[i].bk_on) { any = true; hb = std::max(hb, jobs[i].bk_hb); }
 					if (!any) continue;
 					u32 lbm = 0; for (u32 i = g.lo; i < g.hi; ++i) if (jobs[i].bk_on) lbm = std::max(lbm, jobs[i].bk_lb);
 					const dim3 fgrid(((1u << hb) + MD_WAVES - 1) / MD_WAVES, g.hi - g.lo);
 					// rows by key where a bucket's keys fit (in as little LDS as they need), else handed out on first use through a map
-#define BK_FINISH(NN) { if ((1u << lbm) * 4 * MdRow<NN>::STRIDE <= 4096) hipLaunchKernelGGL((k_model<NN, 0, 4096>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
-						else if ((1u << lbm) * 4 * MdRow<NN>::STRIDE <= MD_ROW_BYTES) hipLaunchKernelGGL((k_model<NN, 0, MD_ROW_BYTES>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
-						else if (lbm <= 10) hipLaunchKernelGGL((k_model<NN, 10, MD_ROW_BYTES>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); \
-						else hipLaunchKernelGGL((k_model<NN, BK_MAX_LB, MD_ROW_BYTES>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk); }
+#define BK_FINISH(NN) { if ((1u << lbm) * 4 * MdRow<NN>::STRIDE <= 4096) hipLaunchKernelGGL((k_model<NN, 0, 4096>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk, d_bcnt, (u32)(SORT_WG * SORT_ITEMS)); \
+						else if ((1u << lbm) * 4 * MdRow<NN>::STRIDE <= MD_ROW_BYTES) hipLaunchKernelGGL((k_model<NN, 0, MD_ROW_BYTES>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk, d_bcnt, (u32)(SORT_WG * SORT_ITEMS)); \
+						else if (lbm <= 10) hipLaunchKernelGGL((k_model<NN, 10, MD_ROW_BYTES>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk, d_bcnt, (u32)(SORT_WG * SORT_ITEMS)); \
+						else hipLaunchKernelGGL((k_model<NN, BK_MAX_LB, MD_ROW_BYTES>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk, d_bcnt, (u32)(SORT_WG * SORT_ITEMS)); }
 					switch (jobs[g.lo].n_alpha)
 					{
 					case 4: BK_FINISH(4) break; case 8: BK_FINISH(8) break; case 16: BK_FINISH(16) break;

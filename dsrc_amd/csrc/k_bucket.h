@@ -111,7 +111,7 @@ __device__ __forceinline__ void bk_elems8_qua(const CtxJob& j, const BkWin& w, c
 // wave's packed counter pair, or ballots where the device failed k_lds_order_test).
 // STAGE: the tile leaves through LDS in bucket order (whole runs per store instruction, 64 KB more LDS) or straight from the registers.
 template <bool ATOMIC, bool STAGE>
-__global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SORT_OCC, SORT_OCC))) k_part(const CtxJob* jobs, u64* pool, const u8* d_stream, const u8* q_stream, const u8* qp_stream, BlkState* st, u32* bk)
+__global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SORT_OCC, SORT_OCC))) k_part(const CtxJob* jobs, u64* pool, const u8* d_stream, const u8* q_stream, const u8* qp_stream, BlkState* st, u32* bk, u16* bcnt)
 {
 	__shared__ u32 s_base[SORT_MAX_BINS];
 	__shared__ u32 s_delta[SORT_MAX_BINS];
@@ -266,6 +266,7 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 			if (dd < bins)
 			{
 				const u32 g = s_base[dd];
+				bcnt[(u64)j.bk_cnt + (u64)(tile / tile_elems) * bins + dd] = (u16)tot;      // the tile's elements per bucket (k_binoff)
 				s_delta[dd] = g - run; s_base[dd] = g + tot;
 #pragma unroll
 				for (u32 w = 0; w < SORT_WAVES; ++w) { s_off[w][dd] = (u16)run; run += c[w]; s_cnt[w][dd] = 0; }
@@ -322,8 +323,8 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 // Rescale() (a row's total reaches 2^16 - 2N, src/SymbolCoderRC.h:67-90) cannot happen here: a bucket holds at most BK_LIMIT
 // symbols, so no row's total gets past N + 2 * BK_LIMIT (streams with larger buckets take the k_sort / k_replay path, which
 // replays epochs).
-// The records leave grouped by time bin: the elements of a bin are consecutive (the bucket is in stream order), a run of them
-// takes its place in the bin's region of the record array with one global atomic on the bin's fill counter.
+// The records leave grouped by time bin: the elements of a bin are consecutive (the bucket is in stream order) and go, as a run,
+// to the place k_binoff worked out for this bucket inside the bin's region of the record array.
 #define MD_WG 256
 #define MD_WAVES (MD_WG / 64)
 #define MD_ROW_BYTES 8192              // counter rows per wave: 64 rows of a 32-symbol alphabet
@@ -377,22 +378,50 @@ template <int N> __device__ __forceinline__ u64 md_code(u32* row, u32 sym)
 	return (u64)f | ((u64)cum << 16) | ((u64)tot << 32);
 }
 
-// the runs of equal time bins in a window of a bucket (stream order, so equal bins are neighbours): lane -> its bin, the lane its
-// run starts at, and for that lane the length of the run
-__device__ __forceinline__ void md_runs(u32 t, bool valid, u32* bin, u32* head_lane, u32* run)
+// the runs of equal time bins in a window of a bucket (stream order, so equal bins are neighbours): lane -> its bin and the lane
+// its run starts at
+__device__ __forceinline__ void md_runs(u32 t, bool valid, u32* bin, u32* head_lane)
 {
 	const u32 lane = lane_id();
 	const u32 b = valid ? t >> BK_TB : 0xFFFFFFFFu;
 	const u32 pb = __shfl_up(b, 1);
 	const bool head = valid && (lane == 0 || b != pb);
 	const u64 hm = __ballot(head);
-	const u32 wl = (u32)__popcll(__ballot(valid));
-	const u64 later = lane == 63 ? 0ull : hm & ~((2ull << lane) - 1ull);
-	const u32 next = later ? (u32)__ffsll((long long)later) - 1u : wl;
 	const u64 le = hm & (lanemask_lt() | (1ull << lane));
 	*bin = b;
 	*head_lane = le ? 63u - (u32)__clzll((long long)le) : 0u;
-	*run = head ? next - lane : 0u;
+}
+
+// ---- k_binoff: where a bucket's records of a time bin go ------------------------------------------------------------------------------
+// k_part left the number of elements per (tile, bucket); a time bin is BK_BIN / tile consecutive tiles.  Per bin the exclusive scan
+// over the buckets gives every bucket's place inside the bin's region of the record array (k_model reads it), written over the
+// bin's first count row.  Grid: x = bin, y = stream of the slice; 256 threads, four buckets each.
+__global__ void __launch_bounds__(256) k_binoff(const CtxJob* jobs, u16* bcnt, const u32* bk, u32 tile_elems)
+{
+	const CtxJob j = jobs[blockIdx.y];
+	const u32 bin = blockIdx.x;
+	if (!j.bk_on || !j.bk_binned || bk[j.jid] || (bin << BK_TB) >= j.n) return;
+	const u32 bins = 1u << j.bk_hb, tpb = BK_BIN / tile_elems;
+	const u32 n_tiles = (j.n + tile_elems - 1) / tile_elems;
+	u16* rows = bcnt + j.bk_cnt + (u64)bin * tpb * bins;
+	u32 c[4], mine = 0;
+#pragma unroll
+	for (u32 k = 0; k < 4; ++k)
+	{
+		const u32 b = 4 * threadIdx.x + k;
+		c[k] = 0;
+		if (b < bins) for (u32 ti = 0; ti < tpb && bin * tpb + ti < n_tiles; ++ti) c[k] += rows[(u64)ti * bins + b];
+		mine += c[k];
+	}
+	u32 tot;
+	u32 run = block_excl_scan(mine, &tot);
+#pragma unroll
+	for (u32 k = 0; k < 4; ++k)
+	{
+		const u32 b = 4 * threadIdx.x + k;
+		if (b < bins) rows[b] = (u16)run;
+		run += c[k];
+	}
 }
 
 template <bool SMALL> struct MdMapT { typedef u8 T; static constexpr u32 NONE = 0xFFu, CLAIM = 0x80u; };
@@ -401,9 +430,9 @@ template <> struct MdMapT<false> { typedef u16 T; static constexpr u32 NONE = 0x
 // Grid: x = bucket / MD_WAVES, y = stream of the launch group (one alphabet size).  MAPBITS = 0: every stream of the group has at
 // most ROWS keys per bucket, key k owns row k; otherwise MAPBITS >= the group's largest bk_lb and rows are handed out on first use.
 // ROW_BYTES: LDS per wave for the rows (the fewer, the more buckets a CU works on at a time).
-#define MD_AHEAD 3                     // windows between a run's reservation (a global atomic) and the store that needs it
+#define MD_AHEAD 3                     // windows of a bucket requested ahead of the one being coded
 template <int N, int MAPBITS, int ROW_BYTES>
-__global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* pool, RcPack* rec_pool, u32* bk)
+__global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* pool, RcPack* rec_pool, u32* bk, const u16* bcnt, u32 tile_elems)
 {
 	constexpr u32 STRIDE = MdRow<N>::STRIDE;
 	constexpr u32 ROWS = ROW_BYTES / (4 * STRIDE);
@@ -411,6 +440,7 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 	typedef typename Map::T map_t;
 	__shared__ map_t s_map[MD_WAVES][1 << MAPBITS];
 	__shared__ unsigned long long s_rows[MD_WAVES][ROW_BYTES / 8];
+	__shared__ u16 s_off[MD_WAVES][BK_MAX_BINS];
 	static_assert(N + 2 * BK_LIMIT < (1 << 16) - 2 * N, "a row of a bucket must stay below the rescale threshold");
 	const CtxJob j = jobs[blockIdx.y];
 	const u32 w = wave_id(), lane = lane_id();
@@ -420,43 +450,31 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 	if (!nb) return;
 	const u64* src = pool + j.elems + lo;
 	RcPack* recs = rec_pool + j.trip;
-	u32* fill = bk + j.bk_fill;
 	const u32 keys = 1u << j.bk_lb, kmask = keys - 1u;
 	const bool binned = j.bk_binned != 0;
-	map_t* map = s_map[w]; u32* rows = (u32*)s_rows[w];
+	map_t* map = s_map[w]; u32* rows = (u32*)s_rows[w]; u16* off = s_off[w];
+	const u32 n_bins = (j.n + BK_BIN - 1) >> BK_TB;
 
 	// the first windows are on their way while the rows are set up
-	u64 elq[MD_AHEAD + 2];                                  // elq[k]: the elements of window p / 64 + k
+	u64 elq[MD_AHEAD];                                      // elq[k]: the elements of window p / 64 + k
 #pragma unroll
-	for (u32 k = 0; k < MD_AHEAD + 2; ++k) elq[k] = 64 * k + lane < nb ? src[64 * k + lane] : 0ull;
+	for (u32 k = 0; k < MD_AHEAD; ++k) elq[k] = 64 * k + lane < nb ? src[64 * k + lane] : 0ull;
+	// where this bucket's records go inside every time bin's region (k_binoff)
+	if (binned) for (u32 b = lane; b < n_bins; b += 64) off[b] = bcnt[(u64)j.bk_cnt + (u64)b * (BK_BIN / tile_elems) * (1u << j.bk_hb) + bucket];
 	if (MAPBITS) for (u32 i = lane; i < keys; i += 64) map[i] = (map_t)Map::NONE;
 	for (u32 i = lane; i < (MAPBITS ? ROWS : keys) * STRIDE; i += 64) rows[i] = md_init_word<N>(i % STRIDE);      // every counter 1
 	wave_fence();
 
-	// A run of equal bins takes its place in the bin's region of the record array with one global atomic on the bin's fill counter,
-	// issued MD_AHEAD windows ahead: it is back by the time the window's records exist.
-	u32 binq[MD_AHEAD + 1], hlq[MD_AHEAD + 1], baseq[MD_AHEAD + 1];
-#pragma unroll
-	for (u32 k = 0; k < MD_AHEAD; ++k)
-	{
-		u32 run;
-		md_runs((u32)elq[k], 64 * k + lane < nb, &binq[k], &hlq[k], &run);
-		baseq[k] = 0;
-		if (binned && run) baseq[k] = atomicAdd(&fill[binq[k]], run);
-	}
+	// The bucket's records of a time bin are consecutive (stream order): they go to off[bin], off[bin] + 1, ...; carry_*: the bin the
+	// previous window ended in and how many of its records are out.
+	u32 carry_bin = 0xFFFFFFFFu, carry_cnt = 0;
 	u32 n_rows = 0;
 	for (u32 p = 0; p < nb; p += 64)
 	{
 		const u64 el = elq[0];
 		const u32 i = p + lane;
 		const bool valid = i < nb;
-		const u64 el_new = i + 64 * (MD_AHEAD + 2) < nb ? src[i + 64 * (MD_AHEAD + 2)] : 0ull;
-		{
-			u32 run;
-			md_runs((u32)elq[MD_AHEAD], i + 64 * MD_AHEAD < nb, &binq[MD_AHEAD], &hlq[MD_AHEAD], &run);
-			baseq[MD_AHEAD] = 0;
-			if (binned && run) baseq[MD_AHEAD] = atomicAdd(&fill[binq[MD_AHEAD]], run);
-		}
+		const u64 el_new = i + 64 * MD_AHEAD < nb ? src[i + 64 * MD_AHEAD] : 0ull;
 
 		const u32 key = (u32)(el >> ELEM_CTX_SHIFT) & kmask, sym = (u32)(el >> ELEM_SYM_SHIFT) & (u32)(N - 1), t = (u32)el;
 		u32 rid = key;
@@ -485,18 +503,20 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 		}
 		u64 rec = 0;
 		if (valid) rec = md_code<N>(rows + rid * STRIDE, sym);
-		const u32 hl = hlq[0];
-		const u32 at = __shfl(baseq[0], (int)hl) + (lane - hl);
-		if (valid)
+		if (binned)
 		{
-			if (binned) recs[(binq[0] << BK_TB) + at] = rec | ((u64)(t & (BK_BIN - 1u)) << 48);
-			else recs[t] = rec;
+			u32 bin, hl;
+			md_runs(t, valid, &bin, &hl);
+			u32 in_run = lane - hl;
+			if (hl == 0 && bin == carry_bin) in_run += carry_cnt;
+			if (valid) recs[(bin << BK_TB) + (u32)off[bin] + in_run] = rec | ((u64)(t & (BK_BIN - 1u)) << 48);
+			const u32 last = (nb - p < 64 ? nb - p : 64u) - 1u;              // the window's last element
+			carry_bin = (u32)__shfl(bin, (int)last); carry_cnt = (u32)__shfl(in_run, (int)last) + 1u;
 		}
+		else if (valid) recs[t] = rec;
 #pragma unroll
-		for (u32 k = 0; k < MD_AHEAD + 1; ++k) elq[k] = elq[k + 1];
-		elq[MD_AHEAD + 1] = el_new;
-#pragma unroll
-		for (u32 k = 0; k < MD_AHEAD; ++k) { binq[k] = binq[k + 1]; hlq[k] = hlq[k + 1]; baseq[k] = baseq[k + 1]; }
+		for (u32 k = 0; k + 1 < MD_AHEAD; ++k) elq[k] = elq[k + 1];
+		elq[MD_AHEAD - 1] = el_new;
 	}
 }
 

@@ -56,7 +56,7 @@ struct CtxJob     // one (block, stream)
 	u32 bk_mul, bk_kmask; // key = (ctx * bk_mul) & bk_kmask
 	u32 bk_boff;        // bk index of the stream's 2^bk_hb + 1 bucket offsets
 	u32 bk_fb;          // bk index of the fallback list of the stream's launch group: count, then job ids
-	u32 bk_fill;        // bk index of the stream's time-bin fill counters
+	u32 bk_cnt;         // index (u16 units) of the stream's per-tile bucket counts / per-bin bucket offsets (k_part, k_binoff)
 	u32 pad0, pad1;
 };
 
