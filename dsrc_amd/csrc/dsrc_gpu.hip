@@ -575,9 +575,9 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	// streams of one alphabet size inside a slice) a fallback list that k_part fills with the streams it hands back to k_sort / k_replay
 	struct BkGroup { u32 lo, hi, fb; };
 	std::vector<std::vector<BkGroup> > bk_groups(slice_lo.size());
-	static const bool bk_enabled = !(getenv("DSRC_GPU_BUCKETS") && atoi(getenv("DSRC_GPU_BUCKETS")) == 0);
-	static const u32 bk_min = getenv("DSRC_GPU_BUCKETS_MIN") ? (u32)atoi(getenv("DSRC_GPU_BUCKETS_MIN")) : 16384u;   // shorter streams: a bucket per workgroup does not pay
-	static const bool bk_binned = !(getenv("DSRC_GPU_BUCKETS_BINNED") && atoi(getenv("DSRC_GPU_BUCKETS_BINNED")) == 0);
+	const bool bk_enabled = !(getenv("DSRC_GPU_BUCKETS") && atoi(getenv("DSRC_GPU_BUCKETS")) == 0);
+	const u32 bk_min = getenv("DSRC_GPU_BUCKETS_MIN") ? (u32)atoi(getenv("DSRC_GPU_BUCKETS_MIN")) : 16384u;   // shorter streams: a bucket per workgroup does not pay
+	const bool bk_binned = !(getenv("DSRC_GPU_BUCKETS_BINNED") && atoi(getenv("DSRC_GPU_BUCKETS_BINNED")) == 0);
 	const bool use_bk = bk_enabled && NJ > 0 && h->lds64_ordered;      // k_model stands on the LDS applying atomics in lane order (k_lds_order_test)
 	size_t o_bk = 0, bk_zero_words = 0, o_bcnt = 0;
 	static_assert(BK_BIN % (SORT_WG * SORT_ITEMS) == 0, "a time bin is a whole number of k_part tiles");
@@ -733,7 +733,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			stage_mark(0);
 			if (use_bk)
 			{	// k_bucket.h: partition, finish in LDS, place -- and behind them k_sort / k_replay for the streams k_part handed back
-				static const bool part_stage = !(getenv("DSRC_GPU_PART_STAGE") && atoi(getenv("DSRC_GPU_PART_STAGE")) == 0);
+				const bool part_stage = !(getenv("DSRC_GPU_PART_STAGE") && atoi(getenv("DSRC_GPU_PART_STAGE")) == 0);
 				if (part_stage) hipLaunchKernelGGL((k_part<true, true>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk, d_bcnt);
 				else hipLaunchKernelGGL((k_part<true, false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk, d_bcnt);
 				KCHK();

@@ -143,3 +143,30 @@ def state_dependent_fastq(n_per_region: int = 9000):
             out += [title, b"\n", seq, b"\n+\n", qua, b"\n"]
         first += n_per_region
     return b"".join(out)
+
+
+def alphabet_fastq(n_sym: int, n_rec: int = 400, L: int = 100, seed: int = 1, iupac: bool = False, spread: bool = False, q_max: int = 93):
+    """Reads whose qualities use exactly `n_sym` distinct values (the order models take the 16-, 32-, 64- or 128-symbol alphabet
+    that holds them).  spread = False: values drawn around a slowly moving mean (few contexts, as instruments write them);
+    True: independent uniform values (as many contexts as symbols allow: the bucketed path runs out of counter rows).
+    iupac: N/R/W/S with high quality stay in the DNA stream (the 8-symbol DNA alphabet at -d >= 1)."""
+    rng = random.Random(1000 * n_sym + seed)
+    vals = sorted(rng.sample(range(0, q_max), n_sym))      # q_max <= 64 for the lossy modes (their bin table has 64 entries)
+    recs = []
+    for i in range(n_rec):
+        if spread:
+            q = [rng.choice(vals) for _ in range(L)]
+        else:
+            c = rng.randrange(n_sym)
+            q = []
+            for _ in range(L):
+                c = min(n_sym - 1, max(0, c + rng.choice([-1, 0, 0, 0, 1])))
+                q.append(vals[c])
+        if i == 0:
+            q[:n_sym] = vals[:L]                        # every value at least once
+        alpha = b"ACGTACGTACGTNRWS" if iupac else b"ACGT"
+        seq = bytes(rng.choice(alpha) for _ in range(L))
+        if iupac:
+            q = [max(v, 10) if seq[k] in b"NRWS" else v for k, v in enumerate(q)]
+        recs.append(b"@a.%d %d\n" % (i, L) + seq + b"\n+\n" + bytes(33 + v for v in q))
+    return b"\n".join(recs)

@@ -1,0 +1,72 @@
+"""The bucketed context path (dsrc_amd/csrc/k_bucket.h: k_part, k_binoff, k_model, k_place) on the CPU emulator: every alphabet size
+of the order models, every counter-row layout (rows by key, rows handed out through the byte / the 16-bit map), both hand-backs to
+k_sort / k_replay (a bucket too large for one wave, more contexts in a bucket than rows), the scattering form, and the switch that
+turns the path off -- always the oracle's block.  Test harness only; the product links libdsrc_gpu.so."""
+import random
+
+import pytest
+
+from dsrc_amd import synth
+from tests._oracle import Config
+from tests.cases import alphabet_fastq
+from tests.test_emu_kernels import emu, run  # noqa: F401  (fixture)
+
+
+def check(emu, oracle, data, levels):
+    for d, q, lossy in levels:
+        cfg = Config.from_levels(d, q, lossy)
+        assert run(emu, cfg, data) == oracle.compress_block(cfg, data), (d, q, lossy)
+
+
+@pytest.mark.parametrize("n_sym", [3, 12, 20, 40, 90])
+def test_alphabet_sizes(emu, oracle, n_sym):
+    """3 / 12 / 20 / 40 / 90 quality values: the 16-, 32-, 64- and 128-symbol models (k_model<16..128>: two to four levels of
+    counter words), at -q1 (few key bits: rows by key) and -q2 (rows through the map)."""
+    data = alphabet_fastq(n_sym, n_rec=420, L=100)
+    check(emu, oracle, data, [(2, 2, False), (1, 1, False)])
+
+
+def test_dna_with_eight_symbols_and_lossy_orders(emu, oracle):
+    """Ambiguity codes kept in the DNA stream: the 8-symbol DNA model (k_model<8>, 21 key bits at -d3: eleven of them inside a
+    bucket); the lossy quality model of -q2 (8 symbols, order 6: 21 key bits as well)."""
+    data = alphabet_fastq(20, n_rec=420, L=100, iupac=True)
+    check(emu, oracle, data, [(3, 2, False), (2, 1, False)])
+    data = alphabet_fastq(20, n_rec=420, L=100, iupac=True, q_max=42)
+    check(emu, oracle, data, [(3, 2, True), (1, 1, True)])
+
+
+def test_model_runs_out_of_rows(emu, oracle, capfd, monkeypatch):
+    """Independent uniform qualities: nearly every symbol of a bucket has a context of its own, k_model runs out of counter rows and
+    hands the stream back to k_sort / k_replay (their launches follow k_model's in the same batch)."""
+    monkeypatch.setenv("DSRC_GPU_DEBUG", "1")
+    data = alphabet_fastq(30, n_rec=500, L=100, spread=True)
+    check(emu, oracle, data, [(3, 2, False)])
+    err = capfd.readouterr().err
+    assert "2 of 2 streams tried, 1 handed back" in err, err
+
+
+def test_bucket_too_large_for_a_wave(emu, oracle, capfd, monkeypatch):
+    """A context that holds most of a stream: one bucket is beyond BK_LIMIT, k_part hands the stream back before partitioning."""
+    monkeypatch.setenv("DSRC_GPU_DEBUG", "1")
+    rng = random.Random(3)
+    recs = []
+    for i in range(300):
+        seq = "".join(rng.choice("AAAAAAAAAAAAAAAC") for _ in range(200))
+        q = "".join("I" if rng.random() < 0.98 else "H" for _ in range(200))
+        recs.append(f"@r.{i}\n{seq}\n+\n{q}")
+    data = "\n".join(recs).encode()
+    check(emu, oracle, data, [(1, 1, False)])
+    assert "2 of 2 streams tried, 1 handed back" in capfd.readouterr().err       # the DNA stream (64 contexts, one of them with most symbols)
+
+
+@pytest.mark.parametrize("env", [{"DSRC_GPU_BUCKETS": "0"}, {"DSRC_GPU_BUCKETS_BINNED": "0"}, {"DSRC_GPU_PART_STAGE": "0"}, {"DSRC_GPU_BUCKETS_MIN": "0"}])
+def test_switches(emu, oracle, env, monkeypatch):
+    """The path off; records scattered to stream order by k_model itself (no k_binoff / k_place); k_part storing from the
+    registers; and the path on for streams of any length (tiny blocks: most buckets empty)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    # (the library reads the switches per batch)
+    data = synth.illumina_fastq(260)[:-1]
+    check(emu, oracle, data, [(3, 2, False), (2, 1, True)])
+    tiny = synth.illumina_fastq(30)[:-1]
+    check(emu, oracle, tiny, [(3, 2, False)])

@@ -325,3 +325,46 @@ def test_one_block_of_a_gigabyte(gpu, oracle):
     want = oracle.compress_block(cfg, chunk)
     assert len(got[0]) == len(want[0]) and hashlib.sha256(got[0]).digest() == hashlib.sha256(want[0]).digest()
     assert got[1] == want[1] and got[2] == want[2]
+
+
+# ---- the bucketed context path (k_bucket.h: k_part, k_binoff, k_model, k_place) ----------------------------------------------
+
+@pytest.mark.parametrize("n_sym", [3, 12, 20, 40, 90])
+def test_bucketed_path_alphabet_sizes(gpu, oracle, n_sym):
+    """16-, 32-, 64- and 128-symbol quality models (k_model<16..128>: one to four counter words per symbol) at -q1 / -q2, with
+    the 4-symbol DNA model beside them, on blocks of ~1.3 M symbols (every bucket of the 1024 in use)."""
+    from tests.cases import alphabet_fastq
+    data = alphabet_fastq(n_sym, n_rec=9000, L=150)
+    for d, q in ((2, 2), (1, 1)):
+        _check(gpu, oracle, Config.from_levels(d, q), [data])
+
+
+def test_bucketed_path_hand_backs_and_switches(gpu, oracle, monkeypatch, capfd):
+    """Streams the bucketed path hands back to k_sort / k_replay inside a batch of streams it keeps: independent uniform qualities
+    (k_model runs out of counter rows), a context with most of a stream's symbols (k_part finds a bucket too large for one wave);
+    then the same batch with the path off, with k_model scattering to stream order itself, with k_part storing from registers."""
+    import random
+    from tests.cases import alphabet_fastq
+    rng = random.Random(3)
+    hot = "\n".join("@r.%d\n%s\n+\n%s" % (i, "".join(rng.choice("AAAAAAAAAAAAAAAC") for _ in range(200)),
+                                            "".join("I" if rng.random() < 0.98 else "H" for _ in range(200))) for i in range(3000)).encode()
+    chunks = [synth.illumina_fastq(6000)[:-1], alphabet_fastq(30, n_rec=6000, L=100, spread=True), hot, synth.illumina_fastq(6000, first=7001)[:-1]]
+    cfg = Config.from_levels(3, 2)
+    monkeypatch.setenv("DSRC_GPU_DEBUG", "1")
+    _check(gpu, oracle, cfg, chunks)
+    err = capfd.readouterr().err
+    assert "8 of 8 streams tried, 3 handed back" in err, err          # the spread qualities, the hot block's qualities and bases
+    for env in ({"DSRC_GPU_BUCKETS": "0"}, {"DSRC_GPU_BUCKETS_BINNED": "0"}, {"DSRC_GPU_PART_STAGE": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        _check(gpu, oracle, cfg, chunks)
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+def test_bucketed_path_lossy_and_eight_symbol_dna(gpu, oracle):
+    """21 key bits (eleven of them inside a bucket, rows through the 16-bit map): the lossy quality model of -q2 and the 8-symbol
+    DNA model of -d3 on reads with ambiguity codes of high quality."""
+    from tests.cases import alphabet_fastq
+    _check(gpu, oracle, Config.from_levels(3, 2), [alphabet_fastq(20, n_rec=8000, L=120, iupac=True)])
+    _check(gpu, oracle, Config.from_levels(3, 2, True), [alphabet_fastq(20, n_rec=8000, L=120, iupac=True, q_max=42)])
