@@ -33,8 +33,10 @@ BUF = 8 << 20                     # -b8 (reference default, src/Common.h:156)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 RECS_PER_BLOCK = 22300
 PMC_RC_BYTES_PER_BLOCK = (13.3515e6 * 2 + 13.3427e6) * 1024 / 512   # measured, see roofline.traffic below
-PMC_SORT_BYTES_PER_BLOCK = (16.6858e6 * 2 + 65.8718e6) * 1024 / 512  # k_sort, eight launches of a 512-block batch (same profile)
-PMC_REPLAY_BYTES_PER_BLOCK = ((9.2572e6 + 8.9190e6) * 2 + 55.0891e6 + 54.9436e6) * 1024 / 512   # k_replay<32> + k_replay<4>: 293 MB per block, 225 of them the scattered 8-byte records at one 32-byte sector each
+# round 4 (profiles/r04_pmc_b512_p1_bucket.txt, KiB per 512-block batch): k_part, eight launches; k_binoff + k_model<32> + k_model<4> + k_place
+PMC_PART_BYTES_PER_BLOCK = (3.4165e6 * 2 + 51.2090e6) * 1024 / 512
+PMC_MODEL_BYTES_PER_BLOCK = ((0.4188e6 + 7.5565e6 + 7.5460e6 + 13.3499e6) * 2 + 0.4178e6 + 15.9316e6 + 15.3738e6 + 26.6939e6) * 1024 / 512
+PMC_ALL_BYTES_PER_BLOCK = 290.0e6 * 1024 / 512      # every compression kernel of the batch: 580 MB per block = 52 x the algorithmic 11.06 MB (round 2: 69 x)
 DECODE_TRAFFIC_PER_BLOCK = 663e6  # HBM bytes per decoded block at -d3 -q2: (FETCH_SIZE + WRITE_SIZE of k_dec_qrc and k_dec_dnarc) x 1 KiB / 2400 blocks (profiles/r03_pmc_decode_b2400.txt)
 MAX_RESIDENT = 3                  # distinct input shards kept in HBM per scheduler instance (2 when N > 1: rank 0 also holds the gathered streams)
 
@@ -378,10 +380,10 @@ def measure_host_e2e(src, size, td, inst=4, runs=3, gap=6.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)  # 10 x 1500 blocks of 8 MiB ~ 3.3 passes over the 100 M-read set (~4500 blocks); inputs stay resident in HBM
+    ap.add_argument("--steps", type=int, default=10)  # 10 x 1800 blocks of 8 MiB = 4 passes over the 100 M-read set (~4500 blocks); inputs stay resident in HBM
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=int(os.environ.get("DSRC_BENCH_BLOCKS", "1500")), help="8 MiB chunks per step per GPU")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DSRC_BENCH_PIPELINE", "5")), help="scheduler instances per GPU")
+    ap.add_argument("--blocks", type=int, default=int(os.environ.get("DSRC_BENCH_BLOCKS", "1800")), help="8 MiB chunks per step per GPU")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DSRC_BENCH_PIPELINE", "4")), help="scheduler instances per GPU (round 4: four batches of 450 blocks: 39-40 GB/s; five of 300: 35-37)")
     ap.add_argument("--dna", type=int, default=3)
     ap.add_argument("--qua", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
@@ -631,14 +633,14 @@ def main():
             # the kernel that bounds the THROUGHPUT (k_rc above is the longest launch, but it is hidden behind the other
             # instances' front ends): the context sort.  Same algorithmic bytes per launch group, its own summed HIP-event time
             line["roofline_frontend"] = {
-                "bound": "hbm", "kernel": "k_sort (stable LSD radix sort of (context, symbol, t) per stream; all launches of one sub-batch)",
+                "bound": "hbm", "kernel": "k_part (stable partition of a stream's (context key, symbol, t) elements into <= 1024 buckets; all launches of one sub-batch)",
                 "achieved": round(alg / (sort_ms / 1e3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(alg / (sort_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5), "kernel_ms": round(sort_ms, 2), "replay_ms": round(replay_ms, 2),
-                "launch_bytes": int(alg), "traffic": int(PMC_SORT_BYTES_PER_BLOCK * sub_blocks),
-                "replay_traffic": int(PMC_REPLAY_BYTES_PER_BLOCK * sub_blocks),
-                "note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE of the k_sort launches of a 512-block batch / 512 (profiles/r02_pmc_b512_p1_d3q2.txt); "
-                        "replay_ms = k_replay_seams + k_replay of the same sub-batch, replay_traffic = the same counters for k_replay: its scatter of one 8-byte record per symbol to stream order "
-                        "(one 32-byte sector each) is what bounds the pipeline with several instances (DESIGN section 10: 33.7 instead of 25.8 GB/s without it)"}
+                "frac": round(alg / (sort_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5), "kernel_ms": round(sort_ms, 2), "model_ms": round(replay_ms, 2),
+                "launch_bytes": int(alg), "traffic": int(PMC_PART_BYTES_PER_BLOCK * sub_blocks),
+                "model_traffic": int(PMC_MODEL_BYTES_PER_BLOCK * sub_blocks), "all_kernels_traffic": int(PMC_ALL_BYTES_PER_BLOCK * sub_blocks),
+                "note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE of the k_part launches of a 512-block batch / 512 (profiles/r04_pmc_b512_p1_bucket.txt); "
+                        "model_ms / model_traffic = k_binoff + k_model (adaptive counter rows in LDS, one wave per bucket) + k_place (time bins into stream order) of the same sub-batch; "
+                        "all_kernels_traffic: every compression kernel, 52 x the algorithmic bytes (round 2, with the two-pass sort and the scattering replay: 69 x)"}
         decode_line = None
         if args.decode_blocks > 0 and world == 1:
             decode_line = measure_decode(lanes, cfg, args.decode_blocks, total_steps - 1)

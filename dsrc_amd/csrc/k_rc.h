@@ -886,10 +886,13 @@ struct RcFin { u32 n; u8 b[60]; };
 #endif                                 // CU with two k_sort workgroups, and it issues half as many DMA requests per symbol
 #define RC_CHUNK 64                    // symbols per chain per LDS chunk (768 B = 48 lanes x 16 B)
 #define RC_ROW_U4 49                   // LDS row pitch in 16-byte units: 48 of data + 1 so that a 16-lane ds_read_b128 pass covers all 64 banks
-#define RC_OVERREAD (8 * RC_CHUNK)     // records the loaders may touch past the longest chain of a wave (arena slack)
 #ifndef RC_LOADERS
-#define RC_LOADERS 2                   // loader waves per workgroup (each feeds RC_LANES / RC_LOADERS rows)
+#define RC_LOADERS 4                   // loader waves per workgroup (each feeds RC_LANES / RC_LOADERS rows)
 #endif
+#ifndef RC_DEPTH
+#define RC_DEPTH 8                     // register sets of a loader wave: a chunk is requested RC_DEPTH - 1 chunk periods before it is converted (even)
+#endif
+#define RC_OVERREAD ((RC_DEPTH + 2) * RC_CHUNK)     // records the loaders may touch past the longest chain of a wave (arena slack)
 #define RC_XB 64                       // per-lane byte buffer of the exact path (LDS)
 
 typedef u32 __attribute__((vector_size(16))) U4;   // one 16-byte LDS / global access
@@ -1070,33 +1073,27 @@ __device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains
 		const u8* base = uniform_ptr(rec_pool + __shfl(c.trip, 0));
 		const u32 pitch = (u32)__builtin_amdgcn_readfirstlane((int)(c.pitch * (u32)sizeof(RcPack)));
 		const u32 lw = wave_id() - 1u, CB = RC_CHUNK * (u32)sizeof(RcPack);
-		// four register sets: a chunk is requested three chunk periods (~8 us) before it is converted -- with other instances'
-		// scatter traffic on the memory system a load can take several microseconds (one period ahead: k_rc 174 ms per 300 blocks
-		// under contention, 77 alone)
-		RcPack r0[RC_ROWS_PER_LOADER], r1[RC_ROWS_PER_LOADER], r2[RC_ROWS_PER_LOADER], r3[RC_ROWS_PER_LOADER];
-		rc_fetch(r0, base, pitch, 0, lw, n_live);
-		rc_fetch(r1, base, pitch, CB, lw, n_live);
-		rc_fetch(r2, base, pitch, 2 * CB, lw, n_live);
-		rc_fetch(r3, base, pitch, 3 * CB, lw, n_live);
-		rc_convert(buf_a, r0, lw, n_live);
+		// RC_DEPTH register sets: a chunk is requested RC_DEPTH - 1 chunk periods before it is converted -- with other instances'
+		// traffic on the memory system a load can take many microseconds, and the coder waits for the slowest of a chunk's 32
+		// rows (round 2, four sets of two loaders: k_rc 130 ms alone, 175 ms next to three other instances' front ends)
+		static_assert(RC_DEPTH % 2 == 0 && RC_DEPTH >= 2, "buffer parity must be static");
+		RcPack r[RC_DEPTH][RC_ROWS_PER_LOADER];
+#pragma unroll
+		for (u32 d = 0; d < RC_DEPTH; ++d) rc_fetch(r[d], base, pitch, d * CB, lw, n_live);
+		rc_convert(buf_a, r[0], lw, n_live);
 		__syncthreads();                                                       // chunk 0 is there
-		for (u32 t0 = 0; t0 < wave_full; t0 += 2 * RC_CHUNK)
+		// one barrier per chunk the coder works through: it takes them in pairs (buf_a, buf_b)
+		const u32 n_sync = 2u * ((wave_full + 2 * RC_CHUNK - 1) / (2 * RC_CHUNK));
+		for (u32 q = 0; q < n_sync; q += RC_DEPTH)
 		{
-			const u32 off = t0 * (u32)sizeof(RcPack);
-			rc_fetch(r0, base, pitch, off + 4 * CB, lw, n_live);
-			rc_convert(buf_b, r1, lw, n_live);
-			__syncthreads();                                                   // coder is through buf_a, chunk t0+64 is in buf_b
-			rc_fetch(r1, base, pitch, off + 5 * CB, lw, n_live);
-			rc_convert(buf_a, r2, lw, n_live);
-			__syncthreads();                                                   // coder is through buf_b, chunk t0+128 is in buf_a
-			t0 += 2 * RC_CHUNK;
-			if (t0 >= wave_full) break;                                        // one coder iteration = two barriers: the halves are the same code on rotated sets
-			rc_fetch(r2, base, pitch, off + 6 * CB, lw, n_live);
-			rc_convert(buf_b, r3, lw, n_live);
-			__syncthreads();
-			rc_fetch(r3, base, pitch, off + 7 * CB, lw, n_live);
-			rc_convert(buf_a, r0, lw, n_live);
-			__syncthreads();
+#pragma unroll
+			for (u32 k = 0; k < RC_DEPTH; ++k)
+			{	// the coder is in chunk q + k (buf_a for even k): its set is free for chunk q + k + RC_DEPTH, the next chunk goes into the other buffer
+				if (q + k >= n_sync) break;
+				rc_fetch(r[k], base, pitch, (q + k + RC_DEPTH) * CB, lw, n_live);
+				rc_convert((k & 1u) ? buf_a : buf_b, r[(k + 1) % RC_DEPTH], lw, n_live);
+				__syncthreads();
+			}
 		}
 		return;
 	}

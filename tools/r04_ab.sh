@@ -8,7 +8,7 @@ run() { # name, pipeline, env...
   python - <<PY
 import json
 d=json.loads(open("$O/$name.json").read().strip().splitlines()[-1])
-print("$name", d["value"], "MB/s  batch_ms", d["roofline"]["batch_ms"], "sort_ms", d["roofline_frontend"]["kernel_ms"], "replay_ms", d["roofline_frontend"]["replay_ms"], "rc_ms", d["roofline"]["kernel_ms"])
+print("$name", d["value"], "MB/s  batch_ms", d["roofline"]["batch_ms"], "sort_ms", d["roofline_frontend"]["kernel_ms"], "replay_ms", d["roofline_frontend"].get("model_ms", d["roofline_frontend"].get("replay_ms")), "rc_ms", d["roofline"]["kernel_ms"])
 PY
 }
 run old_p1 1 DSRC_GPU_BUCKETS=0

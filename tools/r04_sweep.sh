@@ -8,7 +8,7 @@ run() { # name, pipeline, blocks per instance, env...
 import json
 try:
     d=json.loads(open("$O/$name.json").read().strip().splitlines()[-1])
-    print("$name", d["value"], "MB/s  batch_ms", d["roofline"]["batch_ms"], "sort_ms", d["roofline_frontend"]["kernel_ms"], "replay_ms", d["roofline_frontend"]["replay_ms"], "rc_ms", d["roofline"]["kernel_ms"])
+    print("$name", d["value"], "MB/s  batch_ms", d["roofline"]["batch_ms"], "sort_ms", d["roofline_frontend"]["kernel_ms"], "replay_ms", d["roofline_frontend"].get("model_ms", d["roofline_frontend"].get("replay_ms")), "rc_ms", d["roofline"]["kernel_ms"])
 except Exception as e:
     print("$name failed", e, open("$O/$name.err").read()[-300:])
 PY
