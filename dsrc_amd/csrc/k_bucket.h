@@ -503,6 +503,9 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 		}
 		u64 rec = 0;
 		if (valid) rec = md_code<N>(rows + rid * STRIDE, sym);
+#ifdef DSRC_EMU_BUILD
+		(void)__ballot(true);                                         // the emulator runs lanes one after the other: keep them in step per window
+#endif
 		if (binned)
 		{
 			u32 bin, hl;
