@@ -578,6 +578,9 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	const bool bk_enabled = !(getenv("DSRC_GPU_BUCKETS") && atoi(getenv("DSRC_GPU_BUCKETS")) == 0);
 	const u32 bk_min = getenv("DSRC_GPU_BUCKETS_MIN") ? (u32)atoi(getenv("DSRC_GPU_BUCKETS_MIN")) : 16384u;   // shorter streams: a bucket per workgroup does not pay
 	const bool bk_binned = !(getenv("DSRC_GPU_BUCKETS_BINNED") && atoi(getenv("DSRC_GPU_BUCKETS_BINNED")) == 0);
+	// elements per bucket the bucket digit aims at (a wave walks its bucket serially; longer buckets give longer runs per time bin)
+	const u64 bk_elems_dna = getenv("DSRC_GPU_BUCKET_ELEMS_DNA") ? (u64)atol(getenv("DSRC_GPU_BUCKET_ELEMS_DNA")) : 4096u;      // 512 buckets of 6.5 k bases: 512 rows of 8 bytes per wave, runs of 16 records per time bin
+	const u64 bk_elems_qua = getenv("DSRC_GPU_BUCKET_ELEMS_QUA") ? (u64)atol(getenv("DSRC_GPU_BUCKET_ELEMS_QUA")) : 2048u;
 	const bool use_bk = bk_enabled && NJ > 0 && h->lds64_ordered;      // k_model stands on the LDS applying atomics in lane order (k_lds_order_test)
 	size_t o_bk = 0, bk_zero_words = 0, o_bcnt = 0;
 	static_assert(BK_BIN % (SORT_WG * SORT_ITEMS) == 0, "a time bin is a whole number of k_part tiles");
@@ -602,7 +605,8 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			j.bk_binned = bk_binned ? 1u : 0u;
 			j.bk_on = (j.n >= bk_min && n_bins <= BK_MAX_BINS && j.key_bits <= BK_MAX_HB + BK_MAX_LB) ? 1u : 0u;
 			// bucket digit: ~2048 elements per bucket on average, at most 1024 buckets, at most BK_MAX_LB key bits left for the LDS sort
-			u32 hb = 0; while (hb < BK_MAX_HB && ((u64)2048 << hb) < j.n) ++hb;
+			const u64 per_bucket = j.is_dna ? bk_elems_dna : bk_elems_qua;
+			u32 hb = 0; while (hb < BK_MAX_HB && (per_bucket << hb) < j.n) ++hb;
 			hb = std::min(hb, j.key_bits);
 			if (j.key_bits > BK_MAX_LB) hb = std::max(hb, j.key_bits - BK_MAX_LB);
 			j.bk_hb = hb; j.bk_lb = j.key_bits - hb;

@@ -11,9 +11,9 @@
 //              over all buckets) into <= 1024 buckets of a few thousand elements -- what pass 0 of k_sort does, on another digit;
 //   k_model  : one WAVE per bucket: the adaptive counter rows of the bucket's contexts live in LDS (the reference's model table,
 //              1/1024 of it at a time) and every symbol is coded on its row with one returning LDS atomic per trie level, in
-//              stream order; the records leave grouped by time bin (t >> 14): a bucket's ~16 consecutive records of a bin are
-//              written as one run into the bin's region of the stream's record array (the record carries t & 16383);
-//   k_place  : one workgroup per (stream, time bin): the bin's 16 K records are put in stream order through LDS, in place.
+//              stream order; the records leave grouped by time bin (t >> BK_TB): a bucket's consecutive records of a bin are
+//              written as one run into the bin's region of the stream's record array (the record carries the low bits of t);
+//   k_place  : one workgroup per (stream, time bin): the bin's 8 K records are put in stream order through LDS, in place.
 // Per symbol that is 8 B written + 8 B read (partition), 8 B + 8 B (model -> bins), 8 B + 8 B (place), all in runs, against
 // 8 + 16 + 8 B in runs plus one 32-byte sector per record before -- and no sort of the bucket at all: the second LSD pass, the
 // segmented-scan replay and its seams are replaced by log2(N) LDS atomics per symbol.
@@ -28,9 +28,11 @@
 #define BK_MAX_HB 10                   // bucket digit: <= 1024 buckets (k_part's LDS is k_sort's)
 #define BK_MAX_LB 11                   // key bits left inside a bucket (k_model's key -> row map)
 #define BK_LIMIT 16384                 // largest bucket one wave is allowed to walk
-#define BK_TB 14                       // log2(records per time bin): 48 bits of record + 14 bits of t fit the 8-byte slot, a bin fits LDS
+#ifndef BK_TB
+#define BK_TB 13                       // log2(records per time bin): 48 bits of record + the low bits of t fit the 8-byte slot; k_place holds a bin in LDS
+#endif                                 // (64 KB: with 14 bits and 128 KB a k_place workgroup needs a CU nearly to itself -- 1.5 ms alone, 6.9 ms next to three other instances)
 #define BK_BIN (1u << BK_TB)
-#define BK_MAX_BINS 256                // streams of up to 4 M symbols
+#define BK_MAX_BINS 512                // streams of up to 4 M symbols
 #define BK_HASH_MUL 0x9E3779B1u
 
 // the `bk` pool (u32): [0 .. NJ) fallback flag per job | fallback lists, one per launch group: count, then job ids |
