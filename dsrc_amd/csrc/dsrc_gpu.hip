@@ -117,6 +117,7 @@ struct dsrcgpu_handle
 	bool lds64_ordered = false;      // ... and k_lds_order_test64: the bucketed path (k_part / k_model) may run
 	u64 dec_table_budget = 0;        // dsrcgpu_set_table_budget: HBM a decoding pass may take for model tables (0 = automatic)
 	u32* dec_tables = nullptr; u64 dec_tables_cap = 0;     // model tables of the range-decoded levels (bytes), kept between passes
+	std::vector<DecHint> verify_hints;                     // run_batch -> verify_blocks: where the DNA stream of every block it wrote lies
 };
 
 namespace
@@ -882,6 +883,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		if (S.tag_bytes > (u64)desc[b].tag_cap * 4 || S.qua_bytes > (u64)desc[b].qua_cap * 4 || S.dna_bytes > (u64)desc[b].dna_cap * 4)
 			return fail(h, DSRCGPU_E_INPUT, "chunk %u: staging overflow (tag %u/%u qua %u/%u dna %u/%u)", b, S.tag_bytes, desc[b].tag_cap * 4, S.qua_bytes, desc[b].qua_cap * 4, S.dna_bytes, desc[b].dna_cap * 4);
 		desc[b].out_off = total;
+		if (h->set.verify_after_compress) { if (b == 0) h->verify_hints.resize(B); h->verify_hints[b] = DecHint{S.meta_bytes + S.tag_bytes + S.qua_bytes, S.d_total, desc[b].d_scheme, 0u}; }
 		const u64 sz = (u64)S.meta_bytes + S.tag_bytes + S.qua_bytes + S.dna_bytes;
 		io.out_offs[b] = total; io.out_sizes[b] = sz;
 		io.raw[4 * b + 0] = 0; io.raw[4 * b + 1] = S.raw_tag; io.raw[4 * b + 2] = S.raw_dna; io.raw[4 * b + 3] = S.raw_qua;
@@ -964,6 +966,7 @@ struct DecodeIO
 	u8* host_out; u64 host_cap;
 	u64* out_offs; u64* out_sizes;
 	u32* crc_ok;                     // optional, per block: 1 = the stored checksums match the decoded records
+	const DecHint* hints = nullptr;  // optional (verification of blocks just written): start and length of every block's DNA stream
 };
 
 // ---- model tables of the range-decoded levels (here DENSE: every row is reachable) ------------------------
@@ -1064,6 +1067,7 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 	}
 	const size_t o_desc = A.alloc(sizeof(DecDesc) * B), o_state = A.alloc(sizeof(DecState) * B);
 	const size_t o_qtabs = A.alloc(sizeof(DecTab) * B), o_dtabs = A.alloc(sizeof(DecTab) * B);
+	const size_t o_hints = A.alloc(sizeof(DecHint) * B);
 	if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (decode, phase 1)");
 	DecDesc* d_desc = AP<DecDesc>(h, o_desc); DecState* d_state = AP<DecState>(h, o_state);
 	HIPCHK(hipEventRecord(h->ev[0], s));
@@ -1167,21 +1171,63 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 		region_words = std::max<u64>(std::min<u64>(region_words, budget_words), biggest);
 		if (region_words) { const int rc = ensure_dec_tables(h, region_words * 4); if (rc) return rc; }
 		region_words = h->dec_tables_cap / 4;
-		auto fill_round = [&](const DecTab* d_tabs, const std::vector<DecTab>& tabs, const DecRound& r)
+		auto fill_round = [&](const DecTab* d_tabs, const std::vector<DecTab>& tabs, const DecRound& r, hipStream_t on)
 		{
 			u64 mx = 0;
 			for (u32 i = 0; i < r.count; ++i) mx = std::max(mx, tabs[r.first + i].words);
 			const u32 gx = (u32)std::max<u64>(1, std::min<u64>(1024, mx / 4 / (256 * 4)));
-			hipLaunchKernelGGL(k_dec_fill, dim3(gx, r.count), dim3(256), 0, s, h->dec_tables, d_tabs + r.first);
+			hipLaunchKernelGGL(k_dec_fill, dim3(gx, r.count), dim3(256), 0, on, h->dec_tables, d_tabs + r.first);
 		};
+		// Verification of blocks just written (io.hints): the DNA chains start at once, on the range-coder stream, next to the quality
+		// chains -- if the tables of both fit the region together (one round each); otherwise one stage after the other as for archives.
+		bool par = false;
+		std::vector<DecTab> ptabs; u32 p4 = 0;
+		if (io.hints && q_rc && d_rc && h->rc_stream)
+		{
+			u64 qsum = 0; for (const DecTab& t : qtabs) qsum += (t.words + 31) & ~31ull;
+			for (u32 pass = 0; pass < 2; ++pass)
+			{
+				for (u32 b = 0; b < B; ++b)
+					if (io.hints[b].d_scheme == pass) { DecTab t; t.block = b; t.off = 0; t.n = 0; t.words = d_table_words(prm.dna_order, pass); ptabs.push_back(t); }
+				if (pass == 0) p4 = (u32)ptabs.size();
+			}
+			u64 dsum = 0; for (const DecTab& t : ptabs) dsum += (t.words + 31) & ~31ull;
+			if (qsum + dsum <= budget_words && !ptabs.empty())
+			{
+				const int rc = ensure_dec_tables(h, (qsum + dsum) * 4);
+				if (rc) return rc;
+				region_words = h->dec_tables_cap / 4;
+				u64 top = qsum;
+				for (DecTab& t : ptabs) { t.off = top; top += (t.words + 31) & ~31ull; }
+				par = true;
+				DecTab* d_tabs = AP<DecTab>(h, o_dtabs); DecHint* d_hints = AP<DecHint>(h, o_hints);
+				HIPCHK(hipMemcpyAsync(d_hints, io.hints, sizeof(DecHint) * B, hipMemcpyHostToDevice, s));
+				HIPCHK(hipMemcpyAsync(d_tabs, ptabs.data(), sizeof(DecTab) * ptabs.size(), hipMemcpyHostToDevice, s));
+				hipLaunchKernelGGL(k_dec_hint, dim3((B + 63) / 64), dim3(64), 0, s, d_state, d_hints, B); KCHK();
+				HIPCHK(hipEventRecord(h->ev[2], s));
+				HIPCHK(hipStreamWaitEvent(h->rc_stream, h->ev[2], 0));
+				const DecRound r4{0, p4}, r8{p4, (u32)ptabs.size() - p4};
+				if (r4.count)
+				{
+					fill_round(d_tabs, ptabs, r4, h->rc_stream); KCHK();
+					hipLaunchKernelGGL(k_dec_dnarc<4>, dim3((r4.count + 63) / 64), dim3(64), 0, h->rc_stream, io.d_in, d_desc, d_state, d_tabs + r4.first, r4.count, AP<u8>(h, o_d), h->dec_tables, prm); KCHK();
+				}
+				if (r8.count)
+				{
+					fill_round(d_tabs, ptabs, r8, h->rc_stream); KCHK();
+					hipLaunchKernelGGL(k_dec_dnarc<8>, dim3((r8.count + 63) / 64), dim3(64), 0, h->rc_stream, io.d_in, d_desc, d_state, d_tabs + r8.first, r8.count, AP<u8>(h, o_d), h->dec_tables, prm); KCHK();
+				}
+				HIPCHK(hipEventRecord(h->ev[3], h->rc_stream));
+			}
+		}
 		if (q_rc)
 		{
-			const std::vector<DecRound> rounds = plan_rounds(qtabs, region_words);
+			const std::vector<DecRound> rounds = plan_rounds(qtabs, region_words);      // (with the DNA tables behind them: one round)
 			DecTab* d_tabs = AP<DecTab>(h, o_qtabs);
 			HIPCHK(hipMemcpyAsync(d_tabs, qtabs.data(), sizeof(DecTab) * qtabs.size(), hipMemcpyHostToDevice, s));
 			for (const DecRound& r : rounds)
 			{
-				fill_round(d_tabs, qtabs, r); KCHK();
+				fill_round(d_tabs, qtabs, r, s); KCHK();
 				// one launch per alphabet size the round contains
 				u32 sizes_present = 0;
 				for (u32 i = 0; i < r.count; ++i) sizes_present |= qtabs[r.first + i].n;          // 8, 16, 32, 64, 128: one bit each
@@ -1193,9 +1239,11 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 				if (sizes_present & 128u) { hipLaunchKernelGGL(k_dec_qrc<128>, dim3(r.count), dim3(64), 0, s, io.d_in, d_desc, d_state, tp, rp, d_out, h->dec_tables, prm); KCHK(); }
 			}
 		}
+		if (par) HIPCHK(hipStreamWaitEvent(s, h->ev[3], 0));
 		hipLaunchKernelGGL(k_dec_dhead, dim3((B + 63) / 64), dim3(64), 0, s, io.d_in, d_desc, d_state, prm); KCHK();
 		bool any_plain = !d_rc;
-		if (d_rc)
+		if (par) { for (u32 b = 0; b < B; ++b) if (io.hints[b].d_scheme == 255) any_plain = true; }
+		if (d_rc && !par)
 		{
 			HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(DecState) * B, hipMemcpyDeviceToHost, s));
 			HIPCHK(hipStreamSynchronize(s));
@@ -1227,13 +1275,13 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 			if (!dtabs.empty()) HIPCHK(hipMemcpyAsync(d_tabs, dtabs.data(), sizeof(DecTab) * dtabs.size(), hipMemcpyHostToDevice, s));
 			for (const DecRound& r : r4)
 			{
-				fill_round(d_tabs, dtabs, r); KCHK();
+				fill_round(d_tabs, dtabs, r, s); KCHK();
 				hipLaunchKernelGGL(k_dec_dnarc<4>, dim3((r.count + 63) / 64), dim3(64), 0, s, io.d_in, d_desc, d_state, d_tabs + r.first, r.count, AP<u8>(h, o_d), h->dec_tables, prm); KCHK();
 			}
 			for (const DecRound& r8r : r8)
 			{
 				const DecRound r{r8r.first + n4, r8r.count};
-				fill_round(d_tabs, dtabs, r); KCHK();
+				fill_round(d_tabs, dtabs, r, s); KCHK();
 				hipLaunchKernelGGL(k_dec_dnarc<8>, dim3((r.count + 63) / 64), dim3(64), 0, s, io.d_in, d_desc, d_state, d_tabs + r.first, r.count, AP<u8>(h, o_d), h->dec_tables, prm); KCHK();
 			}
 		}
@@ -1290,6 +1338,7 @@ int verify_blocks(dsrcgpu_handle* h, u32 n, const u64* offs, const u64* sizes)
 {
 	std::vector<u64> to(n), ts(n); std::vector<u32> ok(n, 0);
 	DecodeIO io{h->last_d_out, offs, sizes, n, nullptr, nullptr, 0, nullptr, 0, to.data(), ts.data(), ok.data()};
+	if (h->verify_hints.size() == n && !getenv("DSRC_GPU_VERIFY_SERIAL")) io.hints = h->verify_hints.data();
 	// dsrcgpu_last_timing keeps reporting the compression batch: the verifying pass has its own figure
 	const float c_batch = h->batch_ms, c_rc = h->rc_ms; const u32 c_launches = h->rc_launches;
 	const int rc = run_decode(h, io);

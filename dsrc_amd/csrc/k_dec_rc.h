@@ -465,6 +465,16 @@ __global__ void __launch_bounds__(64) k_dec_qrc(const u8* in, const DecDesc* des
 	}
 }
 
+// ---- verification of blocks this library has just written: where the DNA stream starts and how many symbols it holds is known
+// from the compressing pass, so its chain need not wait for the quality chain to find out (run_decode launches both at once).
+struct DecHint { u32 dna_pos, d_total, d_scheme, pad; };
+__global__ void __launch_bounds__(64) k_dec_hint(DecState* st, const DecHint* hint, u32 n_blocks)
+{
+	const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b >= n_blocks) return;
+	st[b].dna_pos = hint[b].dna_pos; st[b].d_total = hint[b].d_total; st[b].d_scheme = hint[b].d_scheme;
+}
+
 // ---- the scheme byte of the DNA stream (IDnaModelerProxy::Decode, src/DnaModelerProxy.h:61-71): thread per block --------------
 __global__ void __launch_bounds__(64) k_dec_dhead(const u8* in, const DecDesc* desc, DecState* st, DecParams prm)
 {

@@ -70,3 +70,21 @@ def test_switches(emu, oracle, env, monkeypatch):
     check(emu, oracle, data, [(3, 2, False), (2, 1, True)])
     tiny = synth.illumina_fastq(30)[:-1]
     check(emu, oracle, tiny, [(3, 2, False)])
+
+
+def test_verify_decodes_both_chains_at_once(emu, oracle, monkeypatch):
+    """verify_after_compress with the wave decoders: the compressing pass knows where every block's DNA stream starts and how many
+    symbols it holds, so k_dec_dnarc runs next to k_dec_qrc instead of behind it (DecHint); DSRC_GPU_VERIFY_SERIAL=1 keeps the order
+    archives need.  Same verdicts either way, 4- and 8-symbol DNA models, blocks without a DNA stream among the others."""
+    good = synth.illumina_fastq(50)[:-1]
+    iup = alphabet_fastq(20, n_rec=50, L=60, iupac=True)
+    no_dna = b"\n".join(b"@n.%d\nNNNNNNNN\n+\n########" % i for i in range(30))
+    for serial in (False, True):
+        if serial:
+            monkeypatch.setenv("DSRC_GPU_VERIFY_SERIAL", "1")
+        for d, q in ((3, 2), (1, 1)):
+            cfg = Config.from_levels(d, q, False, True)
+            h = emu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, True, verify=True)
+            got = h.compress_batch([good, iup, no_dna, good])
+            h.close()
+            assert got[1][0] == oracle.compress_block(cfg, iup)[0]
