@@ -805,8 +805,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 		std::vector<uint64> mapAt(batches.size(), 0);
 		std::vector<std::vector<uint64_t> > mapCaps(batches.size());
 		std::vector<std::thread> faulters;
-		std::atomic<bool> mapBroken(false), reserveFailed(false);
-		std::atomic<int> reservePending(0);
+		std::atomic<bool> mapBroken(false);
 		struct MapGuard          // whatever way this scope is left: helper threads joined, mapping gone
 		{
 			std::vector<std::thread>& th; uchar*& p; uint64& n;
@@ -838,29 +837,18 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 					mapAt[k] = total;
 					for (uint64 i = batches[k].first; i < batches[k].second; ++i) { mapCaps[k].push_back((uint64)words[i] + 1); total += (uint64)words[i] + 1; }
 				}
-				// The space is reserved, not just declared: a full disk shows as a failed fallocate (and the buffered path reports it)
-				// instead of as a SIGBUS in the middle of a copy into the mapping; a file system without fallocate takes the buffered
-				// path as well.  Reserving 16 GB of tmpfs takes 0.65 s (it zeroes the pages, under the inode's lock), so the helper
-				// threads do it piece by piece while the devices come up and the archive is read; no worker touches the mapping
-				// before they are through (reservePending).
-				if (total && ftruncate(fileno(out), (off_t)total) == 0)
+				// the space is reserved, not just declared: a full disk shows here (and the buffered path reports it) instead of as a
+				// SIGBUS in the middle of a copy into the mapping; a file system without fallocate takes the buffered path as well
+				if (total && fallocate(fileno(out), 0, 0, (off_t)total) == 0)
 				{
 					void* q = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fileno(out), 0);
 					if (q != MAP_FAILED)
 					{
 						map = (uchar*)q; mapBytes = total;
-						const int fd = fileno(out);
-						auto fault = [&, total, fd](uint32 t, uint32 nt)
-						{	// 64 MiB pieces, in file order, round-robin over the threads: reserved, then mapped
+						auto fault = [&, total](uint32 t, uint32 nt)
+						{	// 64 MiB pieces, in file order, round-robin over the threads
 							const uint64 piece = 64ull << 20;
-							for (uint64 o = (uint64)t * piece; o < total && !reserveFailed; o += (uint64)nt * piece)
-								if (fallocate(fd, 0, (off_t)o, (off_t)std::min<uint64>(piece, total - o)) != 0)
-								{
-									if (getenv("DSRC_HOST_TRACE")) fprintf(stderr, "[dsrc-amd d] fallocate at %llu: %s\n", (unsigned long long)o, strerror(errno));
-									reserveFailed = true;
-								}
-							--reservePending;
-							for (uint64 o = (uint64)t * piece; o < total && !reserveFailed; o += (uint64)nt * piece)
+							for (uint64 o = (uint64)t * piece; o < total; o += (uint64)nt * piece)
 							{
 								const uint64 len = std::min<uint64>(piece, total - o);
 #ifdef MADV_POPULATE_WRITE
@@ -869,7 +857,6 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 								for (uint64 x = 0; x < len; x += 4096) (void)((volatile const uchar*)map)[o + x];      // a read: the decoded bytes may be there already
 							}
 						};
-						reservePending = 6;
 						for (uint32 t = 0; t < 6; ++t) faulters.emplace_back(fault, t, 6u);
 					}
 					else if (ftruncate(fileno(out), 0) != 0) throw DsrcException("Error writing FASTQ output");
@@ -943,13 +930,6 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 					}
 					mark(idx, k, "read");
 					int rc = DSRCGPU_OK;
-					while (map && reservePending.load() > 0) std::this_thread::sleep_for(std::chrono::milliseconds(1));
-					if (map && reserveFailed && !mapBroken)
-					{	// no room for the text (or no fallocate on this file system): once more the buffered way, which says so
-						std::lock_guard<std::mutex> g(m);
-						mapBroken = true; cv.notify_all();
-						throw DsrcException("__remap__");
-					}
 					if (map && !mapBroken)
 					{
 						uint64 cap = 0; for (uint64 c : mapCaps[k]) cap += c;
@@ -1053,7 +1033,6 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 		mark(0, batches.size(), "all decoded");
 		for (auto& t : faulters) t.join();
 		faulters.clear();
-		mark(0, batches.size(), "leaving");
 		if (args.exitWhenDone && error.empty() && !mapBroken && regular)
 		{	// the text is in the page cache (through the mapping or pwrite); unmapping, closing and the HIP teardown are the
 			// kernel's job at exit, where nobody waits for them one after the other
