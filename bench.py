@@ -34,9 +34,9 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 RECS_PER_BLOCK = 22300
 PMC_RC_BYTES_PER_BLOCK = (13.3515e6 * 2 + 13.3427e6) * 1024 / 512   # measured, see roofline.traffic below
 # round 4 (profiles/r04_pmc_b512_p1_bucket.txt, KiB per 512-block batch): k_part, eight launches; k_binoff + k_model<32> + k_model<4> + k_place
-PMC_PART_BYTES_PER_BLOCK = (3.4165e6 * 2 + 51.2090e6) * 1024 / 512
-PMC_MODEL_BYTES_PER_BLOCK = ((0.4188e6 + 7.5565e6 + 7.5460e6 + 13.3499e6) * 2 + 0.4178e6 + 15.9316e6 + 15.3738e6 + 26.6939e6) * 1024 / 512
-PMC_ALL_BYTES_PER_BLOCK = 290.0e6 * 1024 / 512      # every compression kernel of the batch: 580 MB per block = 52 x the algorithmic 11.06 MB (round 2: 69 x)
+PMC_PART_BYTES_PER_BLOCK = (3.412e6 * 2 + 51.225e6) * 1024 / 512
+PMC_MODEL_BYTES_PER_BLOCK = ((0.419e6 + 8.402e6 + 8.409e6 + 13.355e6) * 2 + 0.835e6 + 18.470e6 + 17.586e6 + 26.691e6) * 1024 / 512
+PMC_ALL_BYTES_PER_BLOCK = 291.8e6 * 1024 / 512      # every compression kernel of the batch: 584 MB per block = 53 x the algorithmic 11.06 MB (round 2: 69 x)
 DECODE_TRAFFIC_PER_BLOCK = 663e6  # HBM bytes per decoded block at -d3 -q2: (FETCH_SIZE + WRITE_SIZE of k_dec_qrc and k_dec_dnarc) x 1 KiB / 2400 blocks (profiles/r03_pmc_decode_b2400.txt)
 MAX_RESIDENT = 3                  # distinct input shards kept in HBM per scheduler instance (2 when N > 1: rank 0 also holds the gathered streams)
 
@@ -640,7 +640,7 @@ def main():
                 "model_traffic": int(PMC_MODEL_BYTES_PER_BLOCK * sub_blocks), "all_kernels_traffic": int(PMC_ALL_BYTES_PER_BLOCK * sub_blocks),
                 "note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE of the k_part launches of a 512-block batch / 512 (profiles/r04_pmc_b512_p1_bucket.txt); "
                         "model_ms / model_traffic = k_binoff + k_model (adaptive counter rows in LDS, one wave per bucket) + k_place (time bins into stream order) of the same sub-batch; "
-                        "all_kernels_traffic: every compression kernel, 52 x the algorithmic bytes (round 2, with the two-pass sort and the scattering replay: 69 x)"}
+                        "all_kernels_traffic: every compression kernel, 53 x the algorithmic bytes (round 2, with the two-pass sort and the scattering replay: 69 x)"}
         decode_line = None
         if args.decode_blocks > 0 and world == 1:
             decode_line = measure_decode(lanes, cfg, args.decode_blocks, total_steps - 1)
