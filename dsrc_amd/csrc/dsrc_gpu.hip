@@ -582,6 +582,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	// elements per bucket the bucket digit aims at (a wave walks its bucket serially; longer buckets give longer runs per time bin)
 	const u64 bk_elems_dna = getenv("DSRC_GPU_BUCKET_ELEMS_DNA") ? (u64)atol(getenv("DSRC_GPU_BUCKET_ELEMS_DNA")) : 4096u;      // 512 buckets of 6.5 k bases: 512 rows of 8 bytes per wave, runs of 16 records per time bin
 	const u64 bk_elems_qua = getenv("DSRC_GPU_BUCKET_ELEMS_QUA") ? (u64)atol(getenv("DSRC_GPU_BUCKET_ELEMS_QUA")) : 2048u;
+	const u32 bk_limit = getenv("DSRC_GPU_BUCKET_LIMIT") ? (u32)atol(getenv("DSRC_GPU_BUCKET_LIMIT")) : (u32)BK_LIMIT;      // tests
 	const bool use_bk = bk_enabled && NJ > 0 && h->lds64_ordered;      // k_model stands on the LDS applying atomics in lane order (k_lds_order_test)
 	size_t o_bk = 0, bk_zero_words = 0, o_bcnt = 0;
 	static_assert(BK_BIN % (SORT_WG * SORT_ITEMS) == 0, "a time bin is a whole number of k_part tiles");
@@ -612,6 +613,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			if (j.key_bits > BK_MAX_LB) hb = std::max(hb, j.key_bits - BK_MAX_LB);
 			j.bk_hb = hb; j.bk_lb = j.key_bits - hb;
 			j.bk_mul = BK_HASH_MUL; j.bk_kmask = (u32)((1ull << j.key_bits) - 1ull);
+			j.bk_limit = bk_limit;
 		}
 		bk_zero_words = cur;
 		for (u32 i = 0; i < NJ; ++i) { jobs[i].bk_boff = cur; cur += jobs[i].bk_on ? (1u << jobs[i].bk_hb) + 1u : 0u; }

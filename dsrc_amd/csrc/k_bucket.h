@@ -18,16 +18,16 @@
 // 8 + 16 + 8 B in runs plus one 32-byte sector per record before -- and no sort of the bucket at all: the second LSD pass, the
 // segmented-scan replay and its seams are replaced by log2(N) LDS atomics per symbol.
 //
-// A wave walks its bucket serially, so a bucket must stay small: a stream with a bucket beyond BK_LIMIT elements (a context that
-// holds a large share of the stream: four-level qualities, poly-A reads), or with more contexts in one bucket than the wave has
-// rows, is handed to k_sort / k_replay_seams / k_replay, whose range-splitting replay is made for exactly that: k_part / k_model
-// append it to the fallback list of its launch group.  Either way the records k_rc reads are the same.
+// A wave walks its bucket serially, so a bucket must not grow without bound: a stream with a bucket beyond BK_LIMIT elements (a
+// context that holds a sixth of a 3 M-symbol stream or more), or with more contexts in one bucket than the wave has rows, is handed
+// to k_sort / k_replay_seams / k_replay, whose range-splitting replay is made for exactly that: k_part / k_model append it to
+// the fallback list of its launch group.  Either way the records k_rc reads are the same.
 #pragma once
 #include "k_rc.h"
 
 #define BK_MAX_HB 10                   // bucket digit: <= 1024 buckets (k_part's LDS is k_sort's)
 #define BK_MAX_LB 11                   // key bits left inside a bucket (k_model's key -> row map)
-#define BK_LIMIT 16384                 // largest bucket one wave is allowed to walk
+#define BK_LIMIT 524288                // largest bucket one wave is allowed to walk (8 K windows, a few ms)
 #ifndef BK_TB
 #define BK_TB 13                       // log2(records per time bin): 48 bits of record + the low bits of t fit the 8-byte slot; k_place holds a bin in LDS
 #endif                                 // (64 KB: with 14 bits and 128 KB a k_place workgroup needs a CU nearly to itself -- 1.5 ms alone, 6.9 ms next to three other instances)
@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 	}
 	for (u32 i = threadIdx.x; i < SORT_WAVES * SORT_MAX_BINS; i += blockDim.x) (&s_cnt[0][0])[i] = 0;
 	__syncthreads();
-	if (s_max > BK_LIMIT) { if (threadIdx.x == 0) bk_fallback(j, bk); return; }
+	if (s_max > j.bk_limit) { if (threadIdx.x == 0) bk_fallback(j, bk); return; }
 
 	u64* dst = pool + j.elems;
 	const u32 shift = ELEM_CTX_SHIFT + lb;
@@ -322,9 +322,9 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 // below s's own at every level, freq = its own field at the last level (2-bit bases: one atomic per symbol, 32 quality values: three).
 // The LDS applies the lanes of one atomic instruction that meet in a word in lane order (k_lds_order_test / k_lds_order_test64
 // measure exactly that before this path is ever used), and a wave's instructions in program order: lane order is stream order.
-// Rescale() (a row's total reaches 2^16 - 2N, src/SymbolCoderRC.h:67-90) cannot happen here: a bucket holds at most BK_LIMIT
-// symbols, so no row's total gets past N + 2 * BK_LIMIT (streams with larger buckets take the k_sort / k_replay path, which
-// replays epochs).
+// Rescale() (a row's total reaches 2^16 - 2N, src/SymbolCoderRC.h:67-90) needs the exact serial order: in buckets large enough
+// for it (> 32 K symbols) a window in which some lane's row could get there is coded one element at a time, and the lane whose row
+// is due halves its counters and rebuilds the sums first.
 // The records leave grouped by time bin: the elements of a bin are consecutive (the bucket is in stream order) and go, as a run,
 // to the place k_binoff worked out for this bucket inside the bin's region of the record array.
 #define MD_WG 256
@@ -352,6 +352,56 @@ template <int N> __device__ __forceinline__ u32 md_init_word(u32 x)
 	const u32 l = w >= 5 ? 2u : w >= 1 ? 1u : 0u;
 	const u32 v = (u32)N >> (2 * (l + 1));
 	return v | (v << 16);
+}
+
+// the row's total (the root's four fields)
+template <int N> __device__ __forceinline__ u32 md_total(const u32* row)
+{
+	const u64 v = *(const unsigned long long*)row;
+	return ((u32)v & 0xFFFFu) + ((u32)v >> 16) + ((u32)(v >> 32) & 0xFFFFu) + (u32)(v >> 48);
+}
+
+// TSymbolCoderRC::Rescale (src/SymbolCoderRC.h:80-90): every counter x becomes x - (x >> 1); the sums above them are rebuilt.
+// One lane, rarely (a context needs ~32 K symbols to get here).
+template <int N> __device__ __forceinline__ void md_rescale(u32* row)
+{
+	typedef MdRow<N> G;
+	unsigned long long* r64 = (unsigned long long*)row;
+	if (G::R2)
+		for (u32 x = 0; x < (u32)N / 2; ++x)
+		{
+			const u32 v = row[2 * G::W64 + x];
+			u32 a = v & 0xFFFFu, b = v >> 16;
+			a -= a >> 1; b -= b >> 1;
+			row[2 * G::W64 + x] = a | (b << 16);
+		}
+	for (int l = G::L4 - 1; l >= 0; --l)
+	{
+		const u32 base = ((1u << (2 * l)) - 1u) / 3u, nw = 1u << (2 * l);
+		for (u32 w = 0; w < nw; ++w)
+		{
+			u64 v = 0;
+			if (!G::R2 && l == G::L4 - 1)
+			{	// the fields are the counters themselves
+				const u64 o = r64[base + w];
+#pragma unroll
+				for (u32 q = 0; q < 4; ++q) { u32 x = (u32)(o >> (16 * q)) & 0xFFFFu; x -= x >> 1; v |= (u64)x << (16 * q); }
+			}
+			else
+			{
+#pragma unroll
+				for (u32 q = 0; q < 4; ++q)
+				{
+					const u32 c = 4 * w + q;
+					u32 sum;
+					if (l == G::L4 - 1) { const u32 p = row[2 * G::W64 + c]; sum = (p & 0xFFFFu) + (p >> 16); }
+					else { const u64 o = r64[((1u << (2 * (l + 1))) - 1u) / 3u + c]; sum = ((u32)o & 0xFFFFu) + ((u32)o >> 16) + ((u32)(o >> 32) & 0xFFFFu) + (u32)(o >> 48); }
+					v |= (u64)sum << (16 * q);
+				}
+			}
+			r64[base + w] = v;
+		}
+	}
 }
 
 // one symbol on its row: returns freq | cum << 16 | total << 32
@@ -443,7 +493,7 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 	__shared__ map_t s_map[MD_WAVES][1 << MAPBITS];
 	__shared__ unsigned long long s_rows[MD_WAVES][ROW_BYTES / 8];
 	__shared__ u16 s_off[MD_WAVES][BK_MAX_BINS];
-	static_assert(N + 2 * BK_LIMIT < (1 << 16) - 2 * N, "a row of a bucket must stay below the rescale threshold");
+	constexpr u32 limit = (1u << 16) - 2u * N;              // MaxAccumulatedValue (src/SymbolCoderRC.h:67): Rescale() before a symbol is coded on a row that has reached it
 	const CtxJob j = jobs[blockIdx.y];
 	const u32 w = wave_id(), lane = lane_id();
 	const u32 bucket = blockIdx.x * MD_WAVES + w;
@@ -454,6 +504,7 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 	RcPack* recs = rec_pool + j.trip;
 	const u32 keys = 1u << j.bk_lb, kmask = keys - 1u;
 	const bool binned = j.bk_binned != 0;
+	const bool may_rescale = (u32)N + 2u * nb + 128u >= (1u << 16) - 2u * N;
 	map_t* map = s_map[w]; u32* rows = (u32*)s_rows[w]; u16* off = s_off[w];
 	const u32 n_bins = (j.n + BK_BIN - 1) >> BK_TB;
 
@@ -504,7 +555,24 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 			}
 		}
 		u64 rec = 0;
-		if (valid) rec = md_code<N>(rows + rid * STRIDE, sym);
+		u32* row = rows + rid * STRIDE;
+		// Only a bucket with > 32 K symbols can bring a row to its rescale point.  There, a window in which some lane's row could get
+		// that far (64 symbols add 128) is coded one element at a time, and the lane whose row is due halves it first.
+		const bool near = may_rescale && valid && md_total<N>(row) + 128u >= limit;
+		if (may_rescale && __ballot(near))
+		{
+			const u64 vm = __ballot(valid);
+			for (u32 l = 0; l < 64 && ((vm >> l) & 1ull); ++l)
+			{
+				if (lane == l)
+				{
+					if (md_total<N>(row) >= limit) md_rescale<N>(row);
+					rec = md_code<N>(row, sym);
+				}
+				wave_fence();
+			}
+		}
+		else if (valid) rec = md_code<N>(row, sym);
 #ifdef DSRC_EMU_BUILD
 		(void)__ballot(true);                                         // the emulator runs lanes one after the other: keep them in step per window
 #endif

@@ -57,7 +57,8 @@ struct CtxJob     // one (block, stream)
 	u32 bk_boff;        // bk index of the stream's 2^bk_hb + 1 bucket offsets
 	u32 bk_fb;          // bk index of the fallback list of the stream's launch group: count, then job ids
 	u32 bk_cnt;         // index (u16 units) of the stream's per-tile bucket counts / per-bin bucket offsets (k_part, k_binoff)
-	u32 pad0, pad1;
+	u32 bk_limit;       // largest bucket a wave of k_model may walk (BK_LIMIT; tests lower it)
+	u32 pad1;
 };
 
 typedef u64 __attribute__((aligned(1))) u64_unaligned;

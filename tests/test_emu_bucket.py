@@ -45,17 +45,40 @@ def test_model_runs_out_of_rows(emu, oracle, capfd, monkeypatch):
     assert "2 of 2 streams tried, 1 handed back" in err, err
 
 
-def test_bucket_too_large_for_a_wave(emu, oracle, capfd, monkeypatch):
-    """A context that holds most of a stream: one bucket is beyond BK_LIMIT, k_part hands the stream back before partitioning."""
-    monkeypatch.setenv("DSRC_GPU_DEBUG", "1")
-    rng = random.Random(3)
+def _hot(n_rec, seed=3):
+    rng = random.Random(seed)
     recs = []
-    for i in range(300):
+    for i in range(n_rec):
         seq = "".join(rng.choice("AAAAAAAAAAAAAAAC") for _ in range(200))
         q = "".join("I" if rng.random() < 0.98 else "H" for _ in range(200))
         recs.append(f"@r.{i}\n{seq}\n+\n{q}")
-    data = "\n".join(recs).encode()
-    check(emu, oracle, data, [(1, 1, False)])
+    return "\n".join(recs).encode()
+
+
+def test_hot_contexts_rescale_inside_the_bucket(emu, oracle, capfd, monkeypatch):
+    """Contexts with 40-60 k symbols (several Rescale() calls each) stay on the bucketed path: in buckets that large k_model codes the
+    windows in which a row could reach its rescale point one element at a time, the lane whose row is due halves it first (md_rescale);
+    4-, 8- and 16-symbol rows, one and two radix-4 levels, with and without the pair level."""
+    monkeypatch.setenv("DSRC_GPU_DEBUG", "1")
+    data = _hot(300)
+    check(emu, oracle, data, [(1, 1, False), (3, 2, False), (2, 1, True)])
+    err = capfd.readouterr().err
+    assert err.count("2 of 2 streams tried, 0 handed back") == 3, err
+    # a 64-symbol alphabet whose hot context rescales
+    rng = random.Random(9)
+    vals = list(range(2, 42))
+    recs = []
+    for i in range(260):
+        q = bytes(33 + (vals[rng.randrange(40)] if rng.random() < 0.03 else 40) for _ in range(200))
+        recs.append(b"@q.%d\n" % i + bytes(rng.choice(b"ACGT") for _ in range(200)) + b"\n+\n" + q)
+    check(emu, oracle, b"\n".join(recs), [(2, 2, False), (1, 1, False)])
+
+
+def test_bucket_too_large_for_a_wave(emu, oracle, capfd, monkeypatch):
+    """A bucket beyond the limit a wave may walk (BK_LIMIT; lowered here): k_part hands the stream back before partitioning."""
+    monkeypatch.setenv("DSRC_GPU_DEBUG", "1")
+    monkeypatch.setenv("DSRC_GPU_BUCKET_LIMIT", "16384")
+    check(emu, oracle, _hot(300), [(1, 1, False)])
     assert "2 of 2 streams tried, 1 handed back" in capfd.readouterr().err       # the DNA stream (64 contexts, one of them with most symbols)
 
 

@@ -341,19 +341,20 @@ def test_bucketed_path_alphabet_sizes(gpu, oracle, n_sym):
 
 def test_bucketed_path_hand_backs_and_switches(gpu, oracle, monkeypatch, capfd):
     """Streams the bucketed path hands back to k_sort / k_replay inside a batch of streams it keeps: independent uniform qualities
-    (k_model runs out of counter rows), a context with most of a stream's symbols (k_part finds a bucket too large for one wave);
+    (k_model runs out of counter rows), a context with most of a 4 M-symbol stream (k_part finds a bucket too large for one wave);
     then the same batch with the path off, with k_model scattering to stream order itself, with k_part storing from registers."""
     import random
     from tests.cases import alphabet_fastq
     rng = random.Random(3)
     hot = "\n".join("@r.%d\n%s\n+\n%s" % (i, "".join(rng.choice("AAAAAAAAAAAAAAAC") for _ in range(200)),
-                                            "".join("I" if rng.random() < 0.98 else "H" for _ in range(200))) for i in range(3000)).encode()
+                                            "".join("I" if rng.random() < 0.98 else "H" for _ in range(200))) for i in range(20000)).encode()
     chunks = [synth.illumina_fastq(6000)[:-1], alphabet_fastq(30, n_rec=6000, L=100, spread=True), hot, synth.illumina_fastq(6000, first=7001)[:-1]]
     cfg = Config.from_levels(3, 2)
     monkeypatch.setenv("DSRC_GPU_DEBUG", "1")
     _check(gpu, oracle, cfg, chunks)
     err = capfd.readouterr().err
-    assert "8 of 8 streams tried, 3 handed back" in err, err          # the spread qualities, the hot block's qualities and bases
+    assert "8 of 8 streams tried, 2 handed back" in err, err          # the spread qualities (rows) and the hot block's bases (a bucket > BK_LIMIT); its qualities
+                                                                      # (contexts of ~470 k symbols, fourteen rescales each) stay in their buckets
     for env in ({"DSRC_GPU_BUCKETS": "0"}, {"DSRC_GPU_BUCKETS_BINNED": "0"}, {"DSRC_GPU_PART_STAGE": "0"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
