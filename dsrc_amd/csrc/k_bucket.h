@@ -23,6 +23,7 @@
 // to k_sort / k_replay_seams / k_replay, whose range-splitting replay is made for exactly that: k_part / k_model append it to
 // the fallback list of its launch group.  Either way the records k_rc reads are the same.
 #pragma once
+#include <type_traits>
 #include "k_rc.h"
 
 #define BK_MAX_HB 10                   // bucket digit: <= 1024 buckets (k_part's LDS is k_sort's)
@@ -522,6 +523,10 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 	// previous window ended in and how many of its records are out.
 	u32 carry_bin = 0xFFFFFFFFu, carry_cnt = 0;
 	u32 n_rows = 0;
+	// the walk in two instantiations: the rescale test costs registers and instructions that only buckets of > 32 K symbols need
+	auto walk = [&](auto resc_tag)
+	{
+	constexpr bool RESC = decltype(resc_tag)::value;
 	for (u32 p = 0; p < nb; p += 64)
 	{
 		const u64 el = elq[0];
@@ -558,8 +563,8 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 		u32* row = rows + rid * STRIDE;
 		// Only a bucket with > 32 K symbols can bring a row to its rescale point.  There, a window in which some lane's row could get
 		// that far (64 symbols add 128) is coded one element at a time, and the lane whose row is due halves it first.
-		const bool near = may_rescale && valid && md_total<N>(row) + 128u >= limit;
-		if (may_rescale && __ballot(near))
+		const bool near = RESC && valid && md_total<N>(row) + 128u >= limit;
+		if (RESC && __ballot(near))
 		{
 			const u64 vm = __ballot(valid);
 			for (u32 l = 0; l < 64 && ((vm >> l) & 1ull); ++l)
@@ -591,6 +596,8 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 		for (u32 k = 0; k + 1 < MD_AHEAD; ++k) elq[k] = elq[k + 1];
 		elq[MD_AHEAD - 1] = el_new;
 	}
+	};
+	if (may_rescale) walk(std::true_type()); else walk(std::false_type());
 }
 
 // ---- k_place: a time bin's records into stream order, in place ------------------------------------------------------------------------
