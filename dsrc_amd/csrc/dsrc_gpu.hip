@@ -741,8 +741,8 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			if (use_bk)
 			{	// k_bucket.h: partition, finish in LDS, place -- and behind them k_sort / k_replay for the streams k_part handed back
 				const bool part_stage = !(getenv("DSRC_GPU_PART_STAGE") && atoi(getenv("DSRC_GPU_PART_STAGE")) == 0);
-				if (part_stage) hipLaunchKernelGGL((k_part<true, true>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk, d_bcnt);
-				else hipLaunchKernelGGL((k_part<true, false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk, d_bcnt);
+				if (part_stage) hipLaunchKernelGGL((k_part<true>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk, d_bcnt);
+				else hipLaunchKernelGGL((k_part<false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk, d_bcnt);
 				KCHK();
 				stage_mark(0); stage_mark(1);
 				u32 slice_bins = 0;

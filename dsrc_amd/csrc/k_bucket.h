@@ -37,7 +37,8 @@
 #define BK_HASH_MUL 0x9E3779B1u
 
 // the `bk` pool (u32): [0 .. NJ) fallback flag per job | fallback lists, one per launch group: count, then job ids |
-// bin fill counters | bucket offsets (2^hb + 1 per job).  Everything up to the bucket offsets is zeroed per batch.
+// bucket offsets (2^hb + 1 per job).  Everything up to the bucket offsets is zeroed per batch.  `bcnt` (u16): per job and tile the
+// elements per bucket (k_part), turned by k_binoff into every bucket's offset inside the time bin's region, in the bin's first row.
 
 __device__ __forceinline__ u64 bk_rekey(const CtxJob& j, u64 el)
 {
@@ -110,10 +111,10 @@ __device__ __forceinline__ void bk_elems8_qua(const CtxJob& j, const BkWin& w, c
 }
 
 // ---- k_part: stable partition by the top digit of the mixed key ------------------------------------------------------------------
-// One workgroup per stream, tiles of SORT_WG * SORT_ITEMS elements, ranking as in k_sort (one LDS atomic per element on the
-// wave's packed counter pair, or ballots where the device failed k_lds_order_test).
+// One workgroup per stream, tiles of SORT_WG * SORT_ITEMS elements, ranking as in k_sort<.., true>: one LDS atomic per element on
+// the wave's packed counter pair (the path is only taken on devices that passed k_lds_order_test).
 // STAGE: the tile leaves through LDS in bucket order (whole runs per store instruction, 64 KB more LDS) or straight from the registers.
-template <bool ATOMIC, bool STAGE>
+template <bool STAGE>
 __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SORT_OCC, SORT_OCC))) k_part(const CtxJob* jobs, u64* pool, const u8* d_stream, const u8* q_stream, const u8* qp_stream, BlkState* st, u32* bk, u16* bcnt)
 {
 	__shared__ u32 s_base[SORT_MAX_BINS];
@@ -229,29 +230,13 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 			const u32 i = wbase + k * 64 + lane;
 			const bool valid = i < n;
 			const u32 d = (u32)(el[k] >> shift);
-			if (ATOMIC)
-			{
-				const u32 sh = (d & 1u) * 16u;
-				u32 old = 0;
-				if (valid) old = atomicAdd(&((u32*)s_cnt[wv])[d >> 1], 1u << sh);
-				rk[k] = (old >> sh) & 0xFFFFu;
+			const u32 sh = (d & 1u) * 16u;
+			u32 old = 0;
+			if (valid) old = atomicAdd(&((u32*)s_cnt[wv])[d >> 1], 1u << sh);
+			rk[k] = (old >> sh) & 0xFFFFu;
 #ifdef DSRC_EMU_BUILD
-				(void)__ballot(true);                                     // the emulator runs lanes one after the other: keep them in step per k
+			(void)__ballot(true);                                     // the emulator runs lanes one after the other: keep them in step per k
 #endif
-				continue;
-			}
-			u64 peers = __ballot(valid);
-#pragma unroll
-			for (u32 b = 0; b < SORT_DIGIT_BITS; ++b)
-			{
-				const u64 m = __ballot((d >> b) & 1u);
-				peers &= ((d >> b) & 1u) ? m : ~m;
-			}
-			const u32 before = valid ? s_cnt[wv][d] : 0;
-			const u32 r = (u32)__popcll(peers & lanemask_lt());
-			rk[k] = before + r;
-			const u64 sync = __ballot(true);
-			if (valid && r == 0 && sync) s_cnt[wv][d] = (u16)(before + (u32)__popcll(peers));
 		}
 		__syncthreads();
 		for (u32 d0 = 0, carry = 0; d0 < bins; d0 += SORT_WG)
