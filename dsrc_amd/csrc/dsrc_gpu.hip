@@ -70,6 +70,8 @@ struct QBatch
 	std::vector<u64> o_offs, o_sizes, raw, comp;
 	u32 next_collect = 0, outstanding = 0;
 	int rc = 0; std::string err;
+	uint64_t seq = 0;                // flush order: the batch's turn in the handle's internal chain (two lanes)
+	std::vector<u32> layout;         // dsrcgpu_set_record_layout at the time of the flush: it belongs to this batch, whichever lane runs it
 };
 #define DSRC_QUEUE_DEPTH 3
 
@@ -106,6 +108,10 @@ struct dsrcgpu_handle
 	std::deque<u32> q_run;
 	std::mutex q_m; std::condition_variable q_cv;
 	std::thread q_thread; bool q_stop = false, q_started = false;
+	// Queue form, second lane: consecutive batches run on two scheduler lanes (this handle and `twin`, a handle of the same settings
+	// with its own arena and streams), so that the range coder of batch i -- 130 ms on a handful of CUs -- overlaps the copies and the
+	// front end of batch i + 1.  What DSRC carries from block to block goes from lane to lane through `q_chain`, in flush order.
+	dsrcgpu_handle* twin = nullptr; dsrcgpu_chain* q_chain = nullptr; std::thread q_thread2; uint64_t q_seq = 0; bool q_lanes_decided = false;
 	int q_rc = 0; std::string q_err;                                 // first failure of the scheduler thread (sticky)
 	float batch_ms = 0.f, rc_ms = 0.f, verify_ms = 0.f;
 	u32 rc_launches = 0;
@@ -1467,7 +1473,10 @@ void dsrcgpu_destroy(dsrcgpu_handle* h)
 	{
 		{ std::lock_guard<std::mutex> g(h->q_m); h->q_stop = true; h->q_cv.notify_all(); }
 		h->q_thread.join();
+		if (h->q_thread2.joinable()) h->q_thread2.join();
 	}
+	if (h->twin) { dsrcgpu_destroy(h->twin); h->twin = nullptr; }
+	if (h->q_chain) { dsrcgpu_chain_destroy(h->q_chain); h->q_chain = nullptr; }
 	for (QBatch& b : h->qb) { if (b.in) hipHostFree(b.in); if (b.out) hipHostFree(b.out); }
 	if (h->arena.base) hipFree(h->arena.base);
 	if (h->dec_tables) hipFree(h->dec_tables);
@@ -1599,8 +1608,9 @@ int pinned_grow(u8*& p, u64& cap, u64 used, u64 need)
 }
 
 // the handle's scheduler thread: runs queued batches in order through the synchronous batch entry point
-void queue_thread(dsrcgpu_handle* h)
+void queue_thread(dsrcgpu_handle* h, int lane)
 {
+	dsrcgpu_handle* L = lane ? h->twin : h;                   // the lane's arena, streams, error text
 	(void)hipSetDevice(h->device);
 	for (;;)
 	{
@@ -1621,13 +1631,20 @@ void queue_thread(dsrcgpu_handle* h)
 		for (int attempt = 0; attempt < 2; ++attempt)
 		{
 			rc = pinned_grow(b.out, b.out_cap, 0, cap);
-			if (rc) { fail(h, rc, "cannot allocate page-locked output memory"); break; }
-			rc = dsrcgpu_compress_batch(h, n, ptrs.data(), b.sizes.data(), b.out, b.out_cap, b.o_offs.data(), b.o_sizes.data(), b.raw.data(), b.comp.data());
+			if (rc) { fail(L, rc, "cannot allocate page-locked output memory"); break; }
+			if (h->q_chain) (void)dsrcgpu_set_chain(L, h->q_chain, b.seq);      // (a retry keeps the turn it has taken)
+			if (attempt == 0 && !b.layout.empty()) { L->rec_chunk_sizes = b.layout; b.layout.clear(); }
+			rc = dsrcgpu_compress_batch(L, n, ptrs.data(), b.sizes.data(), b.out, b.out_cap, b.o_offs.data(), b.o_sizes.data(), b.raw.data(), b.comp.data());
 			if (rc != DSRCGPU_E_CAPACITY) break;
 			cap = b.in_used + (u64)n * (1u << 16);
 		}
 		std::lock_guard<std::mutex> g(h->q_m);
-		b.rc = rc; if (rc) { { std::lock_guard<std::mutex> g(h->err_m); b.err = h->err; } if (!h->q_rc) { h->q_rc = rc; h->q_err = b.err; } }
+		if (h->q_chain && !rc)
+		{	// the handle's own view of the carried state follows the chain (dsrcgpu_get_fields_capacity after a drain)
+			std::lock_guard<std::mutex> gc(h->q_chain->m);
+			if (h->q_chain->next_seq == b.seq + 1) h->fields_cap = h->q_chain->fields_cap;
+		}
+		b.rc = rc; if (rc) { { std::lock_guard<std::mutex> g2(L->err_m); b.err = L->err; } if (!h->q_rc) { h->q_rc = rc; h->q_err = b.err; } }
 		b.state = QBatch::Done; b.next_collect = 0; b.outstanding = 0;
 		h->q_cv.notify_all();
 	}
@@ -1692,7 +1709,25 @@ int dsrcgpu_flush(dsrcgpu_handle* h)
 	if (h->q_rc) return fail(h, h->q_rc, "%s", h->q_err.c_str());
 	QBatch& b = h->qb[h->q_fill];
 	if (b.state != QBatch::Filling || b.ids.empty()) return DSRCGPU_OK;
-	if (!h->q_started) { h->q_started = true; h->q_thread = std::thread(queue_thread, h); }
+	if (!h->q_lanes_decided)
+	{	// second lane unless the caller hands the state over himself (dsrcgpu_set_chain) or DSRC_GPU_QUEUE_LANES=1
+		h->q_lanes_decided = true;
+		const bool want = !h->chain && !(getenv("DSRC_GPU_QUEUE_LANES") && atoi(getenv("DSRC_GPU_QUEUE_LANES")) <= 1);
+		if (want && dsrcgpu_chain_create(&h->q_chain) == DSRCGPU_OK)
+		{
+			dsrcgpu_handle* t = nullptr;
+			if (dsrcgpu_create(&h->set, &h->ds, h->device, 0, &t) == DSRCGPU_OK) { h->twin = t; t->rec_chunk_sizes.clear(); (void)dsrcgpu_chain_seed(h->q_chain, h->fields_cap); }
+			else { if (t) dsrcgpu_destroy(t); dsrcgpu_chain_destroy(h->q_chain); h->q_chain = nullptr; }
+		}
+	}
+	if (!h->q_started)
+	{
+		h->q_started = true;
+		h->q_thread = std::thread(queue_thread, h, 0);
+		if (h->twin) h->q_thread2 = std::thread(queue_thread, h, 1);
+	}
+	b.seq = h->q_seq++;
+	b.layout.swap(h->rec_chunk_sizes); h->rec_chunk_sizes.clear();
 	b.state = QBatch::Queued; ++h->q_pending;
 	h->q_run.push_back(h->q_fill);
 	h->q_fill = (h->q_fill + 1) % DSRC_QUEUE_DEPTH;
@@ -1857,7 +1892,7 @@ int dsrcgpu_release_memory(dsrcgpu_handle* h)
 	if (h->arena.base) { HIPCHK(hipFree(h->arena.base)); h->arena.base = nullptr; h->arena.cap = 0; h->arena.top = 0; }
 	if (h->dec_tables) { HIPCHK(hipFree(h->dec_tables)); h->dec_tables = nullptr; h->dec_tables_cap = 0; }
 	h->last_d_out = nullptr;
-	return DSRCGPU_OK;
+	return h->twin ? dsrcgpu_release_memory(h->twin) : DSRCGPU_OK;
 }
 
 int dsrcgpu_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? DSRCGPU_OK : DSRCGPU_E_HIP; }

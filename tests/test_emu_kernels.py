@@ -470,3 +470,48 @@ def test_release_memory_between_phases(emu, oracle):
         assert texts == h.decompress_batch(got[:3]) == [c + b"\n" for c in chunks]
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("lanes", ["2", "1"])
+def test_queue_form_two_lanes_carry_the_state(emu, oracle, lanes, monkeypatch):
+    """The queue form runs consecutive batches on two scheduler lanes (the handle and its twin: the range coder of one batch next to
+    the front end of the next); what DSRC carries from block to block -- the capacity of TagStats::fields -- goes from lane to lane
+    through the handle's own chain, in flush order.  Titles with 5, 9, 17, 9, 3, 17 fields, one or two chunks per flush, a handle
+    seeded like a shard that starts inside an archive; DSRC_GPU_QUEUE_LANES=1 is the one-lane form."""
+    import random
+    monkeypatch.setenv("DSRC_GPU_QUEUE_LANES", lanes)
+    rng = random.Random(7)
+    chunks = []
+    for k, nf in enumerate((5, 9, 17, 9, 3, 17, 5)):
+        recs = []
+        for i in range(25):
+            title = b"@r.%d" % (100 * k + i) + b"".join(b":%d" % ((7 * i + f) % 90 + 10) for f in range(nf - 2))
+            recs.append(title + b"\n" + bytes(rng.choice(b"ACGT") for _ in range(36)) + b"\n+\n" + bytes(33 + rng.randint(20, 40) for _ in range(36)))
+        chunks.append(b"\n".join(recs))
+    cfg = Config.from_levels(0, 1)
+    for seed in (0, 4):
+        want = oracle.compress_blocks_state(cfg, chunks, fields_cap=seed)
+        h = emu.Handle(cfg.dna_order, cfg.quality_order)
+        if seed:
+            h.set_fields_capacity(seed)
+        got = []
+        for lo, hi in ((0, 1), (1, 3), (3, 4)):                     # three batches in flight, then the rest one by one
+            for i in range(lo, hi):
+                assert h.submit(i, chunks[i])
+            h.flush()
+        for lo in (4, 5, 6):
+            while True:
+                r = h.collect()
+                if r is None:
+                    break
+                got.append(r)
+            assert h.submit(lo, chunks[lo]); h.flush()
+        while True:
+            r = h.collect()
+            if r is None:
+                break
+            got.append(r)
+        assert h.get_fields_capacity() == oracle.last_fields_cap
+        h.close()
+        assert [g[0] for g in got] == list(range(7))
+        assert [(g[1], g[2], g[3]) for g in got] == want, (lanes, seed)
