@@ -682,7 +682,7 @@ def main():
                     for nh in (1, 2):
                         mbs, nbytes, dt = measure_queue_form(cfg, ln.h.device, chunks, nh)
                         q[f"handles_{nh}"] = {"value": mbs, "unit": "MB/s", "bytes": nbytes, "s": round(dt, 2)}
-                    q["what"] = "dsrcgpu_submit / flush / collect / release with host-resident 8 MiB chunks, 192 chunks per flush, one submitting and one collecting thread per handle; host copy into the page-locked ring, PCIe both ways and the compression inside"
+                    q["what"] = "dsrcgpu_submit / flush / collect / release with host-resident 8 MiB chunks, 192 chunks per flush, one submitting and one collecting thread per handle; host copy into the page-locked ring, PCIe both ways and the compression inside; a handle runs consecutive batches on two scheduler lanes of its own (round 4)"
                     line["queue_form"] = q
                     del chunks
                     # the CLI: a >= 16 GB file in tmpfs; every GPU resource of this process is released first
