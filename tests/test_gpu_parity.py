@@ -369,3 +369,44 @@ def test_bucketed_path_lossy_and_eight_symbol_dna(gpu, oracle):
     from tests.cases import alphabet_fastq
     _check(gpu, oracle, Config.from_levels(3, 2), [alphabet_fastq(20, n_rec=8000, L=120, iupac=True)])
     _check(gpu, oracle, Config.from_levels(3, 2, True), [alphabet_fastq(20, n_rec=8000, L=120, iupac=True, q_max=42)])
+
+
+@pytest.mark.parametrize("lanes", ["2", "1"])
+def test_queue_form_two_lanes_carry_the_state(gpu, oracle, lanes, monkeypatch):
+    """The queue form on the device with batches in flight on both scheduler lanes of a handle (round 4): chunks whose titles have
+    5, 9, 17, 9, 3, 17, 5 fields -- the capacity of TagStats::fields changes from batch to batch and every block depends on it --,
+    three flushes before anything is collected, at -d3 -q2 (bucketed front end, range coder on each lane's own stream)."""
+    import random
+    monkeypatch.setenv("DSRC_GPU_QUEUE_LANES", lanes)
+    rng = random.Random(7)
+    chunks = []
+    for k, nf in enumerate((5, 9, 17, 9, 3, 17, 5)):
+        recs = []
+        for i in range(1500):
+            title = b"@r.%d" % (10000 * k + i) + b"".join(b":%d" % ((7 * i + f) % 90 + 10) for f in range(nf - 2))
+            recs.append(title + b"\n" + bytes(rng.choice(b"ACGT") for _ in range(60)) + b"\n+\n" + bytes(33 + rng.randint(20, 40) for _ in range(60)))
+        chunks.append(b"\n".join(recs))
+    cfg = Config.from_levels(3, 2)
+    want = oracle.compress_blocks_state(cfg, chunks)
+    h = gpu.Handle(cfg.dna_order, cfg.quality_order)
+    got = []
+    for lo, hi in ((0, 1), (1, 3), (3, 4)):
+        for i in range(lo, hi):
+            assert h.submit(i, chunks[i])
+        h.flush()
+    for lo in (4, 5, 6):
+        while True:
+            r = h.collect()
+            if r is None:
+                break
+            got.append(r)
+        assert h.submit(lo, chunks[lo]); h.flush()
+    while True:
+        r = h.collect()
+        if r is None:
+            break
+        got.append(r)
+    assert h.get_fields_capacity() == oracle.last_fields_cap
+    h.close()
+    assert [g[0] for g in got] == list(range(7))
+    assert [(g[1], g[2], g[3]) for g in got] == want
