@@ -515,3 +515,33 @@ def test_queue_form_two_lanes_carry_the_state(emu, oracle, lanes, monkeypatch):
         h.close()
         assert [g[0] for g in got] == list(range(7))
         assert [(g[1], g[2], g[3]) for g in got] == want, (lanes, seed)
+
+
+def test_queue_form_then_batch_calls_on_one_handle(emu, oracle):
+    """Batch calls on a handle whose queue form runs two lanes: refused while flushed batches are in flight, allowed once the queue
+    has drained -- and the block-to-block state goes on from one form to the other and back."""
+    import random
+    rng = random.Random(11)
+    chunks = []
+    for k, nf in enumerate((5, 17, 9, 3, 17)):
+        recs = [b"@r.%d" % (100 * k + i) + b"".join(b":%d" % ((7 * i + f) % 90 + 10) for f in range(nf - 2)) + b"\n" +
+                bytes(rng.choice(b"ACGT") for _ in range(36)) + b"\n+\n" + bytes(33 + rng.randint(20, 40) for _ in range(36)) for i in range(25)]
+        chunks.append(b"\n".join(recs))
+    cfg = Config.from_levels(0, 1)
+    want = oracle.compress_blocks_state(cfg, chunks)
+    h = emu.Handle(cfg.dna_order, cfg.quality_order)
+    got = []
+    assert h.submit(0, chunks[0]); h.flush()
+    assert h.submit(1, chunks[1]); h.flush()
+    with pytest.raises(emu.DsrcGpuError) as ei:
+        h.compress_batch([chunks[2]])
+    assert ei.value.code == -6
+    for _ in range(2):
+        r = h.collect(); got.append((r[1], r[2], r[3]))
+    assert h.collect() is None
+    got += h.compress_batch([chunks[2]])                              # drained: the batch form, from the lanes' state
+    got += h.compress_batch([chunks[3]])
+    assert h.submit(4, chunks[4]); h.flush()                          # ... and back
+    r = h.collect(); got.append((r[1], r[2], r[3]))
+    h.close()
+    assert got == want
