@@ -86,6 +86,8 @@ struct dsrcgpu_chain
 	bool failed = false;
 };
 
+static thread_local bool tl_queue_lane = false;      // this thread is a scheduler lane of the queue form calling the batch entry point
+
 struct dsrcgpu_handle
 {
 	dsrcgpu_settings set;
@@ -112,7 +114,6 @@ struct dsrcgpu_handle
 	// with its own arena and streams), so that the range coder of batch i -- 130 ms on a handful of CUs -- overlaps the copies and the
 	// front end of batch i + 1.  What DSRC carries from block to block goes from lane to lane through `q_chain`, in flush order.
 	dsrcgpu_handle* twin = nullptr; dsrcgpu_chain* q_chain = nullptr; std::thread q_thread2; uint64_t q_seq = 0; bool q_lanes_decided = false;
-	bool q_internal_call = false;    // the batch entry point is being called by a scheduler lane, not by the user
 	int q_rc = 0; std::string q_err;                                 // first failure of the scheduler thread (sticky)
 	float batch_ms = 0.f, rc_ms = 0.f, verify_ms = 0.f;
 	u32 rc_launches = 0;
@@ -1504,7 +1505,7 @@ int dsrcgpu_compress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_f
 {
 	if (!h) return DSRCGPU_E_ARG;
 	if (!d_fastq || !offs || !sizes || !d_blocks || !block_offs || !block_sizes || !raw_sizes || !comp_sizes) return fail(h, DSRCGPU_E_ARG, "null argument");
-	if (h->q_chain && !h->q_internal_call)
+	if (h->q_chain && !tl_queue_lane)
 	{	// a batch call by the user on a handle whose queue form runs two lanes: allowed once the queue has drained; the handle's
 		// own copy of the block-to-block state is current then (the next flush hands it back to the lanes' chain)
 		std::lock_guard<std::mutex> g(h->q_m);
@@ -1527,7 +1528,7 @@ int dsrcgpu_compress_batch(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* 
 	if (!h) return DSRCGPU_E_ARG;
 	if (!fastq || !sizes || !blocks || !block_offs || !block_sizes || !raw_sizes || !comp_sizes) return fail(h, DSRCGPU_E_ARG, "null argument");
 	if (n == 0) return DSRCGPU_OK;
-	if (h->q_chain && !h->q_internal_call)
+	if (h->q_chain && !tl_queue_lane)
 	{	// a batch call by the user on a handle whose queue form runs two lanes: allowed once the queue has drained; the handle's
 		// own copy of the block-to-block state is current then (the next flush hands it back to the lanes' chain)
 		std::lock_guard<std::mutex> g(h->q_m);
@@ -1648,10 +1649,10 @@ void queue_thread(dsrcgpu_handle* h, int lane)
 			rc = pinned_grow(b.out, b.out_cap, 0, cap);
 			if (rc) { fail(L, rc, "cannot allocate page-locked output memory"); break; }
 			if (h->q_chain) (void)dsrcgpu_set_chain(L, h->q_chain, b.seq);      // (a retry keeps the turn it has taken)
-			L->q_internal_call = true;
+			tl_queue_lane = true;
 			if (attempt == 0 && !b.layout.empty()) { L->rec_chunk_sizes = b.layout; b.layout.clear(); }
 			rc = dsrcgpu_compress_batch(L, n, ptrs.data(), b.sizes.data(), b.out, b.out_cap, b.o_offs.data(), b.o_sizes.data(), b.raw.data(), b.comp.data());
-			L->q_internal_call = false;
+			tl_queue_lane = false;
 			if (rc != DSRCGPU_E_CAPACITY) break;
 			cap = b.in_used + (u64)n * (1u << 16);
 		}
