@@ -1,5 +1,5 @@
 #!/bin/bash
-# dsrc-amd d on a 16.6 GB archive in tmpfs with the worker timeline and the wall time of the process (start to exit)
+# dsrc-amd d on one 16.6 GB archive with different pass shapes (handles per device x blocks per pass): wall time start to exit
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 python - <<'PY'
 import os, sys
@@ -14,11 +14,11 @@ with open("/dev/shm/t.fastq", "wb") as f:
 h.close()
 PY
 dsrc_amd/csrc/dsrc-amd c -d3 -q2 -t4 /dev/shm/t.fastq /dev/shm/t.dsrc
-for i in 1; do
+for a in "-t4" "-t1 -n2000" "-t2 -n1000" "-t2 -n700" "-t3 -n500" "-t4"; do
   sleep 4; rm -f /dev/shm/t_back.fastq
   t0=$(date +%s.%N)
-  env DSRC_HOST_TRACE=1 "$@" dsrc_amd/csrc/dsrc-amd d ${DARGS:--t4} /dev/shm/t.dsrc /dev/shm/t_back.fastq 2>&1 | grep -E "d\]" | tail -24
-  t1=$(date +%s.%N); python -c "print(\"wall %.2f s\" % ($t1 - $t0))"
+  DSRC_HOST_TRACE=1 dsrc_amd/csrc/dsrc-amd d $a /dev/shm/t.dsrc /dev/shm/t_back.fastq 2>&1 | grep -E "all decoded" | tail -1
+  t1=$(date +%s.%N); python -c "print(\"$a: wall %.2f s\" % ($t1 - $t0))"
 done
 cmp /dev/shm/t.fastq /dev/shm/t_back.fastq && echo identical
 rm -f /dev/shm/t.fastq /dev/shm/t.dsrc /dev/shm/t_back.fastq
