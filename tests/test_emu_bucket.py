@@ -64,14 +64,15 @@ def test_hot_contexts_rescale_inside_the_bucket(emu, oracle, capfd, monkeypatch)
     check(emu, oracle, data, [(1, 1, False), (3, 2, False), (2, 1, True)])
     err = capfd.readouterr().err
     assert err.count("2 of 2 streams tried, 0 handed back") == 3, err
-    # a 64-symbol alphabet whose hot context rescales
-    rng = random.Random(9)
-    vals = list(range(2, 42))
-    recs = []
-    for i in range(260):
-        q = bytes(33 + (vals[rng.randrange(40)] if rng.random() < 0.03 else 40) for _ in range(200))
-        recs.append(b"@q.%d\n" % i + bytes(rng.choice(b"ACGT") for _ in range(200)) + b"\n+\n" + q)
-    check(emu, oracle, b"\n".join(recs), [(2, 2, False), (1, 1, False)])
+    # 32-, 64- and 128-symbol alphabets whose hot context rescales (rows of two and three radix-4 levels, with and without the pair level)
+    for n_vals in (20, 40, 90):
+        rng = random.Random(n_vals)
+        vals = list(range(2, 2 + n_vals))
+        recs = []
+        for i in range(260):
+            q = bytes(33 + (vals[rng.randrange(n_vals)] if rng.random() < 0.03 else vals[-1]) for _ in range(200))
+            recs.append(b"@q.%d\n" % i + bytes(rng.choice(b"ACGT") for _ in range(200)) + b"\n+\n" + q)
+        check(emu, oracle, b"\n".join(recs), [(2, 2, False), (1, 1, False)])
 
 
 def test_bucket_too_large_for_a_wave(emu, oracle, capfd, monkeypatch):
