@@ -640,7 +640,6 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		o_bcnt = A.alloc(cnt_words * 2 + 64);
 	}
 	const size_t o_jobs = A.alloc(sizeof(CtxJob) * std::max(1u, NJ)), o_chains = A.alloc(sizeof(RcChain) * std::max(1u, NJ));
-	const size_t o_fin = A.alloc(sizeof(RcFin) * std::max(1u, NJ));
 	if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (phase 3b): batch needs > %zu bytes of HBM scratch", A.top);
 	CtxJob* d_jobs = AP<CtxJob>(h, o_jobs); RcChain* d_chains = AP<RcChain>(h, o_chains);
 
@@ -864,8 +863,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		HIPCHK(hipEventRecord(h->ev[4], s));
 		HIPCHK(hipStreamWaitEvent(h->rc_stream, h->ev[4], 0));
 		HIPCHK(hipEventRecord(h->ev[2], h->rc_stream));
-		hipLaunchKernelGGL(k_rc, dim3((NJ + RC_LANES - 1) / RC_LANES), dim3(64 * (1 + RC_LOADERS)), 0, h->rc_stream, d_chains, NJ, AP<RcPack>(h, 0), AP<RcFin>(h, o_fin), d_state); KCHK();
-		hipLaunchKernelGGL(k_rc_emit, dim3(NJ), dim3(RC_EMIT_WG), 0, h->rc_stream, d_chains, AP<RcPack>(h, 0), AP<RcFin>(h, o_fin), wpool, d_state); KCHK();
+		hipLaunchKernelGGL(k_rc, dim3((NJ + RC_LANES - 1) / RC_LANES), dim3(64 * RC_WG_WAVES), 0, h->rc_stream, d_chains, NJ, AP<RcPack>(h, 0), wpool, d_state); KCHK();
 		HIPCHK(hipEventRecord(h->ev[3], h->rc_stream));
 		HIPCHK(hipStreamWaitEvent(s, h->ev[3], 0));
 		h->rc_launches = 1;

@@ -859,9 +859,9 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 //     coalesced row and the coder runs 64-128 symbols (6-12 us) behind its loads; lane c then reads row c,
 //     16 records at a time, with ds_read_b128 into ping-pong registers;
 //   * the bytes a symbol pushes out of the coder are NOT packed serially: the step leaves one 32-bit code per
-//     symbol -- the top three bytes of `low` and how many of them (0..2) leave -- written over the record array
-//     (code t at byte 4t is always behind the records still to be read), and k_rc_emit, a data-parallel kernel,
-//     prefix-sums the byte counts and stores the bytes;
+//     symbol -- the top three bytes of `low` and how many of them (0..3) leave -- in an LDS row, and the loader
+//     waves, one chunk behind the coder, prefix-sum the byte counts of the row's 64 codes and store the bytes
+//     (rc_emit_chunk; until round 4 the codes went over the record array in HBM and a second kernel read them back);
 //   * RangeEncoder::EncodeFrequency's carry clamp (src/RangeCoder.h:64-74) needs bits 24..39 of `low` to be
 //     all ones; that is accumulated branch-free and checked once per 16 symbols -- if it ever shows, the
 //     group is replayed from a snapshot with the reference's loop, verbatim.
@@ -877,10 +877,6 @@ struct RcChain
 	u32 pad0;
 };
 
-// what k_rc leaves for k_rc_emit besides the per-symbol codes: the bytes of the last (n mod 16) symbols
-// followed by the 8 bytes of RangeEncoder::End
-struct RcFin { u32 n; u8 b[60]; };
-
 #define RC_GROUP 16                    // symbols per register group / clamp check
 #ifndef RC_LANES
 #define RC_LANES 32                    // chains per wave (lanes beyond idle): half a wave keeps the LDS at 52 KB, so a k_rc wave shares a
@@ -889,6 +885,17 @@ struct RcFin { u32 n; u8 b[60]; };
 #define RC_ROW_U4 49                   // LDS row pitch in 16-byte units: 48 of data + 1 so that a 16-lane ds_read_b128 pass covers all 64 banks
 #ifndef RC_LOADERS
 #define RC_LOADERS 4                   // loader waves per workgroup (each feeds RC_LANES / RC_LOADERS rows)
+#endif
+// Waves of a k_rc workgroup.  A workgroup's waves go round the CU's four SIMDs in order: wave 0 (the coder) keeps its SIMD to itself
+// when the waves 4, 8, ... leave at once (RC_SPARE_SIMD) -- the coder is bound by the VALU of its SIMD, every cycle a loader spends
+// there is added to the chain of dependent steps.
+#ifndef RC_SPARE_SIMD
+#define RC_SPARE_SIMD 1
+#endif
+#if RC_SPARE_SIMD
+#define RC_WG_WAVES (1 + RC_LOADERS + (RC_LOADERS + 2) / 3)
+#else
+#define RC_WG_WAVES (1 + RC_LOADERS)
 #endif
 #ifndef RC_DEPTH
 #define RC_DEPTH 8                     // register sets of a loader wave: a chunk is requested RC_DEPTH - 1 chunk periods before it is converted (even)
@@ -954,7 +961,7 @@ __device__ __forceinline__ RcRec rc_rec(const RcRegs& g, u32 i)
 }
 
 // codes of one group -> codes[0..15].  `row` = the chain's LDS row the group was read from (still intact).
-__device__ __forceinline__ void rc_group(RcState& s, u32* codes, const RcRegs& g, const LDS_AS U4* row, u32 grp, u8* xb, u32* err, u32 force_exact)
+__device__ __forceinline__ void rc_group(RcState& s, LDS_AS u32* codes, const RcRegs& g, const LDS_AS U4* row, u32 grp, u8* xb, u32* err, u32 force_exact)
 {
 	const RcState snap = s;
 	u32 zmax = force_exact ? 0xFFFFu : 0u;
@@ -983,7 +990,7 @@ __device__ __forceinline__ void rc_group(RcState& s, u32* codes, const RcRegs& g
 	for (u32 i = 0; i < RC_GROUP / 4; ++i)
 	{
 		const U4 v = {c[4 * i], c[4 * i + 1], c[4 * i + 2], c[4 * i + 3]};
-		((U4*)codes)[i] = v;
+		((LDS_AS U4*)codes)[i] = v;
 	}
 }
 
@@ -1010,7 +1017,7 @@ __device__ __forceinline__ void rc_fetch(RcPack* r, const u8* base, u32 pitch, u
 #pragma unroll
 	for (u32 k = 0; k < RC_ROWS_PER_LOADER; ++k)
 	{
-		r[k] = lw + k * RC_LOADERS < n_live ? *(const RcPack*)sp : 0ull;       // n_live: constant RC_LANES in full workgroups
+		r[k] = lw + k * RC_LOADERS < n_live ? *(const GLOBAL_AS RcPack*)sp : 0ull;   // global, not flat: a flat access orders itself against the LDS traffic       // n_live: constant RC_LANES in full workgroups
 		sp += (u64)RC_LOADERS * pitch;
 	}
 }
@@ -1033,10 +1040,9 @@ __device__ __forceinline__ void rc_convert(LDS_AS U4* buf, const RcPack* r, u32 
 }
 
 // one 64-symbol chunk of the coder wave: the chain's records are in `cur` (landed), r0 holds its first group
-__device__ __forceinline__ void rc_chunk(RcState& s, u32* codes, RcRegs& r0, RcRegs& r1, const LDS_AS U4* row, u32 t0, u32 n,
+__device__ __forceinline__ void rc_chunk(RcState& s, LDS_AS u32* c, RcRegs& r0, RcRegs& r1, const LDS_AS U4* row, u32 t0, u32 n,
 										 u8* xb, u32* err, u32 fx)
-{
-	u32* c = codes + t0;
+{	// c: the chain's row of the chunk's code buffer (64 codes)
 	rc_load_group(r1, row, 1);
 	if (t0 + 1 * RC_GROUP <= n) rc_group(s, c, r0, row, 0, xb, err, fx);
 	rc_load_group(r0, row, 2);
@@ -1044,6 +1050,48 @@ __device__ __forceinline__ void rc_chunk(RcState& s, u32* codes, RcRegs& r0, RcR
 	rc_load_group(r1, row, 3);
 	if (t0 + 3 * RC_GROUP <= n) rc_group(s, c + 2 * RC_GROUP, r0, row, 2, xb, err, fx);
 	if (t0 + 4 * RC_GROUP <= n) rc_group(s, c + 3 * RC_GROUP, r1, row, 3, xb, err, fx);
+}
+
+// The codes of a chunk go from the coder to the loader waves through LDS (round 4; before, they went to HBM over the consumed
+// records and a second kernel, k_rc_emit, turned them into bytes: 4 B written + 4 B read per symbol and a launch on the critical
+// path of every batch).  Row pitch 68 words: a 16-lane ds_write_b128 pass covers all 64 banks.
+#define RC_CODE_PITCH 68
+// What a loader wave knows about its rows (wave-uniform values, taken once from the lanes of its own copy of the chains:
+// scalar registers -- nothing the byte stores need comes from memory, a load here would wait behind the record fetches in flight).
+struct RcEmitRows { GLOBAL_AS u8* out[RC_LANES / RC_LOADERS]; u32 limit[RC_LANES / RC_LOADERS], n_full[RC_LANES / RC_LOADERS], pos[RC_LANES / RC_LOADERS]; };
+
+// Loader wave `lw`, rows lw, lw + RC_LOADERS, ...: the 64 codes of chunk `chunk` of each row -> bytes at the row's running position
+// (lane l takes code l: scan of the byte counts, up to three byte stores).
+__device__ __forceinline__ void rc_emit_chunk(const LDS_AS u32* codes, RcEmitRows& R, u32 chunk, u32 lw, u32 n_live, u32* over)
+{
+	const u32 lane = lane_id();
+	const u32 t = chunk * RC_CHUNK + lane;
+	u32 v[RC_LANES / RC_LOADERS], kb[RC_LANES / RC_LOADERS], inc[RC_LANES / RC_LOADERS];
+	// the rows' scans are independent chains of DPP steps: kept apart from the stores so that they interleave
+#pragma unroll
+	for (u32 k = 0; k < RC_LANES / RC_LOADERS; ++k)
+	{
+		const u32 j = lw + k * RC_LOADERS;
+		v[k] = codes[(j < n_live ? j : 0u) * RC_CODE_PITCH + lane];
+		kb[k] = j < n_live && t < R.n_full[k] ? v[k] & 3u : 0u;
+	}
+#pragma unroll
+	for (u32 k = 0; k < RC_LANES / RC_LOADERS; ++k) inc[k] = wave_incl_scan_dpp(kb[k]);
+#pragma unroll
+	for (u32 k = 0; k < RC_LANES / RC_LOADERS; ++k)
+	{
+		const u32 total = wave_last(inc[k]);
+		const u32 at = R.pos[k] + inc[k] - kb[k];
+		if (R.pos[k] + total > R.limit[k]) *over |= 1u;
+		else
+		{
+			GLOBAL_AS u8* out = R.out[k];
+			if (kb[k] >= 1) out[at] = (u8)(v[k] >> 24);
+			if (kb[k] >= 2) out[at + 1] = (u8)(v[k] >> 16);
+			if (kb[k] >= 3) out[at + 2] = (u8)(v[k] >> 8);
+		}
+		R.pos[k] += total;
+	}
 }
 
 // A workgroup is 1 + RC_LOADERS waves.  Wave 0 codes (one lane = one chain, RC_LANES chains); the others fetch the 8-byte
@@ -1054,12 +1102,20 @@ __device__ __forceinline__ void rc_chunk(RcState& s, u32* codes, RcRegs& r0, RcR
 // FULL: every lane below RC_LANES has a chain; the last workgroup of a launch may be partial and then must not request
 // rows it does not have (one launch, two instantiations of the body: a wave only ever fetches the code of its own).
 template <bool FULL>
-__device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains, RcPack* rec_pool, RcFin* fin, BlkState* st, LDS_AS U4* buf_a, LDS_AS U4* buf_b, u8* s_xb)
+__device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains, RcPack* rec_pool, u32* word_pool, BlkState* st, LDS_AS U4* buf_a, LDS_AS U4* buf_b, u8* s_xb,
+												 LDS_AS u32* code_a, LDS_AS u32* code_b, LDS_AS u32* s_pos)
 {
 	__builtin_amdgcn_s_setprio(3);                                             // the serial waves win issue arbitration against co-resident data-parallel waves
 	const u32 first_chain = blockIdx.x * RC_LANES;
 	const u32 lane = lane_id(), id = first_chain + lane;
 	const bool loader = wave_id() >= 1;
+#if RC_SPARE_SIMD
+	if (loader && (wave_id() & 3u) == 0) return;                               // before the first barrier: the hardware counts the waves still alive
+	const u32 loader_id = wave_id() - 1u - (wave_id() >> 2);
+	if (loader && loader_id >= RC_LOADERS) return;
+#else
+	const u32 loader_id = wave_id() - 1u;
+#endif
 	const bool have = lane < RC_LANES && (FULL || id < n_chains);
 	const RcChain c = chains[have ? id : n_chains - 1];                        // idle lanes shadow a real chain's values and code nothing
 	const u32 n_live = FULL ? (u32)RC_LANES : n_chains - first_chain;
@@ -1073,7 +1129,7 @@ __device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains
 		// the arrays of a workgroup's chains are c.pitch records apart (wave-uniform; idle lanes shadow the last chain's values)
 		const u8* base = uniform_ptr(rec_pool + __shfl(c.trip, 0));
 		const u32 pitch = (u32)__builtin_amdgcn_readfirstlane((int)(c.pitch * (u32)sizeof(RcPack)));
-		const u32 lw = wave_id() - 1u, CB = RC_CHUNK * (u32)sizeof(RcPack);
+		const u32 lw = loader_id, CB = RC_CHUNK * (u32)sizeof(RcPack);
 		// RC_DEPTH register sets: a chunk is requested RC_DEPTH - 1 chunk periods before it is converted -- with other instances'
 		// traffic on the memory system a load can take many microseconds, and the coder waits for the slowest of a chunk's 32
 		// rows (round 2, four sets of two loaders: k_rc 130 ms alone, 175 ms next to three other instances' front ends)
@@ -1083,24 +1139,42 @@ __device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains
 		for (u32 d = 0; d < RC_DEPTH; ++d) rc_fetch(r[d], base, pitch, d * CB, lw, n_live);
 		rc_convert(buf_a, r[0], lw, n_live);
 		__syncthreads();                                                       // chunk 0 is there
+		RcEmitRows R; u32 over = 0;
+#pragma unroll
+		for (u32 k = 0; k < RC_ROWS_PER_LOADER; ++k)
+		{
+			const u32 j = lw + k * RC_LOADERS < n_live ? lw + k * RC_LOADERS : 0u;
+			R.out[k] = (GLOBAL_AS u8*)uniform_ptr(word_pool + __shfl(c.out_words, j));
+			R.limit[k] = (u32)__builtin_amdgcn_readfirstlane((int)__shfl(c.out_byte0 + c.out_cap, j));
+			R.n_full[k] = (u32)__builtin_amdgcn_readfirstlane((int)__shfl(n_full, j));
+			R.pos[k] = (u32)__builtin_amdgcn_readfirstlane((int)__shfl(c.out_byte0, j));
+		}
 		// one barrier per chunk the coder works through: it takes them in pairs (buf_a, buf_b)
 		const u32 n_sync = 2u * ((wave_full + 2 * RC_CHUNK - 1) / (2 * RC_CHUNK));
 		for (u32 q = 0; q < n_sync; q += RC_DEPTH)
 		{
 #pragma unroll
 			for (u32 k = 0; k < RC_DEPTH; ++k)
-			{	// the coder is in chunk q + k (buf_a for even k): its set is free for chunk q + k + RC_DEPTH, the next chunk goes into the other buffer
+			{	// the coder is in chunk q + k (buf_a / code_a for even k): its set is free for chunk q + k + RC_DEPTH, the next chunk goes
+				// into the other record buffer, and the codes of the chunk before it (in the other code buffer) become bytes
 				if (q + k >= n_sync) break;
 				rc_fetch(r[k], base, pitch, (q + k + RC_DEPTH) * CB, lw, n_live);
 				rc_convert((k & 1u) ? buf_a : buf_b, r[(k + 1) % RC_DEPTH], lw, n_live);
+				if (q + k >= 1) rc_emit_chunk((k & 1u) ? code_a : code_b, R, q + k - 1, lw, n_live, &over);
 				__syncthreads();
 			}
 		}
+		rc_emit_chunk(code_b, R, n_sync - 1, lw, n_live, &over);     // n_sync is even: the last chunk's codes are in code_b
+#pragma unroll
+		for (u32 k = 0; k < RC_ROWS_PER_LOADER; ++k)
+			if (lw + k * RC_LOADERS < n_live && lane_id() == 0) s_pos[lw + k * RC_LOADERS] = R.pos[k] | (over ? 0x80000000u : 0u);
+		__syncthreads();                                                       // the coder takes the positions for the chains' tails
 		return;
 	}
 
 	RcPack* p = rec_pool + c.trip;
-	u32* codes = (u32*)p;                                                      // code t overwrites bytes 4t..4t+3 of the chain's own array (behind every record still to be read)
+	u8* out = (u8*)(word_pool + c.out_words);
+	const u32 limit = c.out_byte0 + c.out_cap;
 	u8* xb = s_xb + lane * RC_XB;
 	u32* err = &st[c.blk].err;
 	RcState s;
@@ -1110,101 +1184,49 @@ __device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains
 		const u32 rowi = lane < RC_LANES ? lane : RC_LANES - 1;               // idle lanes read a valid row and code nothing
 		const LDS_AS U4* row_a = buf_a + rowi * RC_ROW_U4;
 		const LDS_AS U4* row_b = buf_b + rowi * RC_ROW_U4;
+		LDS_AS u32* crow_a = code_a + rowi * RC_CODE_PITCH;
+		LDS_AS u32* crow_b = code_b + rowi * RC_CODE_PITCH;
 		RcRegs r0, r1;
 		__syncthreads();
 		rc_load_group(r0, row_a, 0);
 		for (u32 t0 = 0; t0 < wave_full; t0 += 2 * RC_CHUNK)
 		{
-			rc_chunk(s, codes, r0, r1, row_a, t0, n, xb, err, c.force_exact);
+			rc_chunk(s, crow_a, r0, r1, row_a, t0, n, xb, err, c.force_exact);
 			__syncthreads();
 			rc_load_group(r0, row_b, 0);
-			rc_chunk(s, codes, r0, r1, row_b, t0 + RC_CHUNK, n, xb, err, c.force_exact);
+			rc_chunk(s, crow_b, r0, r1, row_b, t0 + RC_CHUNK, n, xb, err, c.force_exact);
 			__syncthreads();
 			rc_load_group(r0, row_a, 0);
 		}
+		__syncthreads();                                                       // the loaders have turned the last chunk's codes into bytes
 	}
 	if (!have) return;
-	// the last n mod 16 symbols and RangeEncoder::End
+	// the last n mod 16 symbols and RangeEncoder::End, behind the bytes of the chunks
+	u32 pos = c.out_byte0;
+	if (wave_full) { const u32 v = s_pos[lane]; pos = v & 0x7FFFFFFFu; if (v >> 31) atomicOr(err, (u32)DSRC_ERR_OUT_OVERFLOW); }
 	u32 nb = 0;
 	for (u32 t = n_full; t < n; ++t) { const RcRec e = rc_unpack(p[t]); rc_step_exact(s, e, xb, nb); }
-	if (nb + 8 > sizeof(fin->b)) { atomicOr(err, (u32)DSRC_ERR_OUT_OVERFLOW); nb = 0; }
-	RcFin* F = &fin[id];
-	for (u32 k = 0; k < nb; ++k) F->b[k] = xb[k];
-	for (u32 k = 0; k < 8; ++k) { F->b[nb + k] = (u8)(s.low >> 56); s.low <<= 8; }
-	F->n = nb + 8;
+	if (nb > RC_XB) { atomicOr(err, (u32)DSRC_ERR_OUT_OVERFLOW); nb = 0; }
+	if (pos + nb + 8 > limit) atomicOr(err, (u32)DSRC_ERR_OUT_OVERFLOW);
+	else
+	{
+		for (u32 k = 0; k < nb; ++k) out[pos + k] = xb[k];
+		for (u32 k = 0; k < 8; ++k) { out[pos + nb + k] = (u8)(s.low >> 56); s.low <<= 8; }
+	}
+	pos += nb + 8;
+	if (c.is_dna) st[c.blk].dna_bytes = pos; else st[c.blk].qua_bytes = pos;
 }
 
-__global__ void __launch_bounds__(64 * (1 + RC_LOADERS)) k_rc(const RcChain* chains, u32 n_chains, RcPack* rec_pool, RcFin* fin, BlkState* st)
+__global__ void __launch_bounds__(64 * RC_WG_WAVES) k_rc(const RcChain* chains, u32 n_chains, RcPack* rec_pool, u32* word_pool, BlkState* st)
 {
 	__shared__ U4 s_a[RC_LANES * RC_ROW_U4];
 	__shared__ U4 s_b[RC_LANES * RC_ROW_U4];
+	__shared__ U4 s_ca[RC_LANES * RC_CODE_PITCH / 4];
+	__shared__ U4 s_cb[RC_LANES * RC_CODE_PITCH / 4];
+	__shared__ u32 s_pos[RC_LANES];
 	__shared__ u8 s_xb[64 * RC_XB];
-	if (blockIdx.x * RC_LANES + RC_LANES <= n_chains) rc_workgroup<true>(chains, n_chains, rec_pool, fin, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb);
-	else rc_workgroup<false>(chains, n_chains, rec_pool, fin, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb);
-}
-
-// ---- byte emitter: codes -> stream bytes (data-parallel) ------------------------------------------
-// One workgroup per chain: every thread takes 8 consecutive codes, a workgroup scan of the byte counts gives
-// each code its position, the bytes are stored; then the tail left in RcFin.  Sets the stream size.
-#define RC_EMIT_WG 256
-#define RC_EMIT_ITEMS 8
-__global__ void __launch_bounds__(RC_EMIT_WG) k_rc_emit(const RcChain* chains, const RcPack* rec_pool, const RcFin* fin, u32* word_pool, BlkState* st)
-{
-	__shared__ u32 s_w[RC_EMIT_WG / 64];
-	const RcChain c = chains[blockIdx.x];
-	const u32* codes = (const u32*)(rec_pool + c.trip);
-	u8* out = (u8*)(word_pool + c.out_words);
-	const u32 n_codes = c.n & ~(u32)(RC_GROUP - 1);
-	const u32 limit = c.out_byte0 + c.out_cap;
-	u32 pos = c.out_byte0;                                  // workgroup-uniform running position
-	bool over = false;
-	for (u32 tile = 0; tile < n_codes; tile += RC_EMIT_WG * RC_EMIT_ITEMS)
-	{
-		const u32 t0 = tile + threadIdx.x * RC_EMIT_ITEMS;
-		u32 cd[RC_EMIT_ITEMS]; u32 mine = 0;
-		if (t0 < n_codes)                                   // n_codes and t0 are multiples of 8: whole 32-byte pieces
-		{
-			const U4 a = ((const U4*)(codes + t0))[0], b = ((const U4*)(codes + t0))[1];
-			cd[0] = a[0]; cd[1] = a[1]; cd[2] = a[2]; cd[3] = a[3]; cd[4] = b[0]; cd[5] = b[1]; cd[6] = b[2]; cd[7] = b[3];
-#pragma unroll
-			for (u32 k = 0; k < RC_EMIT_ITEMS; ++k) mine += cd[k] & 3u;
-		}
-		else
-		{
-#pragma unroll
-			for (u32 k = 0; k < RC_EMIT_ITEMS; ++k) cd[k] = 0;
-		}
-		const u32 inc = wave_incl_scan(mine);
-		if (lane_id() == 63) s_w[wave_id()] = inc;
-		__syncthreads();
-		u32 wbase = 0, total = 0;
-		for (u32 w = 0; w < RC_EMIT_WG / 64; ++w) { const u32 x = s_w[w]; if (w < wave_id()) wbase += x; total += x; }
-		__syncthreads();
-		u32 at = pos + wbase + inc - mine;
-		if (at + mine > limit) over = true;
-		else
-		{
-#pragma unroll
-			for (u32 k = 0; k < RC_EMIT_ITEMS; ++k)
-			{
-				const u32 kb = cd[k] & 3u, v = cd[k];
-				if (kb >= 1) out[at] = (u8)(v >> 24);
-				if (kb >= 2) out[at + 1] = (u8)(v >> 16);
-				if (kb >= 3) out[at + 2] = (u8)(v >> 8);
-				at += kb;
-			}
-		}
-		pos += total;
-	}
-	if (threadIdx.x == 0)
-	{
-		const RcFin* F = &fin[blockIdx.x];
-		if (pos + F->n > limit) over = true;
-		else for (u32 k = 0; k < F->n; ++k) out[pos + k] = F->b[k];
-		pos += F->n;
-		if (c.is_dna) st[c.blk].dna_bytes = pos; else st[c.blk].qua_bytes = pos;
-	}
-	if (over) atomicOr(&st[c.blk].err, (u32)DSRC_ERR_OUT_OVERFLOW);
+	if (blockIdx.x * RC_LANES + RC_LANES <= n_chains) rc_workgroup<true>(chains, n_chains, rec_pool, word_pool, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb, (LDS_AS u32*)s_ca, (LDS_AS u32*)s_cb, (LDS_AS u32*)s_pos);
+	else rc_workgroup<false>(chains, n_chains, rec_pool, word_pool, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb, (LDS_AS u32*)s_ca, (LDS_AS u32*)s_cb, (LDS_AS u32*)s_pos);
 }
 
 // ---- stream prologues ---------------------------------------------------------------------------
