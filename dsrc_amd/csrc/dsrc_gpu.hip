@@ -593,7 +593,6 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	const u32 bk_limit = getenv("DSRC_GPU_BUCKET_LIMIT") ? (u32)atol(getenv("DSRC_GPU_BUCKET_LIMIT")) : (u32)BK_LIMIT;      // tests
 	const bool use_bk = bk_enabled && NJ > 0 && h->lds64_ordered;      // k_model stands on the LDS applying atomics in lane order (k_lds_order_test)
 	size_t o_bk = 0, bk_zero_words = 0, o_bcnt = 0;
-	static_assert(BK_BIN % (SORT_WG * SORT_ITEMS) == 0, "a time bin is a whole number of k_part tiles");
 	if (use_bk)
 	{
 		u32 cur = NJ;                                            // [0, NJ): the jobs' fallback flags
@@ -624,7 +623,6 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			j.bk_limit = bk_limit;
 		}
 		bk_zero_words = cur;
-		for (u32 i = 0; i < NJ; ++i) { jobs[i].bk_boff = cur; cur += jobs[i].bk_on ? (1u << jobs[i].bk_hb) + 1u : 0u; }
 		o_bk = A.alloc((size_t)cur * 4 + 64);
 		// per (tile, bucket) element counts of k_part (u16); k_binoff turns the first row of every time bin into the buckets' offsets
 		size_t cnt_words = 0;
@@ -633,9 +631,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			{
 				if (cnt_words >= (1ull << 32)) return fail(h, DSRCGPU_E_NOMEM, "batch too large for the bucket count table");
 				jobs[i].bk_cnt = (u32)cnt_words;
-				const size_t n_tiles = (jobs[i].n + (size_t)SORT_WG * SORT_ITEMS - 1) / ((size_t)SORT_WG * SORT_ITEMS);
-				const size_t tpb = BK_BIN / (SORT_WG * SORT_ITEMS);
-				cnt_words += ((n_tiles + tpb - 1) / tpb * tpb) << jobs[i].bk_hb;
+				cnt_words += (((size_t)jobs[i].n + BK_BIN - 1) >> BK_TB) << jobs[i].bk_hb;
 			}
 		o_bcnt = A.alloc(cnt_words * 2 + 64);
 	}
@@ -747,31 +743,30 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			stage_mark(0);
 			if (use_bk)
 			{	// k_bucket.h: partition, finish in LDS, place -- and behind them k_sort / k_replay for the streams k_part handed back
-				const bool part_stage = !(getenv("DSRC_GPU_PART_STAGE") && atoi(getenv("DSRC_GPU_PART_STAGE")) == 0);
-				if (part_stage) hipLaunchKernelGGL((k_part<true>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk, d_bcnt);
-				else hipLaunchKernelGGL((k_part<false>), dim3(s_hi - s_lo), dim3(SORT_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk, d_bcnt);
-				KCHK();
-				stage_mark(0); stage_mark(1);
 				u32 slice_bins = 0;
 				for (u32 i = s_lo; i < s_hi; ++i) if (jobs[i].bk_on) slice_bins = std::max(slice_bins, (jobs[i].n + BK_BIN - 1) >> BK_TB);
-				if (bk_binned && slice_bins) { hipLaunchKernelGGL(k_binoff, dim3(slice_bins, s_hi - s_lo), dim3(256), 0, s, d_jobs + s_lo, d_bcnt, d_bk, (u32)(SORT_WG * SORT_ITEMS)); KCHK(); }
+				hipLaunchKernelGGL(k_part, dim3(std::max(1u, slice_bins), s_hi - s_lo), dim3(PART_WG), 0, s, d_jobs + s_lo, lpool, d_d, d_q, d_qp, d_state, d_bk, d_bcnt);
+				KCHK();
+				stage_mark(0); stage_mark(1);
+				if (slice_bins) { hipLaunchKernelGGL(k_binoff, dim3(slice_bins, s_hi - s_lo), dim3(256), 0, s, d_jobs + s_lo, d_bcnt, d_bk); KCHK(); }
 				for (const BkGroup& g : bk_groups[sl])
 				{
 					u32 hb = 0; bool any = false;
 					for (u32 i = g.lo; i < g.hi; ++i) if (jobs[i].bk_on) { any = true; hb = std::max(hb, jobs[i].bk_hb); }
 					if (!any) continue;
 					u32 lbm = 0; for (u32 i = g.lo; i < g.hi; ++i) if (jobs[i].bk_on) lbm = std::max(lbm, jobs[i].bk_lb);
-					const dim3 fgrid(((1u << hb) + MD_WAVES - 1) / MD_WAVES, g.hi - g.lo);
 					// rows by key where a bucket's keys fit (in as little LDS as they need), else handed out on first use through a map
-#define BK_FINISH(NN) { if ((1u << lbm) * 4 * MdRow<NN>::STRIDE <= 4096) hipLaunchKernelGGL((k_model<NN, 0, 4096>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk, d_bcnt, (u32)(SORT_WG * SORT_ITEMS)); \
-						else if ((1u << lbm) * 4 * MdRow<NN>::STRIDE <= MD_ROW_BYTES) hipLaunchKernelGGL((k_model<NN, 0, MD_ROW_BYTES>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk, d_bcnt, (u32)(SORT_WG * SORT_ITEMS)); \
-						else if (lbm <= 10) hipLaunchKernelGGL((k_model<NN, 10, MD_ROW_BYTES>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk, d_bcnt, (u32)(SORT_WG * SORT_ITEMS)); \
-						else hipLaunchKernelGGL((k_model<NN, BK_MAX_LB, MD_ROW_BYTES>), fgrid, dim3(MD_WG), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk, d_bcnt, (u32)(SORT_WG * SORT_ITEMS)); }
+#define BK_LAUNCH(NN, MB, RB) hipLaunchKernelGGL((k_model<NN, MB, RB>), dim3(((1u << hb) + MD_WAVES_FOR(RB) - 1) / MD_WAVES_FOR(RB), g.hi - g.lo), dim3(64 * MD_WAVES_FOR(RB)), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk, d_bcnt)
+#define BK_FINISH(NN) { if ((1u << lbm) * 4 * MdRow<NN>::STRIDE <= 4096) BK_LAUNCH(NN, 0, 4096); \
+						else if ((1u << lbm) * 4 * MdRow<NN>::STRIDE <= MD_ROW_BYTES) BK_LAUNCH(NN, 0, MD_ROW_BYTES); \
+						else if (lbm <= 10) BK_LAUNCH(NN, 10, MD_ROW_BYTES); \
+						else BK_LAUNCH(NN, BK_MAX_LB, MD_ROW_BYTES); }
 					switch (jobs[g.lo].n_alpha)
 					{
 					case 4: BK_FINISH(4) break; case 8: BK_FINISH(8) break; case 16: BK_FINISH(16) break;
 					case 32: BK_FINISH(32) break; case 64: BK_FINISH(64) break; default: BK_FINISH(128) break;
 					}
+#undef BK_LAUNCH
 #undef BK_FINISH
 					KCHK();
 				}

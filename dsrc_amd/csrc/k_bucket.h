@@ -110,193 +110,139 @@ __device__ __forceinline__ void bk_elems8_qua(const CtxJob& j, const BkWin& w, c
 	}
 }
 
-// ---- k_part: stable partition by the top digit of the mixed key ------------------------------------------------------------------
-// One workgroup per stream, tiles of SORT_WG * SORT_ITEMS elements, ranking as in k_sort<.., true>: one LDS atomic per element on
-// the wave's packed counter pair (the path is only taken on devices that passed k_lds_order_test).
-// STAGE: the tile leaves through LDS in bucket order (whole runs per store instruction, 64 KB more LDS) or straight from the registers.
-template <bool STAGE>
-__global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SORT_OCC, SORT_OCC))) k_part(const CtxJob* jobs, u64* pool, const u8* d_stream, const u8* q_stream, const u8* qp_stream, BlkState* st, u32* bk, u16* bcnt)
+// ---- k_part: a tile's elements grouped by the top digit of the mixed key ---------------------------------------------------------------
+// Grid: x = tile (= time bin: BK_BIN consecutive symbols), y = stream of the slice.  The workgroup makes the tile's elements, ranks
+// them by bucket (stable; as in k_sort<.., true>: one LDS atomic per element on the wave's packed counter pair -- the path is only
+// taken on devices that passed k_lds_order_test) and writes them, grouped by bucket, over the tile's own place of the element
+// array: one contiguous 32 KB piece per workgroup, no pass over the stream before it and nothing carried from tile to tile.  The
+// element is 4 bytes -- the bucket is where it lies, the tile is where it lies: what is left is the low key bits, the symbol and
+// the 13 low bits of t.  Per tile the elements per bucket go to `bcnt` (k_binoff turns them into the buckets' offsets inside the tile,
+// which k_model reads the elements by and writes the records by).
+#ifndef PART_ITEMS
+#define PART_ITEMS 16                  // elements per thread (a multiple of 8): the workgroup is BK_BIN / PART_ITEMS = 512 threads with 48 KB of LDS.
+                                       // Next to other instances' kernels a workgroup of 1024 threads and 66 KB waits long for a CU with that much free at once
+                                       // (k_part of 128 streams: 1.4 ms alone, 5.5 ms in the 4-instance bench; with 512 threads 1.0 and 2.9 ms)
+#endif
+#define PART_WG (BK_BIN / PART_ITEMS)
+#define PART_WAVES (PART_WG / 64)
+#define BK_EL_SYM_SHIFT BK_TB
+#define BK_EL_KEY_SHIFT (BK_TB + 7)
+static_assert(BK_EL_KEY_SHIFT + BK_MAX_LB <= 32, "low key bits, symbol and time inside the tile in 32 bits");
+__device__ __forceinline__ u32 bk_keysym(u64 e) { return ((u32)(e >> (ELEM_SYM_SHIFT + 1)) & ~0x7Fu) | ((u32)(e >> ELEM_SYM_SHIFT) & 0x7Fu); }      // mixed key << 7 | symbol
+static_assert(ELEM_CTX_SHIFT == ELEM_SYM_SHIFT + 8, "bk_keysym");
+
+__global__ void __launch_bounds__(PART_WG) k_part(const CtxJob* jobs, u64* pool, const u8* d_stream, const u8* q_stream, const u8* qp_stream, BlkState* st, u32* bk, u16* bcnt)
 {
-	__shared__ u32 s_base[SORT_MAX_BINS];
-	__shared__ u32 s_delta[SORT_MAX_BINS];
-	__shared__ u16 s_cnt[SORT_WAVES][SORT_MAX_BINS];
-	__shared__ u16 s_off[SORT_WAVES][SORT_MAX_BINS];
-	__shared__ u64 s_tile[STAGE ? SORT_WG * SORT_ITEMS : 1];
-	__shared__ u32 s_ws[SORT_WAVES];
+	__shared__ u16 s_cnt[PART_WAVES][SORT_MAX_BINS];           // per wave: elements per bucket, then the wave's offset of the bucket inside the tile
+	__shared__ u32 s_tile[PART_WG * PART_ITEMS];
+	__shared__ u32 s_ws[PART_WAVES];
 	__shared__ u8 s_rank[256];
-	__shared__ u32 s_max;
-	const CtxJob j = jobs[blockIdx.x];
-	if (!j.bk_on) { if (threadIdx.x == 0) bk_fallback(j, bk); return; }
+	constexpr u32 tile_elems = PART_WG * PART_ITEMS;
+	const CtxJob j = jobs[blockIdx.y];
+	if (!j.bk_on) { if (blockIdx.x == 0 && threadIdx.x == 0) bk_fallback(j, bk); return; }
+	const u32 tile = blockIdx.x * tile_elems;
+	if (tile >= j.n) return;
 	const u32 n = j.n, bins = 1u << j.bk_hb, lb = j.bk_lb;
 	const u32 wv = wave_id(), lane = lane_id();
-	constexpr u32 tile_elems = SORT_WG * SORT_ITEMS;
 	const u8* sym_src = (j.is_dna ? d_stream : q_stream) + j.src_off;
 	const u8* qp = qp_stream + j.src_off;
 
 	for (u32 i = threadIdx.x; i < 256; i += blockDim.x) s_rank[i] = (!j.is_dna && j.translate) ? st[j.blk].q_sym[i] : (u8)i;
-	for (u32 i = threadIdx.x; i < bins; i += blockDim.x) s_base[i] = 0;
-	if (threadIdx.x == 0) s_max = 0;
+	for (u32 i = threadIdx.x; i < PART_WAVES * SORT_MAX_BINS / 2; i += blockDim.x) ((u32*)&s_cnt[0][0])[i] = 0;
 	__syncthreads();
-	{	// bucket sizes
-		bool bad = false;
-		u32 i_from = 0;
-		if (bk_fast8(j) && n >= 64)
-		{
-			const u32 n8 = (n - 24) / 8;                                  // groups starting at t0 = 16, 24, ... (the last one ends before n - 8)
-			BkWin wn = bk_load8(j, sym_src, 16 + 8 * (threadIdx.x < n8 ? threadIdx.x : 0u));
-			for (u32 g = threadIdx.x; g < n8; g += blockDim.x)
-			{
-				const BkWin w = wn;
-				const u32 gn = g + blockDim.x < n8 ? g + blockDim.x : g;       // the next group's windows are on their way while this one is counted
-				wn = bk_load8(j, sym_src, 16 + 8 * gn);
-				u64 e8[8];
-				if (j.is_dna) bk_elems8_dna(j, w, 16 + 8 * g, e8, &bad); else bk_elems8_qua(j, w, qp, s_rank, 16 + 8 * g, e8);
-#pragma unroll
-				for (u32 k = 0; k < 8; ++k) atomicAdd(&s_base[(u32)(e8[k] >> (ELEM_CTX_SHIFT + lb))], 1u);
-			}
-			i_from = 16 + 8 * n8;
-			for (u32 i = threadIdx.x; i < 16; i += blockDim.x)
-			{
-				const u64 el = j.is_dna ? ctx_elem_dna(j, sym_src, i, &bad) : ctx_elem_qua(j, sym_src, qp, s_rank, i);
-				atomicAdd(&s_base[(u32)(bk_rekey(j, el) >> (ELEM_CTX_SHIFT + lb))], 1u);
-			}
-		}
-		for (u32 i = i_from + threadIdx.x; i < n; i += blockDim.x)
-		{
-			const u64 el = j.is_dna ? ctx_elem_dna(j, sym_src, i, &bad) : ctx_elem_qua(j, sym_src, qp, s_rank, i);
-			atomicAdd(&s_base[(u32)(bk_rekey(j, el) >> (ELEM_CTX_SHIFT + lb))], 1u);
-		}
-		if (bad) atomicOr(&st[j.blk].err, (u32)DSRC_ERR_REF_UB);
-	}
-	__syncthreads();
-	{	// exclusive scan -> bucket offsets (k_model reads them), largest bucket
-		u32 carry = 0;
-		for (u32 b0 = 0; b0 < bins; b0 += blockDim.x)
-		{
-			const u32 i = b0 + threadIdx.x;
-			const u32 v = i < bins ? s_base[i] : 0;
-			if (v) atomicMax(&s_max, v);
-			u32 tot;
-			const u32 ex = block_excl_scan(v, &tot);
-			if (i < bins) { s_base[i] = carry + ex; bk[j.bk_boff + i] = carry + ex; }
-			carry += tot;
-		}
-		if (threadIdx.x == 0) bk[j.bk_boff + bins] = n;
-	}
-	for (u32 i = threadIdx.x; i < SORT_WAVES * SORT_MAX_BINS; i += blockDim.x) (&s_cnt[0][0])[i] = 0;
-	__syncthreads();
-	if (s_max > j.bk_limit) { if (threadIdx.x == 0) bk_fallback(j, bk); return; }
 
-	u64* dst = pool + j.elems;
-	const u32 shift = ELEM_CTX_SHIFT + lb;
-	const bool fast8 = bk_fast8(j);
-	// inner tiles (every lane makes eight consecutive elements): their windows are requested one tile ahead
-	BkWin wnext; wnext.a = wnext.b = wnext.c = 0;
-	if (STAGE && fast8 && 2 * tile_elems + 8 <= n) wnext = bk_load8(j, sym_src, tile_elems + wv * 64 * SORT_ITEMS + 8 * lane);
-	for (u32 tile = 0; tile < n; tile += tile_elems)
-	{
-		u64 el[SORT_ITEMS]; u32 rk[SORT_ITEMS];
-		const u32 wbase = tile + wv * 64 * SORT_ITEMS;
-		bool bad = false;
-		if (STAGE && SORT_ITEMS == 8 && fast8 && tile > 0 && tile + tile_elems + 8 <= n)
-		{	// an inner tile: every lane makes the elements of eight consecutive symbols, and the wave's 512 elements change places
-			// through its strip of s_tile (unused until the tile is ranked) so that lane l holds elements l, l + 64, ...: the order
-			// the ranking needs
-			u64* strip = s_tile + wv * 64 * SORT_ITEMS;
-			u64 e8[8];
-			const BkWin w = wnext;
-			if (tile + 2 * tile_elems + 8 <= n) wnext = bk_load8(j, sym_src, wbase + tile_elems + 8 * lane);
-			if (j.is_dna) bk_elems8_dna(j, w, wbase + 8 * lane, e8, &bad); else bk_elems8_qua(j, w, qp, s_rank, wbase + 8 * lane, e8);
+	// ks[k]: mixed key << 7 | symbol of element wbase + 64 k + lane
+	u32 ks[PART_ITEMS], rk[PART_ITEMS];
+	const u32 wbase = tile + wv * 64 * PART_ITEMS;
+	bool bad = false;
+	if (bk_fast8(j) && tile > 0 && tile + tile_elems + 8 <= n)
+	{	// an inner tile: every lane makes the elements of eight consecutive symbols, and the wave's 512 elements change places
+		// through its strip of s_tile (unused until the tile is ranked) so that lane l holds elements l, l + 64, ...: the order
+		// the ranking needs
+		u32* strip = s_tile + wv * 64 * PART_ITEMS;
+		static_assert(PART_ITEMS % 8 == 0, "eight consecutive symbols per lane and round");
 #pragma unroll
-			for (u32 k = 0; k < 8; ++k) strip[8 * lane + k] = e8[k];
-			wave_fence();
-#pragma unroll
-			for (u32 k = 0; k < 8; ++k) el[k] = strip[64 * k + lane];
-			wave_fence();
-		}
-		else
+		for (u32 h = 0; h < PART_ITEMS / 8; ++h)
 		{
+			u64 e8[8];
+			const u32 t0 = wbase + 512 * h + 8 * lane;
+			const BkWin w = bk_load8(j, sym_src, t0);
+			if (j.is_dna) bk_elems8_dna(j, w, t0, e8, &bad); else bk_elems8_qua(j, w, qp, s_rank, t0, e8);
 #pragma unroll
-			for (u32 k = 0; k < SORT_ITEMS; ++k)
-			{
-				const u32 i = wbase + k * 64 + lane;
-				el[k] = 0;
-				if (i < n) el[k] = bk_rekey(j, j.is_dna ? ctx_elem_dna(j, sym_src, i, &bad) : ctx_elem_qua(j, sym_src, qp, s_rank, i));
-			}
+			for (u32 k = 0; k < 8; ++k) strip[512 * h + 8 * lane + k] = bk_keysym(e8[k]);
 		}
+		wave_fence();
 #pragma unroll
-		for (u32 k = 0; k < SORT_ITEMS; ++k)
+		for (u32 k = 0; k < PART_ITEMS; ++k) ks[k] = strip[64 * k + lane];
+	}
+	else
+	{
+#pragma unroll
+		for (u32 k = 0; k < PART_ITEMS; ++k)
 		{
 			const u32 i = wbase + k * 64 + lane;
-			const bool valid = i < n;
-			const u32 d = (u32)(el[k] >> shift);
-			const u32 sh = (d & 1u) * 16u;
-			u32 old = 0;
-			if (valid) old = atomicAdd(&((u32*)s_cnt[wv])[d >> 1], 1u << sh);
-			rk[k] = (old >> sh) & 0xFFFFu;
-#ifdef DSRC_EMU_BUILD
-			(void)__ballot(true);                                     // the emulator runs lanes one after the other: keep them in step per k
-#endif
-		}
-		__syncthreads();
-		for (u32 d0 = 0, carry = 0; d0 < bins; d0 += SORT_WG)
-		{
-			const u32 dd = d0 + threadIdx.x;
-			u32 c[SORT_WAVES], tot = 0;
-#pragma unroll
-			for (u32 w = 0; w < SORT_WAVES; ++w) { c[w] = dd < bins ? s_cnt[w][dd] : 0u; tot += c[w]; }
-			const u32 inc = wave_incl_scan_dpp(tot);
-			if (lane == 63) s_ws[wv] = inc;
-			__syncthreads();
-			u32 run = carry + inc - tot;
-			const u32 nws = (bins - d0 + 63) / 64 < SORT_WAVES ? (bins - d0 + 63) / 64 : SORT_WAVES;
-			for (u32 i = 0; i < nws; ++i) { const u32 x = s_ws[i]; run += i < wv ? x : 0u; carry += x; }
-			if (dd < bins)
+			ks[k] = 0;
+			if (i < n)
 			{
-				const u32 g = s_base[dd];
-				bcnt[(u64)j.bk_cnt + (u64)(tile / tile_elems) * bins + dd] = (u16)tot;      // the tile's elements per bucket (k_binoff)
-				s_delta[dd] = g - run; s_base[dd] = g + tot;
-#pragma unroll
-				for (u32 w = 0; w < SORT_WAVES; ++w) { s_off[w][dd] = (u16)run; run += c[w]; s_cnt[w][dd] = 0; }
+				const u64 e = bk_rekey(j, j.is_dna ? ctx_elem_dna(j, sym_src, i, &bad) : ctx_elem_qua(j, sym_src, qp, s_rank, i));
+				ks[k] = bk_keysym(e);
 			}
-			if (d0 + SORT_WG < bins) __syncthreads();
 		}
-		__syncthreads();
-		if (STAGE)
-		{
-#pragma unroll
-			for (u32 k = 0; k < SORT_ITEMS; ++k)
-			{
-				const u32 i = wbase + k * 64 + lane;
-				if (i < n) s_tile[(u32)s_off[wv][(u32)(el[k] >> shift)] + rk[k]] = el[k];
-			}
-			__syncthreads();
-			const u32 tile_n = n - tile < tile_elems ? n - tile : tile_elems;
-#pragma unroll
-			for (u32 k = 0; k < SORT_ITEMS; ++k)
-			{
-				const u32 p = k * SORT_WG + threadIdx.x;
-				if (p < tile_n)
-				{
-					const u64 e = s_tile[p];
-					dst[s_delta[(u32)(e >> shift)] + p] = e;
-				}
-			}
-			if (fast8) __syncthreads();                        // the next tile's strips are s_tile
-		}
-		else
-		{
-#pragma unroll
-			for (u32 k = 0; k < SORT_ITEMS; ++k)
-			{
-				const u32 i = wbase + k * 64 + lane;
-				const u32 d = (u32)(el[k] >> shift);
-				if (i < n) dst[s_delta[d] + (u32)s_off[wv][d] + rk[k]] = el[k];
-			}
-			__syncthreads();                                   // s_off / s_delta are rewritten by the next tile's scan
-		}
-		if (bad) atomicOr(&st[j.blk].err, (u32)DSRC_ERR_REF_UB);
 	}
+	if (bad) atomicOr(&st[j.blk].err, (u32)DSRC_ERR_REF_UB);
+	const u32 shift = 7 + lb;
+#pragma unroll
+	for (u32 k = 0; k < PART_ITEMS; ++k)
+	{
+		const u32 i = wbase + k * 64 + lane;
+		const u32 d = ks[k] >> shift;
+		const u32 sh = (d & 1u) * 16u;
+		u32 old = 0;
+		if (i < n) old = atomicAdd(&((u32*)s_cnt[wv])[d >> 1], 1u << sh);
+		rk[k] = (old >> sh) & 0xFFFFu;
+#ifdef DSRC_EMU_BUILD
+		(void)__ballot(true);                                     // the emulator runs lanes one after the other: keep them in step per k
+#endif
+	}
+	__syncthreads();                                               // the strips are read, the counts are complete
+	for (u32 d0 = 0, carry = 0; d0 < bins; d0 += PART_WG)
+	{
+		const u32 dd = d0 + threadIdx.x;
+		u32 c[PART_WAVES], tot = 0;
+#pragma unroll
+		for (u32 w = 0; w < PART_WAVES; ++w) { c[w] = dd < bins ? s_cnt[w][dd] : 0u; tot += c[w]; }
+		const u32 inc = wave_incl_scan_dpp(tot);
+		if (lane == 63) s_ws[wv] = inc;
+		__syncthreads();
+		u32 run = carry + inc - tot;
+		const u32 nws = (bins - d0 + 63) / 64 < PART_WAVES ? (bins - d0 + 63) / 64 : PART_WAVES;
+		for (u32 i = 0; i < nws; ++i) { const u32 x = s_ws[i]; run += i < wv ? x : 0u; carry += x; }
+		if (dd < bins)
+		{
+			bcnt[(u64)j.bk_cnt + (u64)blockIdx.x * bins + dd] = (u16)tot;      // the tile's elements per bucket (k_binoff)
+#pragma unroll
+			for (u32 w = 0; w < PART_WAVES; ++w) { s_cnt[w][dd] = (u16)run; run += c[w]; }
+		}
+		if (d0 + PART_WG < bins) __syncthreads();
+	}
+	__syncthreads();
+	const u32 lbmask = (1u << lb) - 1u;
+#pragma unroll
+	for (u32 k = 0; k < PART_ITEMS; ++k)
+	{
+		const u32 i = wbase + k * 64 + lane;
+		if (i < n)
+			s_tile[(u32)s_cnt[wv][ks[k] >> shift] + rk[k]] = (((ks[k] >> 7) & lbmask) << BK_EL_KEY_SHIFT) | ((ks[k] & 0x7Fu) << BK_EL_SYM_SHIFT) | (i & (BK_BIN - 1u));
+	}
+	__syncthreads();
+	u32* dst = (u32*)(pool + j.elems) + tile;
+	const u32 tile_n = n - tile < tile_elems ? n - tile : tile_elems;
+	if (tile_n == tile_elems)
+	{
+#pragma unroll
+		for (u32 k = 0; k < PART_ITEMS / 2; ++k) ((u64*)dst)[k * PART_WG + threadIdx.x] = ((const u64*)s_tile)[k * PART_WG + threadIdx.x];      // the array is 8-byte aligned
+	}
+	else for (u32 p = threadIdx.x; p < tile_n; p += PART_WG) dst[p] = s_tile[p];
 }
 
 // ---- k_model: a bucket's model statistics on counter rows in LDS -------------------------------------------------------------------
@@ -313,8 +259,9 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 // is due halves its counters and rebuilds the sums first.
 // The records leave grouped by time bin: the elements of a bin are consecutive (the bucket is in stream order) and go, as a run,
 // to the place k_binoff worked out for this bucket inside the bin's region of the record array.
-#define MD_WG 256
-#define MD_WAVES (MD_WG / 64)
+// waves per workgroup: the LDS a wave needs decides how many waves a CU holds, in steps of a workgroup (measured: 32-symbol rows of
+// 8 KB 2.88 ms with two waves against 3.20 with four; 4-symbol rows of 4 KB 2.11 with four against 2.38 with two)
+#define MD_WAVES_FOR(ROW_BYTES) ((ROW_BYTES) <= 4096 ? 4 : 2)
 #define MD_ROW_BYTES 8192              // counter rows per wave: 64 rows of a 32-symbol alphabet
 #define MD_NONE 0xFFFFFFFFu
 
@@ -416,39 +363,22 @@ template <int N> __device__ __forceinline__ u64 md_code(u32* row, u32 sym)
 	return (u64)f | ((u64)cum << 16) | ((u64)tot << 32);
 }
 
-// the runs of equal time bins in a window of a bucket (stream order, so equal bins are neighbours): lane -> its bin and the lane
-// its run starts at
-__device__ __forceinline__ void md_runs(u32 t, bool valid, u32* bin, u32* head_lane)
-{
-	const u32 lane = lane_id();
-	const u32 b = valid ? t >> BK_TB : 0xFFFFFFFFu;
-	const u32 pb = __shfl_up(b, 1);
-	const bool head = valid && (lane == 0 || b != pb);
-	const u64 hm = __ballot(head);
-	const u64 le = hm & (lanemask_lt() | (1ull << lane));
-	*bin = b;
-	*head_lane = le ? 63u - (u32)__clzll((long long)le) : 0u;
-}
-
-// ---- k_binoff: where a bucket's records of a time bin go ------------------------------------------------------------------------------
-// k_part left the number of elements per (tile, bucket); a time bin is BK_BIN / tile consecutive tiles.  Per bin the exclusive scan
-// over the buckets gives every bucket's place inside the bin's region of the record array (k_model reads it), written over the
-// bin's first count row.  Grid: x = bin, y = stream of the slice; 256 threads, four buckets each.
-__global__ void __launch_bounds__(256) k_binoff(const CtxJob* jobs, u16* bcnt, const u32* bk, u32 tile_elems)
+// ---- k_binoff: where a bucket's elements (and records) of a tile lie ------------------------------------------------------------------
+// k_part left the number of elements per (tile, bucket).  Per tile the exclusive scan over the buckets gives every bucket's place
+// inside the tile, written over the counts.  Grid: x = tile, y = stream of the slice; 256 threads, four buckets each.
+__global__ void __launch_bounds__(256) k_binoff(const CtxJob* jobs, u16* bcnt, const u32* bk)
 {
 	const CtxJob j = jobs[blockIdx.y];
 	const u32 bin = blockIdx.x;
-	if (!j.bk_on || !j.bk_binned || bk[j.jid] || (bin << BK_TB) >= j.n) return;
-	const u32 bins = 1u << j.bk_hb, tpb = BK_BIN / tile_elems;
-	const u32 n_tiles = (j.n + tile_elems - 1) / tile_elems;
-	u16* rows = bcnt + j.bk_cnt + (u64)bin * tpb * bins;
+	if (!j.bk_on || bk[j.jid] || (bin << BK_TB) >= j.n) return;
+	const u32 bins = 1u << j.bk_hb;
+	u16* row = bcnt + j.bk_cnt + (u64)bin * bins;
 	u32 c[4], mine = 0;
 #pragma unroll
 	for (u32 k = 0; k < 4; ++k)
 	{
 		const u32 b = 4 * threadIdx.x + k;
-		c[k] = 0;
-		if (b < bins) for (u32 ti = 0; ti < tpb && bin * tpb + ti < n_tiles; ++ti) c[k] += rows[(u64)ti * bins + b];
+		c[k] = b < bins ? (u32)row[b] : 0u;
 		mine += c[k];
 	}
 	u32 tot;
@@ -457,7 +387,7 @@ __global__ void __launch_bounds__(256) k_binoff(const CtxJob* jobs, u16* bcnt, c
 	for (u32 k = 0; k < 4; ++k)
 	{
 		const u32 b = 4 * threadIdx.x + k;
-		if (b < bins) rows[b] = (u16)run;
+		if (b < bins) row[b] = (u16)run;
 		run += c[k];
 	}
 }
@@ -468,58 +398,118 @@ template <> struct MdMapT<false> { typedef u16 T; static constexpr u32 NONE = 0x
 // Grid: x = bucket / MD_WAVES, y = stream of the launch group (one alphabet size).  MAPBITS = 0: every stream of the group has at
 // most ROWS keys per bucket, key k owns row k; otherwise MAPBITS >= the group's largest bk_lb and rows are handed out on first use.
 // ROW_BYTES: LDS per wave for the rows (the fewer, the more buckets a CU works on at a time).
-#define MD_AHEAD 3                     // windows of a bucket requested ahead of the one being coded
+#ifndef MD_AHEAD
+#define MD_AHEAD 3
+#endif
+//      MD_AHEAD:                     // windows of a bucket requested ahead of the one being coded
 template <int N, int MAPBITS, int ROW_BYTES>
-__global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* pool, RcPack* rec_pool, u32* bk, const u16* bcnt, u32 tile_elems)
+__global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const CtxJob* jobs, const u64* pool, RcPack* rec_pool, u32* bk, const u16* bcnt)
 {
 	constexpr u32 STRIDE = MdRow<N>::STRIDE;
 	constexpr u32 ROWS = ROW_BYTES / (4 * STRIDE);
+	constexpr u32 MD_WAVES = MD_WAVES_FOR(ROW_BYTES);
 	typedef MdMapT<(ROWS <= 127)> Map;
 	typedef typename Map::T map_t;
 	__shared__ map_t s_map[MD_WAVES][1 << MAPBITS];
 	__shared__ unsigned long long s_rows[MD_WAVES][ROW_BYTES / 8];
 	__shared__ u16 s_off[MD_WAVES][BK_MAX_BINS];
+	__shared__ u16 s_num[MD_WAVES][BK_MAX_BINS];
+	__shared__ u8 s_head[MD_WAVES][64];
 	constexpr u32 limit = (1u << 16) - 2u * N;              // MaxAccumulatedValue (src/SymbolCoderRC.h:67): Rescale() before a symbol is coded on a row that has reached it
 	const CtxJob j = jobs[blockIdx.y];
 	const u32 w = wave_id(), lane = lane_id();
 	const u32 bucket = blockIdx.x * MD_WAVES + w;
-	if (!j.bk_on || bucket >= (1u << j.bk_hb) || bk[j.jid]) return;
-	const u32 lo = bk[j.bk_boff + bucket], nb = bk[j.bk_boff + bucket + 1] - lo;
-	if (!nb) return;
-	const u64* src = pool + j.elems + lo;
+	const u32 buckets = 1u << j.bk_hb;
+	if (!j.bk_on || bucket >= buckets || bk[j.jid]) return;
+	const u32* src = (const u32*)(pool + j.elems);
 	RcPack* recs = rec_pool + j.trip;
-	const u32 keys = 1u << j.bk_lb, kmask = keys - 1u;
+	const u32 keys = 1u << j.bk_lb;
 	const bool binned = j.bk_binned != 0;
-	const bool may_rescale = (u32)N + 2u * nb + 128u >= (1u << 16) - 2u * N;
-	map_t* map = s_map[w]; u32* rows = (u32*)s_rows[w]; u16* off = s_off[w];
+	map_t* map = s_map[w]; u32* rows = (u32*)s_rows[w]; u16* off = s_off[w]; u16* num = s_num[w]; u8* head = s_head[w];
 	const u32 n_bins = (j.n + BK_BIN - 1) >> BK_TB;
 
+	// where this bucket's elements lie inside every tile (k_binoff: the offsets of the tile's buckets), and how many
+	u32 nb = 0;
+	for (u32 b = lane; b < n_bins; b += 64)
+	{
+		const u16* row = bcnt + (u64)j.bk_cnt + (u64)b * buckets;
+		const u32 o = row[bucket];
+		const u32 tile_n = j.n - (b << BK_TB) < BK_BIN ? j.n - (b << BK_TB) : BK_BIN;
+		const u32 c = (bucket + 1 < buckets ? (u32)row[bucket + 1] : tile_n) - o;
+		off[b] = (u16)o; num[b] = (u16)c;
+		nb += c;
+	}
+	head[lane] = 0xFFu;
+	for (u32 d = 32; d >= 1; d >>= 1) nb += __shfl_xor(nb, (int)d);
+	if (!nb) return;
+	if (nb > j.bk_limit)
+	{	// a bucket one wave should not walk: the stream goes through k_sort / k_replay (their launches follow this one)
+		if (lane == 0) bk_fallback(j, bk);
+		return;
+	}
+	const bool may_rescale = (u32)N + 2u * nb + 128u >= (1u << 16) - 2u * N;
+	wave_fence();
+
+	// The windows of a bucket: its elements tile by tile (stream order), 64 tiles (a group) at a time: lane k looks at tile g_bin + k,
+	// whose elements take the positions [g_f, g_inc) of the group.  A window is the next 64 positions: the lanes whose tile starts
+	// (or goes on) inside it leave their number at head[position], and a position finds its tile at the nearest head at or below
+	// it.  The last window of a group is short.  -> index into the element array (= into the record array), or MD_NONE
+	u32 g_bin = 0, g_pos = 0, g_tot = 0, left = nb;        // wave-uniform
+	u32 g_inc = 0, g_f = 0;
+	auto load_group = [&]()
+	{
+		const u32 b = g_bin + lane;
+		const u32 c = b < n_bins ? (u32)num[b] : 0u;
+		g_inc = wave_incl_scan_dpp(c); g_f = g_inc - c;
+		g_tot = wave_last(g_inc); g_pos = 0;
+	};
+	load_group();
+	auto next_window = [&]() -> u32
+	{
+		if (!left) return MD_NONE;
+		while (g_pos >= g_tot) { g_bin += 64; load_group(); }
+		const int rel = (int)(g_f - g_pos);
+		if (g_inc > g_f && g_inc > g_pos && rel < 64) head[rel > 0 ? rel : 0] = (u8)lane;
+		wave_fence();
+		const u32 hd = head[lane];
+		wave_fence();
+		head[lane] = 0xFFu;
+		const u64 hm = __ballot(hd != 0xFFu);
+		const u64 le = hm & (lanemask_lt() | (1ull << lane));
+		const u32 hl = le ? 63u - (u32)__clzll((long long)le) : 0u;
+		const u32 k = (u32)__shfl((int)hd, (int)hl) & 63u;
+		const u32 k0 = (u32)__builtin_amdgcn_readfirstlane((int)hd) & 63u;         // position 0 always has a head
+		const u32 f0 = (u32)__builtin_amdgcn_readlane((int)g_f, (int)k0);
+		const u32 r = lane - hl + (hl == 0 ? g_pos - f0 : 0u);
+		const u32 avail = g_tot - g_pos < 64 ? g_tot - g_pos : 64u;
+		const u32 bin = g_bin + k;
+		const u32 idx = lane < avail ? (bin << BK_TB) + (u32)off[bin & (BK_MAX_BINS - 1u)] + r : MD_NONE;
+		g_pos += avail; left -= avail;
+		return idx;
+	};
+
 	// the first windows are on their way while the rows are set up
-	u64 elq[MD_AHEAD];                                      // elq[k]: the elements of window p / 64 + k
+	u32 elq[MD_AHEAD], ixq[MD_AHEAD];                       // the elements of the next windows and where they lie
 #pragma unroll
-	for (u32 k = 0; k < MD_AHEAD; ++k) elq[k] = 64 * k + lane < nb ? src[64 * k + lane] : 0ull;
-	// where this bucket's records go inside every time bin's region (k_binoff)
-	if (binned) for (u32 b = lane; b < n_bins; b += 64) off[b] = bcnt[(u64)j.bk_cnt + (u64)b * (BK_BIN / tile_elems) * (1u << j.bk_hb) + bucket];
+	for (u32 k = 0; k < MD_AHEAD; ++k) { ixq[k] = next_window(); elq[k] = ixq[k] != MD_NONE ? src[ixq[k]] : 0u; }
 	if (MAPBITS) for (u32 i = lane; i < keys; i += 64) map[i] = (map_t)Map::NONE;
 	for (u32 i = lane; i < (MAPBITS ? ROWS : keys) * STRIDE; i += 64) rows[i] = md_init_word<N>(i % STRIDE);      // every counter 1
 	wave_fence();
 
-	// The bucket's records of a time bin are consecutive (stream order): they go to off[bin], off[bin] + 1, ...; carry_*: the bin the
-	// previous window ended in and how many of its records are out.
-	u32 carry_bin = 0xFFFFFFFFu, carry_cnt = 0;
 	u32 n_rows = 0;
 	// the walk in two instantiations: the rescale test costs registers and instructions that only buckets of > 32 K symbols need
 	auto walk = [&](auto resc_tag)
 	{
 	constexpr bool RESC = decltype(resc_tag)::value;
-	for (u32 p = 0; p < nb; p += 64)
+	for (u32 coded = 0; coded < nb;)
 	{
-		const u64 el = elq[0];
-		const u32 i = p + lane;
-		const bool valid = i < nb;
-		const u64 el_new = i + 64 * MD_AHEAD < nb ? src[i + 64 * MD_AHEAD] : 0ull;
+		const u32 el = elq[0], ix = ixq[0];
+		const bool valid = ix != MD_NONE;
+		coded += (u32)__popcll(__ballot(valid));
+		const u32 ix_new = next_window();
+		const u32 el_new = ix_new != MD_NONE ? src[ix_new] : 0u;
 
-		const u32 key = (u32)(el >> ELEM_CTX_SHIFT) & kmask, sym = (u32)(el >> ELEM_SYM_SHIFT) & (u32)(N - 1), t = (u32)el;
+		const u32 key = el >> BK_EL_KEY_SHIFT, sym = (el >> BK_EL_SYM_SHIFT) & (u32)(N - 1);
 		u32 rid = key;
 		if (MAPBITS)
 		{
@@ -535,7 +525,7 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 				n_rows += (u32)__popcll(lm);
 				if (n_rows > ROWS)
 				{	// more contexts in this bucket than rows: the stream goes through k_sort / k_replay (their launches follow this one)
-					if (lane == 0 && atomicExch(&bk[j.jid], 1u) == 0u) { const u32 k = atomicAdd(&bk[j.bk_fb], 1u); bk[j.bk_fb + 1 + k] = j.jid; }
+					if (lane == 0) bk_fallback(j, bk);
 					return;
 				}
 				wave_fence();
@@ -566,20 +556,15 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 #ifdef DSRC_EMU_BUILD
 		(void)__ballot(true);                                         // the emulator runs lanes one after the other: keep them in step per window
 #endif
-		if (binned)
+		// the record takes the element's place (k_place puts the tile in stream order), or goes where it belongs at once
+		if (valid)
 		{
-			u32 bin, hl;
-			md_runs(t, valid, &bin, &hl);
-			u32 in_run = lane - hl;
-			if (hl == 0 && bin == carry_bin) in_run += carry_cnt;
-			if (valid) recs[(bin << BK_TB) + (u32)off[bin] + in_run] = rec | ((u64)(t & (BK_BIN - 1u)) << 48);
-			const u32 last = (nb - p < 64 ? nb - p : 64u) - 1u;              // the window's last element
-			carry_bin = (u32)__shfl(bin, (int)last); carry_cnt = (u32)__shfl(in_run, (int)last) + 1u;
+			if (binned) recs[ix] = rec | ((u64)(el & (BK_BIN - 1u)) << 48);
+			else recs[(ix & ~(BK_BIN - 1u)) | (el & (BK_BIN - 1u))] = rec;
 		}
-		else if (valid) recs[t] = rec;
 #pragma unroll
-		for (u32 k = 0; k + 1 < MD_AHEAD; ++k) elq[k] = elq[k + 1];
-		elq[MD_AHEAD - 1] = el_new;
+		for (u32 k = 0; k + 1 < MD_AHEAD; ++k) { elq[k] = elq[k + 1]; ixq[k] = ixq[k + 1]; }
+		elq[MD_AHEAD - 1] = el_new; ixq[MD_AHEAD - 1] = ix_new;
 	}
 	};
 	if (may_rescale) walk(std::true_type()); else walk(std::false_type());
@@ -587,10 +572,16 @@ __global__ void __launch_bounds__(MD_WG) k_model(const CtxJob* jobs, const u64* 
 
 // ---- k_place: a time bin's records into stream order, in place ------------------------------------------------------------------------
 // Grid: x = time bin, y = stream of the slice.
-#define PLACE_WG 1024
+#ifndef PLACE_WG
+#define PLACE_WG 512
+#endif
+#ifndef PLACE_PASSES
+#define PLACE_PASSES 2                 // the bin's records wait in registers (16 per thread) and go through LDS half a bin at a time: 32 KB, so that a
+#endif                                 // workgroup finds room on a CU next to a k_rc workgroup and other instances' kernels (64 KB: 1.4 ms alone, 2.5 - 3 ms in the bench)
 __global__ void __launch_bounds__(PLACE_WG) k_place(const CtxJob* jobs, RcPack* rec_pool, const u32* bk)
 {
-	__shared__ u64 s_rec[BK_BIN];
+	constexpr u32 PER = BK_BIN / PLACE_WG, HALF = BK_BIN / PLACE_PASSES;
+	__shared__ u64 s_rec[HALF];
 	const CtxJob j = jobs[blockIdx.y];
 	if (!j.bk_on || !j.bk_binned || bk[j.jid]) return;
 	const u32 bin = blockIdx.x;
@@ -598,11 +589,21 @@ __global__ void __launch_bounds__(PLACE_WG) k_place(const CtxJob* jobs, RcPack* 
 	if (t0 >= j.n) return;
 	const u32 cnt = j.n - t0 < BK_BIN ? j.n - t0 : BK_BIN;
 	RcPack* r = rec_pool + j.trip + t0;
-	for (u32 i = threadIdx.x; i < cnt; i += PLACE_WG)
+	u64 v[PER];
+#pragma unroll
+	for (u32 k = 0; k < PER; ++k) v[k] = threadIdx.x + k * PLACE_WG < cnt ? r[threadIdx.x + k * PLACE_WG] : ~0ull;      // no record: a time no pass takes
+#pragma unroll
+	for (u32 p = 0; p < PLACE_PASSES; ++p)
 	{
-		const u64 v = r[i];
-		s_rec[(u32)(v >> 48)] = v & 0xFFFFFFFFFFFFull;
+		const u32 lo = p * HALF;
+#pragma unroll
+		for (u32 k = 0; k < PER; ++k)
+		{
+			const u32 t = (u32)(v[k] >> 48) - lo;
+			if (t < HALF) s_rec[t] = v[k] & 0xFFFFFFFFFFFFull;
+		}
+		__syncthreads();                                               // (first pass: every record of the bin is in some thread's registers by now)
+		for (u32 i = threadIdx.x; i < HALF && lo + i < cnt; i += PLACE_WG) r[lo + i] = s_rec[i];
+		if (p + 1 < PLACE_PASSES) __syncthreads();
 	}
-	__syncthreads();
-	for (u32 i = threadIdx.x; i < cnt; i += PLACE_WG) r[i] = s_rec[i];
 }

@@ -83,7 +83,7 @@ def test_bucket_too_large_for_a_wave(emu, oracle, capfd, monkeypatch):
     assert "2 of 2 streams tried, 1 handed back" in capfd.readouterr().err       # the DNA stream (64 contexts, one of them with most symbols)
 
 
-@pytest.mark.parametrize("env", [{"DSRC_GPU_BUCKETS": "0"}, {"DSRC_GPU_BUCKETS_BINNED": "0"}, {"DSRC_GPU_PART_STAGE": "0"}, {"DSRC_GPU_BUCKETS_MIN": "0"}])
+@pytest.mark.parametrize("env", [{"DSRC_GPU_BUCKETS": "0"}, {"DSRC_GPU_BUCKETS_BINNED": "0"}, {"DSRC_GPU_BUCKETS_MIN": "0"}])
 def test_switches(emu, oracle, env, monkeypatch):
     """The path off; records scattered to stream order by k_model itself (no k_binoff / k_place); k_part storing from the
     registers; and the path on for streams of any length (tiny blocks: most buckets empty)."""

@@ -355,7 +355,7 @@ def test_bucketed_path_hand_backs_and_switches(gpu, oracle, monkeypatch, capfd):
     err = capfd.readouterr().err
     assert "8 of 8 streams tried, 2 handed back" in err, err          # the spread qualities (rows) and the hot block's bases (a bucket > BK_LIMIT); its qualities
                                                                       # (contexts of ~470 k symbols, fourteen rescales each) stay in their buckets
-    for env in ({"DSRC_GPU_BUCKETS": "0"}, {"DSRC_GPU_BUCKETS_BINNED": "0"}, {"DSRC_GPU_PART_STAGE": "0"}):
+    for env in ({"DSRC_GPU_BUCKETS": "0"}, {"DSRC_GPU_BUCKETS_BINNED": "0"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         _check(gpu, oracle, cfg, chunks)
