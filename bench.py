@@ -32,11 +32,11 @@ sys.path.insert(0, ROOT)
 BUF = 8 << 20                     # -b8 (reference default, src/Common.h:156)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 RECS_PER_BLOCK = 22300
-PMC_RC_BYTES_PER_BLOCK = (13.3515e6 * 2 + 13.3427e6) * 1024 / 512   # measured, see roofline.traffic below
-# round 4 (profiles/r04_pmc_b512_p1_bucket.txt, KiB per 512-block batch): k_part, eight launches; k_binoff + k_model<32> + k_model<4> + k_place
-PMC_PART_BYTES_PER_BLOCK = (3.412e6 * 2 + 51.225e6) * 1024 / 512
-PMC_MODEL_BYTES_PER_BLOCK = ((0.419e6 + 8.402e6 + 8.409e6 + 13.355e6) * 2 + 0.835e6 + 18.470e6 + 17.586e6 + 26.691e6) * 1024 / 512
-PMC_ALL_BYTES_PER_BLOCK = 291.8e6 * 1024 / 512      # every compression kernel of the batch: 584 MB per block = 53 x the algorithmic 11.06 MB (round 2: 69 x)
+# round 4 (profiles/r04_pmc_b512_p1_tiles.txt, KiB per 512-block batch; traffic = FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md):
+PMC_RC_BYTES_PER_BLOCK = (13.353e6 * 2 + 1.295e6) * 1024 / 512      # k_rc: the 8-byte records read once, the stream bytes written once
+PMC_PART_BYTES_PER_BLOCK = (1.706e6 * 2 + 14.180e6) * 1024 / 512    # k_part, eight launches
+PMC_MODEL_BYTES_PER_BLOCK = ((0.419e6 + 5.447e6 + 3.741e6 + 13.390e6) * 2 + 0.835e6 + 18.995e6 + 15.006e6 + 26.694e6) * 1024 / 512   # k_binoff + k_model<32> + k_model<4> + k_place
+PMC_ALL_BYTES_PER_BLOCK = 205.6e6 * 1024 / 512      # every compression kernel of the batch: 411 MB per block = 37 x the algorithmic 11.06 MB (round 2: 69 x)
 DECODE_TRAFFIC_PER_BLOCK = 663e6  # HBM bytes per decoded block at -d3 -q2: (FETCH_SIZE + WRITE_SIZE of k_dec_qrc and k_dec_dnarc) x 1 KiB / 2400 blocks (profiles/r03_pmc_decode_b2400.txt)
 MAX_RESIDENT = 3                  # distinct input shards kept in HBM per scheduler instance (2 when N > 1: rank 0 also holds the gathered streams)
 
@@ -622,25 +622,25 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          # L2<->fabric bytes of one k_rc launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), 512-block launch:
-                         # FETCH 13.3515e6 KiB x 2 (gfx950 counts 16 B/lane streaming reads at half) + WRITE 13.3427e6 KiB = 80.1 MB per block,
-                         # i.e. exactly the 8-byte records read once + the 4-byte codes written once (profiles/r02_pmc_b512_p1_d3q2.txt)
-                         "traffic": int(PMC_RC_BYTES_PER_BLOCK * sub_blocks), "kernel": "k_rc (range-coder arithmetic, one lane per stream; followed by k_rc_emit)",
+                         # FETCH 13.353e6 KiB x 2 (gfx950 counts 16 B/lane streaming reads at half) + WRITE 1.295e6 KiB = 56 MB per block,
+                         # i.e. exactly the 8-byte records read once + the stream bytes written once (profiles/r04_pmc_b512_p1_tiles.txt)
+                         "traffic": int(PMC_RC_BYTES_PER_BLOCK * sub_blocks), "kernel": "k_rc (range-coder arithmetic, one lane per stream; its loader waves turn the per-symbol codes into the stream bytes)",
                          "kernel_ms": round(rc_ms, 2), "launch_bytes": int(alg), "batch_ms": round(batch_ms, 2),
-                         "note": "algorithmic bytes = chunk bytes in + block bytes out of one sub-batch launch (SURVEY 8d); kernel_ms = k_rc + k_rc_emit from HIP events on the range-coder stream, measured while other scheduler instances share the GPU (alone: 132 ms)"},
+                         "note": "algorithmic bytes = chunk bytes in + block bytes out of one sub-batch launch (SURVEY 8d); kernel_ms = k_rc from HIP events on the range-coder stream, measured while other scheduler instances share the GPU (alone: 128 ms)"},
         }
         sort_ms = sum(x[3] for x in tm) / max(1, len(tm)); replay_ms = sum(x[4] for x in tm) / max(1, len(tm))
         if sort_ms > 0:
             # the kernel that bounds the THROUGHPUT (k_rc above is the longest launch, but it is hidden behind the other
             # instances' front ends): the context sort.  Same algorithmic bytes per launch group, its own summed HIP-event time
             line["roofline_frontend"] = {
-                "bound": "hbm", "kernel": "k_part (stable partition of a stream's (context key, symbol, t) elements into <= 1024 buckets; all launches of one sub-batch)",
+                "bound": "hbm", "kernel": "k_part (the (context key, symbol, t) elements of every 8192-symbol tile of a stream, grouped by <= 1024 buckets; all launches of one sub-batch)",
                 "achieved": round(alg / (sort_ms / 1e3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(alg / (sort_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5), "kernel_ms": round(sort_ms, 2), "model_ms": round(replay_ms, 2),
                 "launch_bytes": int(alg), "traffic": int(PMC_PART_BYTES_PER_BLOCK * sub_blocks),
                 "model_traffic": int(PMC_MODEL_BYTES_PER_BLOCK * sub_blocks), "all_kernels_traffic": int(PMC_ALL_BYTES_PER_BLOCK * sub_blocks),
-                "note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE of the k_part launches of a 512-block batch / 512 (profiles/r04_pmc_b512_p1_bucket.txt); "
+                "note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE of the k_part launches of a 512-block batch / 512 (profiles/r04_pmc_b512_p1_tiles.txt); "
                         "model_ms / model_traffic = k_binoff + k_model (adaptive counter rows in LDS, one wave per bucket) + k_place (time bins into stream order) of the same sub-batch; "
-                        "all_kernels_traffic: every compression kernel, 53 x the algorithmic bytes (round 2, with the two-pass sort and the scattering replay: 69 x)"}
+                        "all_kernels_traffic: every compression kernel, 37 x the algorithmic bytes (round 2, with the two-pass sort and the scattering replay: 69 x)"}
         decode_line = None
         if args.decode_blocks > 0 and world == 1:
             decode_line = measure_decode(lanes, cfg, args.decode_blocks, total_steps - 1)

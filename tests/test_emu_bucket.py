@@ -76,7 +76,7 @@ def test_hot_contexts_rescale_inside_the_bucket(emu, oracle, capfd, monkeypatch)
 
 
 def test_bucket_too_large_for_a_wave(emu, oracle, capfd, monkeypatch):
-    """A bucket beyond the limit a wave may walk (BK_LIMIT; lowered here): k_part hands the stream back before partitioning."""
+    """A bucket beyond the limit a wave may walk (BK_LIMIT; lowered here): the wave that finds it (k_model adds up its tiles' counts) hands the stream back."""
     monkeypatch.setenv("DSRC_GPU_DEBUG", "1")
     monkeypatch.setenv("DSRC_GPU_BUCKET_LIMIT", "16384")
     check(emu, oracle, _hot(300), [(1, 1, False)])
@@ -85,8 +85,7 @@ def test_bucket_too_large_for_a_wave(emu, oracle, capfd, monkeypatch):
 
 @pytest.mark.parametrize("env", [{"DSRC_GPU_BUCKETS": "0"}, {"DSRC_GPU_BUCKETS_BINNED": "0"}, {"DSRC_GPU_BUCKETS_MIN": "0"}])
 def test_switches(emu, oracle, env, monkeypatch):
-    """The path off; records scattered to stream order by k_model itself (no k_binoff / k_place); k_part storing from the
-    registers; and the path on for streams of any length (tiny blocks: most buckets empty)."""
+    """The path off; records scattered to stream order by k_model itself (no k_place); and the path on for streams of any length (tiny blocks: most buckets empty)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     # (the library reads the switches per batch)

@@ -341,8 +341,8 @@ def test_bucketed_path_alphabet_sizes(gpu, oracle, n_sym):
 
 def test_bucketed_path_hand_backs_and_switches(gpu, oracle, monkeypatch, capfd):
     """Streams the bucketed path hands back to k_sort / k_replay inside a batch of streams it keeps: independent uniform qualities
-    (k_model runs out of counter rows), a context with most of a 4 M-symbol stream (k_part finds a bucket too large for one wave);
-    then the same batch with the path off, with k_model scattering to stream order itself, with k_part storing from registers."""
+    (k_model runs out of counter rows), a context with most of a 4 M-symbol stream (k_model finds a bucket too large for one wave);
+    then the same batch with the path off and with k_model scattering to stream order itself."""
     import random
     from tests.cases import alphabet_fastq
     rng = random.Random(3)
