@@ -475,7 +475,8 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 	auto next_window = [&]() -> u32
 	{
 		if (!left) return MD_NONE;
-		while (g_pos >= g_tot) { g_bin += 64; load_group(); }
+		while (g_pos >= g_tot && g_bin < n_bins) { g_bin += 64; load_group(); }
+		if (g_pos >= g_tot) { left = 0; return MD_NONE; }          // (the counts add up to nb: not reached)
 		const int rel = (int)(g_f - g_pos);
 		if (g_inc > g_f && g_inc > g_pos && rel < 64) head[rel > 0 ? rel : 0] = (u8)lane;
 		wave_fence();
@@ -509,11 +510,13 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 	auto walk = [&](auto resc_tag)
 	{
 	constexpr bool RESC = decltype(resc_tag)::value;
-	for (u32 coded = 0; coded < nb;)
+	for (u32 coded = 0, dry = 0; coded < nb && dry <= MD_AHEAD;)
 	{
 		const u32 el = elq[0], ix = ixq[0];
 		const bool valid = ix != MD_NONE;
-		coded += (u32)__popcll(__ballot(valid));
+		const u32 n_valid = (u32)__popcll(__ballot(valid));
+		coded += n_valid;
+		dry = (n_valid || left) ? 0u : dry + 1u;               // (nothing left and nothing in flight: the counts did not add up -- not reached)
 		const u32 ix_new = next_window();
 		const u32 el_new = ix_new != MD_NONE ? src[ix_new] : 0u;
 
