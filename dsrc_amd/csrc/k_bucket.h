@@ -1,27 +1,30 @@
-// Bucketed context path (round 4): the order-k model statistics of a stream in ONE pass over 8-byte elements in HBM
-// instead of two, and records that leave in runs instead of one 32-byte sector per 8-byte record.
+// Bucketed context path (round 4): the order-k model statistics of a stream without a sort -- 4-byte elements grouped tile by
+// tile, counter rows in LDS -- and records that leave in runs instead of one 32-byte sector per 8-byte record.
 //   TDnaRCOrderModeler::UpdateHash / EncodeSymbol    src/DnaModelerRCO.h:94-131
 //   TQualityModelBase::UpdateHash, TQualityModelExt  src/QualityEncoder.h:77-94,126-151
 //   TSymbolCoderRC::EncodeSymbol/Accumulate/Rescale   src/SymbolCoderRC.h:35-90
 //
 // k_sort + k_replay (k_rc.h) sort a stream's (context, symbol, t) elements by context with two LSD passes through HBM, replay
 // the sorted array and scatter one 8-byte record per symbol to stream order.  Here:
-//   k_part   : ONE stable partition of the elements by the top `hb` bits of a *mixed* context key (key = ctx * odd constant mod
-//              2^K: a bijection, so equal keys <=> equal contexts, and the top bits spread hot neighbourhoods of the context space
-//              over all buckets) into <= 1024 buckets of a few thousand elements -- what pass 0 of k_sort does, on another digit;
+//   k_part   : every tile of BK_BIN = 8192 consecutive symbols is grouped, in place, by the top `hb` bits of a *mixed* context key
+//              (key = ctx * odd constant mod 2^K: a bijection, so equal keys <=> equal contexts, and the top bits spread hot
+//              neighbourhoods of the context space over all buckets): <= 1024 buckets, stable inside a tile; one workgroup per
+//              tile, no pass over the stream before it; the element is 4 bytes (low key bits, symbol, t mod 8192);
+//   k_binoff : per tile the exclusive scan of the elements per bucket: where a bucket's elements lie inside the tile;
 //   k_model  : one WAVE per bucket: the adaptive counter rows of the bucket's contexts live in LDS (the reference's model table,
 //              1/1024 of it at a time) and every symbol is coded on its row with one returning LDS atomic per trie level, in
-//              stream order; the records leave grouped by time bin (t >> BK_TB): a bucket's consecutive records of a bin are
-//              written as one run into the bin's region of the stream's record array (the record carries the low bits of t);
-//   k_place  : one workgroup per (stream, time bin): the bin's 8 K records are put in stream order through LDS, in place.
-// Per symbol that is 8 B written + 8 B read (partition), 8 B + 8 B (model -> bins), 8 B + 8 B (place), all in runs, against
-// 8 + 16 + 8 B in runs plus one 32-byte sector per record before -- and no sort of the bucket at all: the second LSD pass, the
+//              stream order: the wave reads its bucket tile by tile and writes the record of an element over the element's
+//              index in the stream's record array (the record carries the low bits of t);
+//   k_place  : one workgroup per (stream, tile = time bin): the bin's 8 K records are put in stream order through LDS, in place.
+// Per symbol that is 4 B written (elements), 4 B read + 8 B written (model), 8 B + 8 B (place), all in runs, against
+// 8 + 16 + 8 B in runs plus one 32-byte sector per record before -- and no sort at all: the LSD passes, the
 // segmented-scan replay and its seams are replaced by log2(N) LDS atomics per symbol.
 //
 // A wave walks its bucket serially, so a bucket must not grow without bound: a stream with a bucket beyond BK_LIMIT elements (a
 // context that holds a sixth of a 3 M-symbol stream or more), or with more contexts in one bucket than the wave has rows, is handed
-// to k_sort / k_replay_seams / k_replay, whose range-splitting replay is made for exactly that: k_part / k_model append it to
-// the fallback list of its launch group.  Either way the records k_rc reads are the same.
+// to k_sort / k_replay_seams / k_replay, whose range-splitting replay is made for exactly that: k_model appends it to
+// the fallback list of its launch group (k_part: the streams too short or too long for the path).  Either way the records k_rc
+// reads are the same.
 #pragma once
 #include <type_traits>
 #include "k_rc.h"
@@ -36,9 +39,8 @@
 #define BK_MAX_BINS 512                // streams of up to 4 M symbols
 #define BK_HASH_MUL 0x9E3779B1u
 
-// the `bk` pool (u32): [0 .. NJ) fallback flag per job | fallback lists, one per launch group: count, then job ids |
-// bucket offsets (2^hb + 1 per job).  Everything up to the bucket offsets is zeroed per batch.  `bcnt` (u16): per job and tile the
-// elements per bucket (k_part), turned by k_binoff into every bucket's offset inside the time bin's region, in the bin's first row.
+// the `bk` pool (u32): [0 .. NJ) fallback flag per job | fallback lists, one per launch group: count, then job ids; zeroed per
+// batch.  `bcnt` (u16): per job and tile the elements per bucket (k_part), turned by k_binoff into every bucket's offset inside the tile.
 
 __device__ __forceinline__ u64 bk_rekey(const CtxJob& j, u64 el)
 {
