@@ -126,6 +126,9 @@ __device__ __forceinline__ void bk_elems8_qua(const CtxJob& j, const BkWin& w, c
                                        // (k_part of 128 streams: 1.4 ms alone, 5.5 ms in the 4-instance bench; with 512 threads 1.0 and 2.9 ms)
 #endif
 #define PART_WG (BK_BIN / PART_ITEMS)
+#ifndef PART_PASSES
+#define PART_PASSES 1                  // the tile leaves through LDS in this many pieces (two of 16 KB: 32 KB of LDS per workgroup instead of 48 -- no faster, alone or in the bench)
+#endif
 #define PART_WAVES (PART_WG / 64)
 #define BK_EL_SYM_SHIFT BK_TB
 #define BK_EL_KEY_SHIFT (BK_TB + 7)
@@ -136,7 +139,7 @@ static_assert(ELEM_CTX_SHIFT == ELEM_SYM_SHIFT + 8, "bk_keysym");
 __global__ void __launch_bounds__(PART_WG) k_part(const CtxJob* jobs, u64* pool, const u8* d_stream, const u8* q_stream, const u8* qp_stream, BlkState* st, u32* bk, u16* bcnt)
 {
 	__shared__ u16 s_cnt[PART_WAVES][SORT_MAX_BINS];           // per wave: elements per bucket, then the wave's offset of the bucket inside the tile
-	__shared__ u32 s_tile[PART_WG * PART_ITEMS];
+	__shared__ u32 s_tile[BK_BIN / PART_PASSES];                // the tile in bucket order, PART_PASSES pieces one after the other
 	__shared__ u32 s_ws[PART_WAVES];
 	__shared__ u8 s_rank[256];
 	constexpr u32 tile_elems = PART_WG * PART_ITEMS;
@@ -161,21 +164,25 @@ __global__ void __launch_bounds__(PART_WG) k_part(const CtxJob* jobs, u64* pool,
 	{	// an inner tile: every lane makes the elements of eight consecutive symbols, and the wave's 512 elements change places
 		// through its strip of s_tile (unused until the tile is ranked) so that lane l holds elements l, l + 64, ...: the order
 		// the ranking needs
-		u32* strip = s_tile + wv * 64 * PART_ITEMS;
 		static_assert(PART_ITEMS % 8 == 0, "eight consecutive symbols per lane and round");
+		static_assert(PART_WAVES * 512 <= BK_BIN / PART_PASSES, "a strip of 512 elements per wave");
+		u32* strip = s_tile + wv * 512;
+		BkWin w = bk_load8(j, sym_src, wbase + 8 * lane);
 #pragma unroll
 		for (u32 h = 0; h < PART_ITEMS / 8; ++h)
-		{
+		{	// 512 consecutive elements of the wave per round (the next round's windows are on their way)
 			u64 e8[8];
 			const u32 t0 = wbase + 512 * h + 8 * lane;
-			const BkWin w = bk_load8(j, sym_src, t0);
-			if (j.is_dna) bk_elems8_dna(j, w, t0, e8, &bad); else bk_elems8_qua(j, w, qp, s_rank, t0, e8);
+			const BkWin wc = w;
+			if (h + 1 < PART_ITEMS / 8) w = bk_load8(j, sym_src, t0 + 512);
+			if (j.is_dna) bk_elems8_dna(j, wc, t0, e8, &bad); else bk_elems8_qua(j, wc, qp, s_rank, t0, e8);
+			if (h) wave_fence();
 #pragma unroll
-			for (u32 k = 0; k < 8; ++k) strip[512 * h + 8 * lane + k] = bk_keysym(e8[k]);
+			for (u32 k = 0; k < 8; ++k) strip[8 * lane + k] = bk_keysym(e8[k]);
+			wave_fence();
+#pragma unroll
+			for (u32 k = 0; k < 8; ++k) ks[8 * h + k] = strip[64 * k + lane];
 		}
-		wave_fence();
-#pragma unroll
-		for (u32 k = 0; k < PART_ITEMS; ++k) ks[k] = strip[64 * k + lane];
 	}
 	else
 	{
@@ -229,22 +236,32 @@ __global__ void __launch_bounds__(PART_WG) k_part(const CtxJob* jobs, u64* pool,
 	}
 	__syncthreads();
 	const u32 lbmask = (1u << lb) - 1u;
-#pragma unroll
-	for (u32 k = 0; k < PART_ITEMS; ++k)
-	{
-		const u32 i = wbase + k * 64 + lane;
-		if (i < n)
-			s_tile[(u32)s_cnt[wv][ks[k] >> shift] + rk[k]] = (((ks[k] >> 7) & lbmask) << BK_EL_KEY_SHIFT) | ((ks[k] & 0x7Fu) << BK_EL_SYM_SHIFT) | (i & (BK_BIN - 1u));
-	}
-	__syncthreads();
 	u32* dst = (u32*)(pool + j.elems) + tile;
 	const u32 tile_n = n - tile < tile_elems ? n - tile : tile_elems;
-	if (tile_n == tile_elems)
+	constexpr u32 PIECE = BK_BIN / PART_PASSES;
+	// where every element goes inside the tile (the ranks' registers are free now)
+#pragma unroll
+	for (u32 k = 0; k < PART_ITEMS; ++k) rk[k] += (u32)s_cnt[wv][ks[k] >> shift];
+#pragma unroll
+	for (u32 p = 0; p < PART_PASSES; ++p)
 	{
 #pragma unroll
-		for (u32 k = 0; k < PART_ITEMS / 2; ++k) ((u64*)dst)[k * PART_WG + threadIdx.x] = ((const u64*)s_tile)[k * PART_WG + threadIdx.x];      // the array is 8-byte aligned
+		for (u32 k = 0; k < PART_ITEMS; ++k)
+		{
+			const u32 i = wbase + k * 64 + lane;
+			const u32 at = rk[k] - p * PIECE;
+			if (i < n && at < PIECE)
+				s_tile[at] = (((ks[k] >> 7) & lbmask) << BK_EL_KEY_SHIFT) | ((ks[k] & 0x7Fu) << BK_EL_SYM_SHIFT) | (i & (BK_BIN - 1u));
+		}
+		__syncthreads();
+		if (tile_n == tile_elems)
+		{
+#pragma unroll
+			for (u32 k = 0; k < PIECE / 2 / PART_WG; ++k) ((u64*)(dst + p * PIECE))[k * PART_WG + threadIdx.x] = ((const u64*)s_tile)[k * PART_WG + threadIdx.x];      // the array is 8-byte aligned
+		}
+		else for (u32 q = threadIdx.x; q < PIECE && p * PIECE + q < tile_n; q += PART_WG) dst[p * PIECE + q] = s_tile[q];
+		if (p + 1 < PART_PASSES) __syncthreads();
 	}
-	else for (u32 p = threadIdx.x; p < tile_n; p += PART_WG) dst[p] = s_tile[p];
 }
 
 // ---- k_model: a bucket's model statistics on counter rows in LDS -------------------------------------------------------------------

@@ -72,7 +72,7 @@ def test_hot_contexts_rescale_inside_the_bucket(emu, oracle, capfd, monkeypatch)
         for i in range(260):
             q = bytes(33 + (vals[rng.randrange(n_vals)] if rng.random() < 0.03 else vals[-1]) for _ in range(200))
             recs.append(b"@q.%d\n" % i + bytes(rng.choice(b"ACGT") for _ in range(200)) + b"\n+\n" + q)
-        check(emu, oracle, b"\n".join(recs), [(2, 2, False), (1, 1, False)])
+        check(emu, oracle, b"\n".join(recs), [(2, 2, False)] if n_vals != 40 else [(1, 1, False)])
 
 
 def test_bucket_too_large_for_a_wave(emu, oracle, capfd, monkeypatch):
