@@ -2,7 +2,7 @@
 // used by dsrc_amd/csrc, so that the kernel *logic* (indexing, scans, ballots,
 // LDS protocols, bit packing) can be exercised by the CPU test-suite in a
 // container that has no GPU.  One workgroup runs at a time; its threads are
-// ucontext coroutines that yield at __syncthreads() and at wave-level
+// coroutines (a register-only context switch: no signal-mask system calls) that yield at __syncthreads() and at wave-level
 // exchanges (__ballot/__shfl*), which complete when every live lane of the
 // 64-wide wave has arrived (kernels only use them in wave-uniform control flow).
 //
@@ -11,7 +11,6 @@
 // on the include path.  It is not a fallback and is not shipped in libdsrc_gpu.so.
 #pragma once
 
-#include <ucontext.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -30,9 +29,10 @@ struct dim3
 
 namespace emu
 {
+struct Ctx { void* sp; };       // a suspended coroutine: its stack pointer (the callee-saved registers are on its stack)
 struct Thread
 {
-	ucontext_t ctx;
+	Ctx ctx;
 	std::vector<char> stack;
 	int state;               // 0 run, 1 at barrier, 2 at wave op, 3 done
 	uint64_t deposit;
@@ -41,7 +41,7 @@ struct Thread
 };
 extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 extern Thread* g_cur;
-extern ucontext_t g_sched;
+extern Ctx g_sched;
 void yield_to_scheduler();
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 uint64_t wave_exchange(uint64_t v, uint64_t out[64]);   // returns active mask
