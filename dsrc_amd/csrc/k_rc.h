@@ -915,8 +915,9 @@ __device__ __forceinline__ u32 rc_div(u32 range, u32 m_lo, u32 m_hi)
 
 struct RcState { u64 low; u32 range; };
 
-// fast step: returns the symbol's code = top three bytes of low (bits 31..8) | bytes leaving (0..2: range' >= 2^8
-// because range >= 2^24 and total <= 2^16); `flag` collects the clamp pre-condition as a running 16-bit maximum
+// fast step: returns the symbol's code = top three bytes of low (bits 31..8) | 8 * bytes leaving (0..2: range' >= 2^8
+// because range >= 2^24 and total <= 2^16); `flag` collects the clamp pre-condition as a running maximum of bits 8..39 of low
+// (its top half is the maximum of bits 24..39: one alignbit per symbol, no mask; the count stays multiplied by 8: no shift)
 __device__ __forceinline__ u32 rc_step_fast(RcState& s, const RcRec& e, u32& flag)
 {
 	const u32 r = rc_div(s.range, e.m_lo, e.mf >> 16);
@@ -925,11 +926,11 @@ __device__ __forceinline__ u32 rc_step_fast(RcState& s, const RcRec& e, u32& fla
 	__builtin_assume(range != 0);
 	const u32 lz = (u32)__builtin_clz(range);
 	const u32 k8 = lz & 0x18u;                                             // 8 * bytes leaving
-	const u32 z = (u32)(low >> 24) & 0xFFFFu;                              // bits 24..39 all ones <=> z == 0xFFFF
+	const u32 z = __builtin_amdgcn_alignbit((u32)(low >> 32), (u32)low, 8);     // bits 24..39 all ones <=> z >> 16 == 0xFFFF
 	flag = z > flag ? z : flag;
 	s.low = low << k8;
 	s.range = range << k8;
-	return ((u32)(low >> 32) & 0xFFFFFF00u) | (lz >> 3);
+	return ((u32)(low >> 32) & 0xFFFFFF00u) | k8;
 }
 
 // exact step: RangeEncoder::EncodeFrequency, verbatim; bytes go to the lane's LDS buffer
@@ -964,11 +965,11 @@ __device__ __forceinline__ RcRec rc_rec(const RcRegs& g, u32 i)
 __device__ __forceinline__ void rc_group(RcState& s, LDS_AS u32* codes, const RcRegs& g, const LDS_AS U4* row, u32 grp, u8* xb, u32* err, u32 force_exact)
 {
 	const RcState snap = s;
-	u32 zmax = force_exact ? 0xFFFFu : 0u;
+	u32 zmax = force_exact ? 0xFFFF0000u : 0u;
 	u32 c[RC_GROUP];
 #pragma unroll
 	for (u32 i = 0; i < RC_GROUP; ++i) c[i] = rc_step_fast(s, rc_rec(g, i), zmax);
-	if (zmax == 0xFFFFu)
+	if ((zmax >> 16) == 0xFFFFu)
 	{	// the reference's loop on the same 16 records; its bytes are dealt out three per code slot, in order
 		s = snap;
 		const LDS_AS u32* d = (const LDS_AS u32*)row + 3 * RC_GROUP * grp;
@@ -983,7 +984,7 @@ __device__ __forceinline__ void rc_group(RcState& s, LDS_AS u32* codes, const Rc
 		for (u32 i = 0; i < RC_GROUP; ++i)
 		{
 			const u32 have = nb > 3 * i ? nb - 3 * i : 0u, take = have < 3 ? have : 3u;
-			c[i] = ((u32)xb[3 * i] << 24) | ((u32)xb[3 * i + 1] << 16) | ((u32)xb[3 * i + 2] << 8) | take;
+			c[i] = ((u32)xb[3 * i] << 24) | ((u32)xb[3 * i + 1] << 16) | ((u32)xb[3 * i + 2] << 8) | (take << 3);
 		}
 	}
 #pragma unroll
@@ -1073,7 +1074,7 @@ __device__ __forceinline__ void rc_emit_chunk(const LDS_AS u32* codes, RcEmitRow
 	{
 		const u32 j = lw + k * RC_LOADERS;
 		v[k] = codes[(j < n_live ? j : 0u) * RC_CODE_PITCH + lane];
-		kb[k] = j < n_live && t < R.n_full[k] ? v[k] & 3u : 0u;
+		kb[k] = j < n_live && t < R.n_full[k] ? (v[k] >> 3) & 3u : 0u;      // the code's low byte is 8 * bytes
 	}
 #pragma unroll
 	for (u32 k = 0; k < RC_LANES / RC_LOADERS; ++k) inc[k] = wave_incl_scan_dpp(kb[k]);
