@@ -626,7 +626,7 @@ def main():
                          # i.e. exactly the 8-byte records read once + the stream bytes written once (profiles/r04_pmc_b512_p1_tiles.txt)
                          "traffic": int(PMC_RC_BYTES_PER_BLOCK * sub_blocks), "kernel": "k_rc (range-coder arithmetic, one lane per stream; its loader waves turn the per-symbol codes into the stream bytes)",
                          "kernel_ms": round(rc_ms, 2), "launch_bytes": int(alg), "batch_ms": round(batch_ms, 2),
-                         "note": "algorithmic bytes = chunk bytes in + block bytes out of one sub-batch launch (SURVEY 8d); kernel_ms = k_rc from HIP events on the range-coder stream, measured while other scheduler instances share the GPU (alone: 128 ms)"},
+                         "note": "algorithmic bytes = chunk bytes in + block bytes out of one sub-batch launch (SURVEY 8d); kernel_ms = k_rc from HIP events on the range-coder stream, measured while other scheduler instances share the GPU (alone: 118 ms)"},
         }
         sort_ms = sum(x[3] for x in tm) / max(1, len(tm)); replay_ms = sum(x[4] for x in tm) / max(1, len(tm))
         if sort_ms > 0:

@@ -884,7 +884,8 @@ struct RcChain
 #define RC_CHUNK 64                    // symbols per chain per LDS chunk (768 B = 48 lanes x 16 B)
 #define RC_ROW_U4 49                   // LDS row pitch in 16-byte units: 48 of data + 1 so that a 16-lane ds_read_b128 pass covers all 64 banks
 #ifndef RC_LOADERS
-#define RC_LOADERS 4                   // loader waves per workgroup (each feeds RC_LANES / RC_LOADERS rows)
+#define RC_LOADERS 8                   // loader waves per workgroup (each feeds RC_LANES / RC_LOADERS rows; with the bytes written by the loaders four of them
+                                       // are what the coder waits for: k_rc 128.2 ms with four, 118.6 with eight)
 #endif
 // Waves of a k_rc workgroup.  A workgroup's waves go round the CU's four SIMDs in order: wave 0 (the coder) keeps its SIMD to itself
 // when the waves 4, 8, ... leave at once (RC_SPARE_SIMD) -- the coder is bound by the VALU of its SIMD, every cycle a loader spends
