@@ -409,7 +409,7 @@ def main():
         dist_.init_process_group("nccl", device_id=torch.device("cuda", local))
         dist = dist_
 
-    from tests._oracle import Config
+    from dsrc_amd.config import Config
     cfg = Config.from_levels(args.dna, args.qua)
     P = max(1, args.pipeline)
     sub_blocks = max(1, args.blocks // P)

@@ -23,6 +23,7 @@ EXPORTS = [
     "dsrcgpu_decompress_block", "dsrcgpu_decompress_batch", "dsrcgpu_decompress_batch_device",
     "dsrcgpu_title_fields", "dsrcgpu_fields_capacity_after", "dsrcgpu_set_fields_capacity", "dsrcgpu_get_fields_capacity",
     "dsrcgpu_chain_seed", "dsrcgpu_last_stage_timing", "dsrcgpu_try_collect", "dsrcgpu_prepare", "dsrcgpu_set_table_budget", "dsrcgpu_device_memory", "dsrcgpu_release_memory",
+    "dsrcgpu_synth_fastq",
 ]
 
 
@@ -274,7 +275,7 @@ class Handle:
         self._chk(self.L.dsrcgpu_dev_download(self.h, buf, C.c_void_p(d_src), C.c_uint64(nbytes)))
         return bytes(buf)
 
-    def synth_illumina(self, first: int, count: int, d_out: int, cap: int) -> int:
+    def synth_illumina(self, first: int, count: int, d_out: int, cap: int, binned: bool = False) -> int:
         n = C.c_uint64()
-        self._chk(self.L.dsrcgpu_synth_illumina(self.h, C.c_uint64(first), C.c_uint64(count), C.c_void_p(d_out), C.c_uint64(cap), C.byref(n)))
+        self._chk(self.L.dsrcgpu_synth_fastq(self.h, C.c_uint32(1 if binned else 0), C.c_uint64(first), C.c_uint64(count), C.c_void_p(d_out), C.c_uint64(cap), C.byref(n)))
         return n.value

@@ -42,6 +42,19 @@
 namespace
 {
 
+// Environment switches.  The product reads four, all documented in INTEGRATION.md section 4: DSRC_GPU_DEBUG (1: arena use per batch,
+// 2: + the host-side stage timeline), DSRC_GPU_TRACE (roctx ranges around the batch stages), DSRC_GPU_QUEUE_LANES (1: one scheduler
+// lane per handle in the queue form), DSRC_GPU_DEC_TABLE_MB (HBM for the decoder's model tables) -- and GPU_MAX_HW_QUEUES in
+// dsrcgpu_prepare.  Everything else is a TEST HOOK that forces a path the library otherwise chooses by itself (the ballot ranking,
+// the reference loop of the range coder, the sort-and-replay front end, the one-lane decoders ...): compiled in only with
+// -DDSRC_GPU_TEST_HOOKS, i.e. in tests/emu/libdsrc_emu.so and in dsrc_amd/csrc/libdsrc_gpu_hooks.so, which only tests/ load.
+#ifdef DSRC_GPU_TEST_HOOKS
+const char* hook_env(const char* name) { return getenv(name); }
+#else
+const char* hook_env(const char*) { return nullptr; }
+#endif
+long hook_int(const char* name, long dflt) { const char* v = hook_env(name); return v ? atol(v) : dflt; }
+
 struct Arena
 {
 	u8* base = nullptr;
@@ -86,7 +99,7 @@ struct dsrcgpu_chain
 	bool failed = false;
 };
 
-static thread_local bool tl_queue_lane = false;      // this thread is a scheduler lane of the queue form calling the batch entry point
+static thread_local int tl_queue_lane = 0;           // this thread is a scheduler lane of the queue form running a batch: 1 the handle's only lane, 2 one of two
 
 struct dsrcgpu_handle
 {
@@ -98,7 +111,8 @@ struct dsrcgpu_handle
 	Arena arena;
 	u64 arena_fixed = 0;
 	u32 fields_cap = 0;              // capacity of the reference's TagStats::fields vector, carried block to block
-	std::vector<u32> rec_chunk_sizes; // dsrcgpu_set_record_layout: applies to the next batch, then cleared
+	std::vector<u32> rec_pending;    // dsrcgpu_set_record_layout: taken (under q_m) by the next batch call or the next flush, whichever comes first;
+	                                 // from there it travels with that batch as a per-call argument -- no scheduler thread ever touches this field
 	dsrcgpu_chain* chain = nullptr;  // if set: fields_cap comes from / goes to the chain, in batch order
 	uint64_t chain_seq = 0; bool chain_taken = false; u32 chain_cap_in = 0;
 	bool chain_batch_done = true;    // the batch announced by dsrcgpu_set_chain has run to completion
@@ -114,6 +128,7 @@ struct dsrcgpu_handle
 	// with its own arena and streams), so that the range coder of batch i -- 130 ms on a handful of CUs -- overlaps the copies and the
 	// front end of batch i + 1.  What DSRC carries from block to block goes from lane to lane through `q_chain`, in flush order.
 	dsrcgpu_handle* twin = nullptr; dsrcgpu_chain* q_chain = nullptr; std::thread q_thread2; uint64_t q_seq = 0; bool q_lanes_decided = false;
+	bool q_user_batch = false;       // (q_m) a batch call by the user has advanced h->fields_cap since the last flush: the next flush hands it to the lanes' chain
 	int q_rc = 0; std::string q_err;                                 // first failure of the scheduler thread (sticky)
 	float batch_ms = 0.f, rc_ms = 0.f, verify_ms = 0.f;
 	u32 rc_launches = 0;
@@ -146,7 +161,7 @@ int ensure_arena(dsrcgpu_handle* h, size_t need)
 {
 	// debugging aid: DSRC_GPU_DEBUG_FILL=<byte> fills the arena before every batch -- an output that changes with the byte
 	// means some kernel reads arena bytes nobody wrote
-	const char* fill = getenv("DSRC_GPU_DEBUG_FILL");
+	const char* fill = hook_env("DSRC_GPU_DEBUG_FILL");
 	if (h->arena.cap >= need) { h->arena.top = 0; h->arena.failed = false; if (fill) HIPCHK(hipMemsetAsync(h->arena.base, atoi(fill), h->arena.cap, h->stream)); return 0; }
 	if (h->arena_fixed && need > h->arena_fixed)
 		return fail(h, DSRCGPU_E_NOMEM, "batch needs %zu bytes of HBM scratch, arena is fixed at %llu", need, (unsigned long long)h->arena_fixed);
@@ -182,6 +197,7 @@ struct BatchIO
 	u8* d_out; u64 out_cap;          // device output (nullptr => arena-allocated, copied to host_out)
 	u8* host_out; u64 host_cap;
 	u64* out_offs; u64* out_sizes; u64* raw; u64* comp;
+	const std::vector<u32>* layout = nullptr;     // dsrcgpu_set_record_layout of this batch (empty / null: chunks cut from a file)
 };
 
 template <typename T> T* AP(dsrcgpu_handle* h, size_t off) { return (T*)(h->arena.base + off); }
@@ -209,11 +225,13 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	DsrcParams prm;
 	prm.dna_order = dna_order; prm.quality_order = qo; prm.lossy = lossy; prm.crc = crc; prm.tag_flags = (u32)h->set.tag_preserve_flags;
 	prm.quality_offset = h->ds.quality_offset; prm.n_blocks = B; prm.max_tiles = 1;
-	prm.record_layout = h->rec_chunk_sizes.empty() ? 0u : 1u;
+	static const std::vector<u32> no_layout;
+	const std::vector<u32>& layout = io.layout ? *io.layout : no_layout;
+	prm.record_layout = layout.empty() ? 0u : 1u;
 	prm.color_space = h->ds.color_space ? 1u : 0u;
 	if (prm.color_space && (prm.record_layout || prm.tag_flags))
 		return fail(h, DSRCGPU_E_ARG, "colour space cannot be combined with the field filter or the record layout on the GPU path");
-	if (prm.record_layout && (h->rec_chunk_sizes.size() != B || prm.tag_flags || crc))
+	if (prm.record_layout && (layout.size() != B || prm.tag_flags || crc))
 		return fail(h, DSRCGPU_E_ARG, "record layout: one chunkSize per chunk of the batch, no field filter, no CRC (src/DsrcArchive.cpp:33-47)");
 
 	std::vector<BlkDesc> desc(B);
@@ -224,7 +242,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	{
 		if (io.sizes[b] == 0 || io.sizes[b] >= (1ull << 31)) return fail(h, DSRCGPU_E_ARG, "chunk %u: size %llu out of range", b, (unsigned long long)io.sizes[b]);
 		desc[b].in_off = io.offs[b]; desc[b].in_size = (u32)io.sizes[b];
-		if (prm.record_layout) desc[b].chunk_size_value = h->rec_chunk_sizes[b];
+		if (prm.record_layout) desc[b].chunk_size_value = layout[b];
 		desc[b].n_tiles = (u32)((io.sizes[b] + DSRC_TILE_BYTES - 1) / DSRC_TILE_BYTES);
 		prm.max_tiles = std::max(prm.max_tiles, desc[b].n_tiles);
 		in_total += io.sizes[b];
@@ -326,22 +344,28 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		if (h->chain->failed) { turn.published = true; return fail(h, DSRCGPU_E_STATE, "an earlier batch of the chain failed"); }
 		h->chain_cap_in = h->chain->fields_cap; h->chain_taken = true;
 	}
-	if (h->chain) h->fields_cap = h->chain_cap_in;
-	else turn.published = true;
+	// The fold runs on a working copy.  A scheduler lane of the queue form leaves h->fields_cap alone: lane 0 IS the user's handle, and
+	// its view of the state is written by whichever lane completes a batch, under q_m (queue_thread) -- never from here, where the
+	// other lane's completion could land between two steps of the fold.
+	u32 fcap = h->chain ? h->chain_cap_in : h->fields_cap;
+	if (!h->chain) turn.published = true;
 	for (u32 b = 0; b < B; ++b)
 	{	// TagStats::fields capacity emulation (see oracle/dsrc_oracle.c tags_init)
-		u32 cap = h->fields_cap; int last = -1;
+		u32 cap = fcap; int last = -1;
 		for (u32 i = 0; i < st[b].n_fields; ++i) if (i == cap) { last = (int)i; cap = cap ? cap * 2 : 1; }
 		desc[b].fields_keep_from = last < 0 ? 0u : (u32)last;
-		h->fields_cap = cap;
+		fcap = cap;
 	}
+	if (tl_queue_lane != 2) h->fields_cap = fcap;
 	if (h->chain && !turn.published)
 	{
 		std::lock_guard<std::mutex> g(h->chain->m);
-		if (h->chain->next_seq == h->chain_seq) { h->chain->fields_cap = h->fields_cap; h->chain->next_seq = h->chain_seq + 1; }
+		if (h->chain->next_seq == h->chain_seq) { h->chain->fields_cap = fcap; h->chain->next_seq = h->chain_seq + 1; }
 		turn.published = true;
 		h->chain->cv.notify_all();
 	}
+	// (test hook, timing only: the batch stays busy after it has published its state -- what a large batch does anyway)
+	if (const long hold_ms = hook_int("DSRC_GPU_HOOK_BATCH_HOLD_MS", 0)) std::this_thread::sleep_for(std::chrono::milliseconds(hold_ms));
 
 	for (u32 b = 0; b < B; ++b)
 	{
@@ -518,7 +542,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		// flight stay within the memory-side cache) and k_rc streams it through LDS.  The 64 chains of a k_rc wave
 		// are one pitch apart (a multiple of 4 records: rows stay 16-byte aligned); k_rc's DMA may read RC_OVERREAD
 		// records past the longest chain of its wave.
-		const u32 force_exact = getenv("DSRC_GPU_FORCE_EXACT_RC") ? 1u : 0u;             // tests only (read per batch)
+		const u32 force_exact = hook_env("DSRC_GPU_FORCE_EXACT_RC") ? 1u : 0u;           // tests only (read per batch)
 		size_t trip_words = 0;
 		std::vector<size_t> cbase(NJ + 1, 0); std::vector<u32> cpitch(NJ + 1, 0);
 		for (u32 g = 0; g < NJ; g += RC_LANES)
@@ -551,7 +575,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	// the range coder has run is the record array, which keeps many more blocks in flight per GiB of HBM.
 	std::vector<u32> slice_lo;
 	{
-		const char* env = getenv("DSRC_GPU_SORT_SLICE_MB");
+		const char* env = hook_env("DSRC_GPU_SORT_SLICE_MB");
 		// ~128 streams of an 8 MiB chunk per slice.  Larger slices (one k_sort workgroup per CU) are no faster for one
 		// instance, and with several instances sharing the GPU shorter launches interleave better (measured: 14 GiB
 		// 17.5, 7 GiB 19.6, 3.5 GiB 19.0 GB/s with four instances)
@@ -584,13 +608,13 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	// streams of one alphabet size inside a slice) a fallback list that k_part fills with the streams it hands back to k_sort / k_replay
 	struct BkGroup { u32 lo, hi, fb; };
 	std::vector<std::vector<BkGroup> > bk_groups(slice_lo.size());
-	const bool bk_enabled = !(getenv("DSRC_GPU_BUCKETS") && atoi(getenv("DSRC_GPU_BUCKETS")) == 0);
-	const u32 bk_min = getenv("DSRC_GPU_BUCKETS_MIN") ? (u32)atoi(getenv("DSRC_GPU_BUCKETS_MIN")) : 16384u;   // shorter streams: a bucket per workgroup does not pay
-	const bool bk_binned = !(getenv("DSRC_GPU_BUCKETS_BINNED") && atoi(getenv("DSRC_GPU_BUCKETS_BINNED")) == 0);
+	const bool bk_enabled = hook_int("DSRC_GPU_BUCKETS", 1) != 0;
+	const u32 bk_min = (u32)hook_int("DSRC_GPU_BUCKETS_MIN", 16384);   // shorter streams: a bucket per workgroup does not pay
+	const bool bk_binned = hook_int("DSRC_GPU_BUCKETS_BINNED", 1) != 0;
 	// elements per bucket the bucket digit aims at (a wave walks its bucket serially; longer buckets give longer runs per time bin)
-	const u64 bk_elems_dna = getenv("DSRC_GPU_BUCKET_ELEMS_DNA") ? (u64)atol(getenv("DSRC_GPU_BUCKET_ELEMS_DNA")) : 4096u;      // 512 buckets of 6.5 k bases: 512 rows of 8 bytes per wave, runs of 16 records per time bin
-	const u64 bk_elems_qua = getenv("DSRC_GPU_BUCKET_ELEMS_QUA") ? (u64)atol(getenv("DSRC_GPU_BUCKET_ELEMS_QUA")) : 2048u;
-	const u32 bk_limit = getenv("DSRC_GPU_BUCKET_LIMIT") ? (u32)atol(getenv("DSRC_GPU_BUCKET_LIMIT")) : (u32)BK_LIMIT;      // tests
+	const u64 bk_elems_dna = 4096u;      // 512 buckets of 6.5 k bases: 512 rows of 8 bytes per wave, runs of 16 records per time bin
+	const u64 bk_elems_qua = 2048u;
+	const u32 bk_limit = (u32)hook_int("DSRC_GPU_BUCKET_LIMIT", (long)BK_LIMIT);
 	const bool use_bk = bk_enabled && NJ > 0 && h->lds64_ordered;      // k_model stands on the LDS applying atomics in lane order (k_lds_order_test)
 	size_t o_bk = 0, bk_zero_words = 0, o_bcnt = 0;
 	if (use_bk)
@@ -736,7 +760,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		u32* d_bk = use_bk ? AP<u32>(h, o_bk) : nullptr;
 		u16* d_bcnt = use_bk ? AP<u16>(h, o_bcnt) : nullptr;
 		if (use_bk) HIPCHK(hipMemsetAsync(d_bk, 0, bk_zero_words * 4, s));
-		static const u32 max_parts = getenv("DSRC_GPU_REPLAY_PARTS") ? (u32)atoi(getenv("DSRC_GPU_REPLAY_PARTS")) : 2048u;   // tuning knob of k_replay
+		const u32 max_parts = 2048u;         // waves per stream of k_replay (measured: 256 parts 21.4, 512 23.3, 1024 24.3, 2048 24.7, 3200 23.2 GB/s with five instances)
 		for (size_t sl = 0; sl + 1 < slice_lo.size(); ++sl)
 		{
 			const u32 s_lo = slice_lo[sl], s_hi = slice_lo[sl + 1];
@@ -938,7 +962,6 @@ template <typename F> int with_arena_retry(dsrcgpu_handle* h, size_t initial, F&
 	const int rc = with_arena_retry_(h, initial, body);
 	if (rc != DSRCGPU_OK) chain_abort(h);
 	else h->chain_batch_done = true;
-	h->rec_chunk_sizes.clear();           // dsrcgpu_set_record_layout is one-shot
 	return rc;
 }
 
@@ -953,7 +976,7 @@ template <typename F> int with_arena_retry_(dsrcgpu_handle* h, size_t initial, F
 		rc = body();
 		// a batch that did not complete (capacity, checksum, input, memory) leaves the block-to-block state where it was: the
 		// caller may run the same batch again (grow-and-retry) and must get the blocks a fresh pass would have written
-		if (rc != DSRCGPU_OK) h->fields_cap = saved_cap;
+		if (rc != DSRCGPU_OK && tl_queue_lane != 2) h->fields_cap = saved_cap;
 		if (rc != DSRCGPU_E_NOMEM || h->arena_fixed || !h->arena.failed) return rc;
 		need = std::max(h->arena.top + h->arena.top / 8, need + need / 4);      // A.top is a lower bound of what the failed pass needed
 	}
@@ -1058,7 +1081,7 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 	prm.dna_order = h->set.dna_order; prm.quality_order = h->set.quality_order; prm.lossy = h->set.lossy ? 1u : 0u;
 	prm.crc = h->set.calculate_crc32 ? 1u : 0u; prm.quality_offset = h->ds.quality_offset; prm.n_blocks = B;
 	prm.tag_flags = (u32)h->set.tag_preserve_flags; prm.plus_rep = h->ds.plus_repetition ? 1u : 0u; prm.color_space = h->ds.color_space ? 1u : 0u;
-	prm.serial_quality = getenv("DSRC_GPU_DEC_SERIAL") ? 1u : 0u;
+	prm.serial_quality = hook_env("DSRC_GPU_DEC_SERIAL") ? 1u : 0u;
 	const bool q_rc = prm.quality_order > 0, d_rc = prm.dna_order > 0;
 
 	std::vector<DecDesc> desc(B); std::vector<DecState> st(B);
@@ -1243,7 +1266,7 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 			}
 		}
 		if (par) HIPCHK(hipStreamWaitEvent(s, h->ev[3], 0));
-		hipLaunchKernelGGL(k_dec_dhead, dim3((B + 63) / 64), dim3(64), 0, s, io.d_in, d_desc, d_state, prm); KCHK();
+		hipLaunchKernelGGL(k_dec_dhead, dim3((B + 63) / 64), dim3(64), 0, s, io.d_in, d_desc, d_state, prm, par ? (const DecHint*)AP<DecHint>(h, o_hints) : (const DecHint*)nullptr); KCHK();
 		bool any_plain = !d_rc;
 		if (par) { for (u32 b = 0; b < B; ++b) if (io.hints[b].d_scheme == 255) any_plain = true; }
 		if (d_rc && !par)
@@ -1341,7 +1364,7 @@ int verify_blocks(dsrcgpu_handle* h, u32 n, const u64* offs, const u64* sizes)
 {
 	std::vector<u64> to(n), ts(n); std::vector<u32> ok(n, 0);
 	DecodeIO io{h->last_d_out, offs, sizes, n, nullptr, nullptr, 0, nullptr, 0, to.data(), ts.data(), ok.data()};
-	if (h->verify_hints.size() == n && !getenv("DSRC_GPU_VERIFY_SERIAL")) io.hints = h->verify_hints.data();
+	if (h->verify_hints.size() == n && !hook_env("DSRC_GPU_VERIFY_SERIAL")) io.hints = h->verify_hints.data();
 	// dsrcgpu_last_timing keeps reporting the compression batch: the verifying pass has its own figure
 	const float c_batch = h->batch_ms, c_rc = h->rc_ms; const u32 c_launches = h->rc_launches;
 	const int rc = run_decode(h, io);
@@ -1368,6 +1391,26 @@ int check_settings(dsrcgpu_handle* h, const dsrcgpu_settings* s, const dsrcgpu_d
 	return 0;
 }
 
+// A batch call made by the USER (not by a scheduler lane of the queue form): takes the pending record layout -- it belongs to this call,
+// one-shot -- and, on a handle whose queue form runs two lanes, checks that the queue has drained and notes that the handle's own copy
+// of the block-to-block state is about to move (the next flush hands it to the lanes' chain).
+int user_batch_begin(dsrcgpu_handle* h, std::vector<u32>& layout)
+{
+	std::lock_guard<std::mutex> g(h->q_m);
+	if (h->q_chain)
+	{
+		if (h->q_pending) return fail(h, DSRCGPU_E_STATE, "batches of the queue form are still in flight on this handle");
+		h->chain = nullptr;          // the queue is drained: no lane touches the handle until the next flush
+		h->q_user_batch = true;
+	}
+	layout.swap(h->rec_pending); h->rec_pending.clear();
+	return DSRCGPU_OK;
+}
+
+int compress_batch_host(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* fastq, const uint64_t* sizes,
+						uint8_t* blocks, uint64_t blocks_cap, uint64_t* block_offs, uint64_t* block_sizes,
+						uint64_t* raw_sizes, uint64_t* comp_sizes, const std::vector<u32>& layout);
+
 } // namespace
 
 extern "C" {
@@ -1386,36 +1429,12 @@ int dsrcgpu_create(const dsrcgpu_settings* settings, const dsrcgpu_dataset* data
 	if (device < 0 || device >= ndev) return fail(h, DSRCGPU_E_ARG, "device %d out of range (%d devices)", device, ndev);
 	HIPCHK(hipSetDevice(device));
 	{
-		// Optional CU partitioning (DSRC_GPU_RC_CUS=n): the serial coder gets n compute units of its own (every
-		// (256/n)-th CU, i.e. spread over the XCDs) and the data-parallel kernels get the rest, so that
-		// concurrent scheduler instances never share a CU's instruction cache / issue slots with k_rc.
-		const char* env = getenv("DSRC_GPU_RC_CUS");
-		const int rc_cus = env ? atoi(env) : 0;
-		hipDeviceProp_t prop;
-		HIPCHK(hipGetDeviceProperties(&prop, device));
-		const int ncu = prop.multiProcessorCount;
-		if (rc_cus > 0 && rc_cus < ncu)
-		{
-			const int words = (ncu + 31) / 32;
-			std::vector<uint32_t> m_rc(words, 0), m_fe(words, 0);
-			const int step = ncu / rc_cus;
-			for (int c = 0; c < ncu; ++c)
-			{
-				const bool is_rc = (c % step) == 0 && (c / step) < rc_cus;
-				(is_rc ? m_rc : m_fe)[c / 32] |= 1u << (c % 32);
-			}
-			HIPCHK(hipExtStreamCreateWithCUMask(&h->stream, words, m_fe.data()));
-			HIPCHK(hipExtStreamCreateWithCUMask(&h->rc_stream, words, m_rc.data()));
-		}
-		else
-		{
-			// non-blocking: a host framework's work on the legacy default stream (torch, RCCL bookkeeping) must not
-			// serialise with the scheduler's streams
-			HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-			int lo_p = 0, hi_p = 0;
-			HIPCHK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-			HIPCHK(hipStreamCreateWithPriority(&h->rc_stream, hipStreamNonBlocking, hi_p));
-		}
+		// non-blocking: a host framework's work on the legacy default stream (torch, RCCL bookkeeping) must not
+		// serialise with the scheduler's streams.  (CUs reserved for k_rc through a CU mask were measured in rounds 2 and 4: no gain.)
+		HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+		int lo_p = 0, hi_p = 0;
+		HIPCHK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+		HIPCHK(hipStreamCreateWithPriority(&h->rc_stream, hipStreamNonBlocking, hi_p));
 	}
 	for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
 	h->arena_fixed = arena_bytes;
@@ -1453,7 +1472,7 @@ int dsrcgpu_create(const dsrcgpu_settings* settings, const dsrcgpu_dataset* data
 			if ((bad & 1u) && getenv("DSRC_GPU_DEBUG")) fprintf(stderr, "[dsrc_gpu] LDS atomics are not applied in lane order on device %d: k_sort ranks with ballots\n", device);
 			if ((bad & 2u) && getenv("DSRC_GPU_DEBUG")) fprintf(stderr, "[dsrc_gpu] 64-bit LDS atomics are not applied in lane order on device %d: no bucketed path (k_model)\n", device);
 		}
-		h->sort_atomic = !((k - 1) & 1) && !getenv("DSRC_GPU_SORT_BALLOT");
+		h->sort_atomic = !((k - 1) & 1) && !hook_env("DSRC_GPU_SORT_BALLOT");
 		h->lds64_ordered = !((k - 1) & 2) && h->sort_atomic;
 	}
 	if (arena_bytes) { rc = ensure_arena(h, (size_t)arena_bytes); if (rc) return rc; }
@@ -1498,16 +1517,11 @@ int dsrcgpu_compress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_f
 {
 	if (!h) return DSRCGPU_E_ARG;
 	if (!d_fastq || !offs || !sizes || !d_blocks || !block_offs || !block_sizes || !raw_sizes || !comp_sizes) return fail(h, DSRCGPU_E_ARG, "null argument");
-	if (h->q_chain && !tl_queue_lane)
-	{	// a batch call by the user on a handle whose queue form runs two lanes: allowed once the queue has drained; the handle's
-		// own copy of the block-to-block state is current then (the next flush hands it back to the lanes' chain)
-		std::lock_guard<std::mutex> g(h->q_m);
-		if (h->q_pending) return fail(h, DSRCGPU_E_STATE, "batches of the queue form are still in flight on this handle");
-		h->chain = nullptr;
-	}
+	std::vector<u32> layout;
+	{ const int rc = user_batch_begin(h, layout); if (rc) return rc; }
 	HIPCHK(hipSetDevice(h->device));
 	return with_arena_retry(h, estimate_arena(h, n, sizes), [&]() {
-		BatchIO io{(const u8*)d_fastq, offs, sizes, n, (u8*)d_blocks, blocks_cap, nullptr, 0, block_offs, block_sizes, raw_sizes, comp_sizes};
+		BatchIO io{(const u8*)d_fastq, offs, sizes, n, (u8*)d_blocks, blocks_cap, nullptr, 0, block_offs, block_sizes, raw_sizes, comp_sizes, &layout};
 		const int rc = run_batch(h, io);
 		if (rc != DSRCGPU_OK || !h->set.verify_after_compress || !h->set.calculate_crc32) return rc;
 		return verify_blocks(h, n, block_offs, block_sizes);
@@ -1521,13 +1535,21 @@ int dsrcgpu_compress_batch(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* 
 	if (!h) return DSRCGPU_E_ARG;
 	if (!fastq || !sizes || !blocks || !block_offs || !block_sizes || !raw_sizes || !comp_sizes) return fail(h, DSRCGPU_E_ARG, "null argument");
 	if (n == 0) return DSRCGPU_OK;
-	if (h->q_chain && !tl_queue_lane)
-	{	// a batch call by the user on a handle whose queue form runs two lanes: allowed once the queue has drained; the handle's
-		// own copy of the block-to-block state is current then (the next flush hands it back to the lanes' chain)
-		std::lock_guard<std::mutex> g(h->q_m);
-		if (h->q_pending) return fail(h, DSRCGPU_E_STATE, "batches of the queue form are still in flight on this handle");
-		h->chain = nullptr;
-	}
+	std::vector<u32> layout;
+	{ const int rc = user_batch_begin(h, layout); if (rc) return rc; }
+	return compress_batch_host(h, n, fastq, sizes, blocks, blocks_cap, block_offs, block_sizes, raw_sizes, comp_sizes, layout);
+}
+
+} // extern "C"
+
+namespace
+{
+// host-resident chunks -> blocks: the body of dsrcgpu_compress_batch, also what a scheduler lane of the queue form runs (with the
+// record layout its batch was flushed with)
+int compress_batch_host(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* fastq, const uint64_t* sizes,
+						uint8_t* blocks, uint64_t blocks_cap, uint64_t* block_offs, uint64_t* block_sizes,
+						uint64_t* raw_sizes, uint64_t* comp_sizes, const std::vector<u32>& layout)
+{
 	HIPCHK(hipSetDevice(h->device));
 	std::vector<u64> offs(n);
 	size_t in_bytes = 0;
@@ -1537,12 +1559,15 @@ int dsrcgpu_compress_batch(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* 
 		if (h->arena.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (input)");
 		u8* d_in = h->arena.base + o_in;
 		for (u32 i = 0; i < n; ++i) HIPCHK(hipMemcpyAsync(d_in + offs[i], fastq[i], sizes[i], hipMemcpyHostToDevice, h->stream));
-		BatchIO io{d_in, offs.data(), sizes, n, nullptr, 0, blocks, blocks_cap, block_offs, block_sizes, raw_sizes, comp_sizes};
+		BatchIO io{d_in, offs.data(), sizes, n, nullptr, 0, blocks, blocks_cap, block_offs, block_sizes, raw_sizes, comp_sizes, &layout};
 		const int rc = run_batch(h, io);
 		if (rc != DSRCGPU_OK || !h->set.verify_after_compress || !h->set.calculate_crc32) return rc;
 		return verify_blocks(h, n, block_offs, block_sizes);
 	});
 }
+} // namespace
+
+extern "C" {
 
 int dsrcgpu_decompress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_blocks, const uint64_t* offs, const uint64_t* sizes,
 									const uint64_t* text_caps, void* d_text, uint64_t text_cap, uint64_t* text_offs, uint64_t* text_sizes, uint32_t* crc_ok)
@@ -1589,7 +1614,8 @@ int dsrcgpu_set_record_layout(dsrcgpu_handle* h, uint32_t n, const uint32_t* chu
 {
 	if (!h) return DSRCGPU_E_ARG;
 	if (n && !chunk_sizes) return fail(h, DSRCGPU_E_ARG, "null argument");
-	h->rec_chunk_sizes.assign(chunk_sizes, chunk_sizes + n);
+	std::lock_guard<std::mutex> g(h->q_m);
+	h->rec_pending.assign(chunk_sizes, chunk_sizes + n);
 	return DSRCGPU_OK;
 }
 
@@ -1621,6 +1647,8 @@ void queue_thread(dsrcgpu_handle* h, int lane)
 {
 	dsrcgpu_handle* L = lane ? h->twin : h;                   // the lane's arena, streams, error text
 	(void)hipSetDevice(h->device);
+	// (test hook, timing only: lane 0 starts late, so that the twin takes the first batches)
+	if (lane == 0) if (const long late_ms = hook_int("DSRC_GPU_HOOK_LANE0_DELAY_MS", 0)) std::this_thread::sleep_for(std::chrono::milliseconds(late_ms));
 	for (;;)
 	{
 		u32 k;
@@ -1642,10 +1670,9 @@ void queue_thread(dsrcgpu_handle* h, int lane)
 			rc = pinned_grow(b.out, b.out_cap, 0, cap);
 			if (rc) { fail(L, rc, "cannot allocate page-locked output memory"); break; }
 			if (h->q_chain) (void)dsrcgpu_set_chain(L, h->q_chain, b.seq);      // (a retry keeps the turn it has taken)
-			tl_queue_lane = true;
-			if (attempt == 0 && !b.layout.empty()) { L->rec_chunk_sizes = b.layout; b.layout.clear(); }
-			rc = dsrcgpu_compress_batch(L, n, ptrs.data(), b.sizes.data(), b.out, b.out_cap, b.o_offs.data(), b.o_sizes.data(), b.raw.data(), b.comp.data());
-			tl_queue_lane = false;
+			tl_queue_lane = h->q_chain ? 2 : 1;
+			rc = compress_batch_host(L, n, ptrs.data(), b.sizes.data(), b.out, b.out_cap, b.o_offs.data(), b.o_sizes.data(), b.raw.data(), b.comp.data(), b.layout);
+			tl_queue_lane = 0;
 			if (rc != DSRCGPU_E_CAPACITY) break;
 			cap = b.in_used + (u64)n * (1u << 16);
 		}
@@ -1727,7 +1754,7 @@ int dsrcgpu_flush(dsrcgpu_handle* h)
 		if (want && dsrcgpu_chain_create(&h->q_chain) == DSRCGPU_OK)
 		{
 			dsrcgpu_handle* t = nullptr;
-			if (dsrcgpu_create(&h->set, &h->ds, h->device, 0, &t) == DSRCGPU_OK) { h->twin = t; t->rec_chunk_sizes.clear(); (void)dsrcgpu_chain_seed(h->q_chain, h->fields_cap); }
+			if (dsrcgpu_create(&h->set, &h->ds, h->device, 0, &t) == DSRCGPU_OK) { h->twin = t; (void)dsrcgpu_chain_seed(h->q_chain, h->fields_cap); h->q_user_batch = false; }
 			else { if (t) dsrcgpu_destroy(t); dsrcgpu_chain_destroy(h->q_chain); h->q_chain = nullptr; }
 		}
 	}
@@ -1737,13 +1764,15 @@ int dsrcgpu_flush(dsrcgpu_handle* h)
 		h->q_thread = std::thread(queue_thread, h, 0);
 		if (h->twin) h->q_thread2 = std::thread(queue_thread, h, 1);
 	}
-	if (h->q_chain && h->chain != h->q_chain && h->q_seq)
-	{	// the user made batch calls on the handle since the last flush (only possible with the queue drained): the lanes go on from its state
+	if (h->q_chain && h->q_user_batch)
+	{	// the user made batch calls on the handle since the last flush (only possible with the queue drained, and noted by those calls
+		// themselves under q_m -- which lane ran which batch says nothing about it): the lanes go on from the handle's state
 		std::lock_guard<std::mutex> gc(h->q_chain->m);
 		h->q_chain->fields_cap = h->fields_cap;
+		h->q_user_batch = false;
 	}
 	b.seq = h->q_seq++;
-	b.layout.swap(h->rec_chunk_sizes); h->rec_chunk_sizes.clear();
+	b.layout.swap(h->rec_pending); h->rec_pending.clear();
 	b.state = QBatch::Queued; ++h->q_pending;
 	h->q_run.push_back(h->q_fill);
 	h->q_fill = (h->q_fill + 1) % DSRC_QUEUE_DEPTH;
@@ -1837,8 +1866,27 @@ int dsrcgpu_chain_seed(dsrcgpu_chain* c, uint32_t fields_capacity)
 	return DSRCGPU_OK;
 }
 
-int dsrcgpu_set_fields_capacity(dsrcgpu_handle* h, uint32_t cap) { if (!h) return DSRCGPU_E_ARG; h->fields_cap = cap; return DSRCGPU_OK; }
-int dsrcgpu_get_fields_capacity(const dsrcgpu_handle* h, uint32_t* cap) { if (!h || !cap) return DSRCGPU_E_ARG; *cap = h->fields_cap; return DSRCGPU_OK; }
+// (under q_m: with the queue form a lane that completes a batch writes the handle's view of the state)
+int dsrcgpu_set_fields_capacity(dsrcgpu_handle* h, uint32_t cap)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	std::lock_guard<std::mutex> g(h->q_m);
+	if (h->q_chain)
+	{	// two lanes: between flushes with the queue drained the lanes go on from this value; with batches in flight there is no
+		// point in the archive it could belong to
+		if (h->q_pending) return fail(h, DSRCGPU_E_STATE, "batches of the queue form are still in flight on this handle");
+		h->q_user_batch = true;
+	}
+	h->fields_cap = cap;
+	return DSRCGPU_OK;
+}
+int dsrcgpu_get_fields_capacity(const dsrcgpu_handle* h, uint32_t* cap)
+{
+	if (!h || !cap) return DSRCGPU_E_ARG;
+	std::lock_guard<std::mutex> g(const_cast<dsrcgpu_handle*>(h)->q_m);
+	*cap = h->fields_cap;
+	return DSRCGPU_OK;
+}
 
 // TagAnalyzer::InitializeFieldsStats' field split (src/TagModeler.cpp:159-222) on the title the compressor will see,
 // i.e. after FastqParserExt's rewrite when a field filter is set (src/FastqParser.cpp:198-251)
@@ -1935,7 +1983,16 @@ int dsrcgpu_synth_illumina(dsrcgpu_handle* h, uint64_t first, uint64_t count, vo
 	if (!h) return DSRCGPU_E_ARG;
 	if (!d_out || !bytes) return fail(h, DSRCGPU_E_ARG, "null argument");
 	HIPCHK(hipSetDevice(h->device));
-	return synth_illumina_device(h->stream, first, count, (u8*)d_out, cap, bytes) ? fail(h, DSRCGPU_E_CAPACITY, "synthetic FASTQ does not fit in %llu bytes", (unsigned long long)cap) : DSRCGPU_OK;
+	return synth_illumina_device(h->stream, first, count, (u8*)d_out, cap, bytes, 0u) ? fail(h, DSRCGPU_E_CAPACITY, "synthetic FASTQ does not fit in %llu bytes", (unsigned long long)cap) : DSRCGPU_OK;
+}
+
+int dsrcgpu_synth_fastq(dsrcgpu_handle* h, uint32_t flavour, uint64_t first, uint64_t count, void* d_out, uint64_t cap, uint64_t* bytes)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	if (!d_out || !bytes) return fail(h, DSRCGPU_E_ARG, "null argument");
+	if (flavour > 1) return fail(h, DSRCGPU_E_ARG, "unknown synthetic flavour %u", flavour);
+	HIPCHK(hipSetDevice(h->device));
+	return synth_illumina_device(h->stream, first, count, (u8*)d_out, cap, bytes, flavour) ? fail(h, DSRCGPU_E_CAPACITY, "synthetic FASTQ does not fit in %llu bytes", (unsigned long long)cap) : DSRCGPU_OK;
 }
 
 int dsrcgpu_dev_alloc(dsrcgpu_handle* h, uint64_t bytes, void** d_ptr)

@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(64) k_dec_qrc(const u8* in, const DecDesc* des
 	if (threadIdx.x == 0)
 	{
 		if (!s.err) S->dna_pos = bs_pos(s);
-		S->err |= s.err;
+		if (s.err) atomicOr(&S->err, s.err);                  // (a verifying pass runs k_dec_dnarc on the same DecState at the same time)
 	}
 }
 
@@ -476,7 +476,10 @@ __global__ void __launch_bounds__(64) k_dec_hint(DecState* st, const DecHint* hi
 }
 
 // ---- the scheme byte of the DNA stream (IDnaModelerProxy::Decode, src/DnaModelerProxy.h:61-71): thread per block --------------
-__global__ void __launch_bounds__(64) k_dec_dhead(const u8* in, const DecDesc* desc, DecState* st, DecParams prm)
+// With `hint` (a verifying pass whose DNA chains started from the compressing pass's figures): what the quality stage has parsed out
+// of the block's BYTES since -- where the DNA stream starts, how many bases it holds -- and the scheme byte found there must be what
+// the DNA stage was told, or the block is not the one that was meant to be written.
+__global__ void __launch_bounds__(64) k_dec_dhead(const u8* in, const DecDesc* desc, DecState* st, DecParams prm, const DecHint* hint)
 {
 	const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
 	if (b >= prm.n_blocks) return;
@@ -487,6 +490,7 @@ __global__ void __launch_bounds__(64) k_dec_dhead(const u8* in, const DecDesc* d
 	const u32 sch = in[d.in_off + S->dna_pos];
 	S->d_scheme = sch;
 	if (sch != 255 && sch > 1) S->err |= DEC_ERR_FORMAT;
+	if (hint && (hint[b].dna_pos != S->dna_pos || hint[b].d_total != S->d_total || hint[b].d_scheme != sch)) S->err |= DEC_ERR_FORMAT;
 }
 
 // ---- the coder's bytes for one lane's stream ------------------------------------------------------------------------------------
@@ -550,7 +554,7 @@ __global__ void __launch_bounds__(64) k_dec_dnarc(const u8* in, const DecDesc* d
 	const u32 ord = N == 8 ? (prm.dna_order < 7u ? prm.dna_order : 7u) : prm.dna_order;
 	const u32 mask = (1u << (abits * ord)) - 1u;              // <= 21 bits
 	BitSrc s; s.p = in + d.in_off; s.size = d.in_size; s.err = 0; s.bit = ((u64)S->dna_pos + 1) * 8;      // behind the scheme byte
-	if ((((u64)mask + 1) * W) > tb.words) { S->err |= DEC_ERR_POOL; return; }
+	if ((((u64)mask + 1) * W) > tb.words) { atomicOr(&S->err, (u32)DEC_ERR_POOL); return; }
 	u32* tab = tables + tb.off;
 	u8* dst = d_stream + d.d_base;
 	const u32 total = S->d_total;
@@ -697,7 +701,7 @@ __global__ void __launch_bounds__(64) k_dec_dnarc(const u8* in, const DecDesc* d
 	const u32 end = lw_pos(win);
 	if (end > s.size) err |= DEC_ERR_TRUNC;
 	S->end_pos = end;
-	S->err |= err;
+	if (err) atomicOr(&S->err, err);                          // (a verifying pass runs k_dec_qrc on the same DecState at the same time)
 }
 
 // ---- DNA of the -d0 level and blocks without a DNA stream: wave per block -----------------------------------------------------

@@ -1112,6 +1112,13 @@ __device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains
 	const u32 lane = lane_id(), id = first_chain + lane;
 	const bool loader = wave_id() >= 1;
 #if RC_SPARE_SIMD
+	// Waves that leave before the first barrier: on gfx9 (GCN / CDNA) s_barrier releases when every wave of the workgroup that has NOT
+	// yet terminated has arrived -- a wave that ends drops out of the count (ISA: "s_barrier: ... waves that have ended are not
+	// waited for").  The HIP programming model does not promise that, so the form is tied to the architecture it was measured on;
+	// any other target has to build with RC_SPARE_SIMD=0 (all loaders stay, the coder shares its SIMD: 188 instead of 118 ms).
+#if !defined(DSRC_EMU_BUILD) && defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "RC_SPARE_SIMD relies on the gfx9 barrier counting only live waves: build other targets with -DRC_SPARE_SIMD=0"
+#endif
 	if (loader && (wave_id() & 3u) == 0) return;                               // before the first barrier: the hardware counts the waves still alive
 	const u32 loader_id = wave_id() - 1u - (wave_id() >> 2);
 	if (loader && loader_id >= RC_LOADERS) return;

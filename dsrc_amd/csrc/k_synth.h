@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) k_synth_write(u64 first, u64 count, const
 			const i32 z4 = num >= 0 ? num / 209 : -((-num + 208) / 209);       // floor division
 			i32 qv = 38 - (i32)((6 * pos) / 100) + z4;
 			qv = qv < 2 ? 2 : (qv > 40 ? 40 : qv);
-			if (binned) qv = qv < 3 ? 2 : qv < 18 ? 12 : qv < 30 ? 23 : 37;      // DSRC_SYNTH_BINNED=1: four-level (NovaSeq-like) qualities, for experiments only
+			if (binned) qv = qv < 3 ? 2 : qv < 18 ? 12 : qv < 30 ? 23 : 37;      // flavour 1 of dsrcgpu_synth_fastq: four-level (NovaSeq-like) qualities
 			p[pos] = is_n ? (u8)'N' : (u8)"ACGT"[h1 & 3];
 			q[pos] = (u8)(33 + (is_n ? 2 : qv));
 		}
@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(256) k_synth_write(u64 first, u64 count, const
 }
 
 // host driver; returns non-zero if the data does not fit
-static inline int synth_illumina_device(hipStream_t s, u64 first, u64 count, u8* d_out, u64 cap, u64* bytes)
+// binned: the same records with the qualities quantised to four levels (2, 12, 23, 37: what current instruments write)
+static inline int synth_illumina_device(hipStream_t s, u64 first, u64 count, u8* d_out, u64 cap, u64* bytes, u32 binned)
 {
 	const u32 n_chunks = (u32)((count + SYNTH_CHUNK - 1) / SYNTH_CHUNK);
 	if (n_chunks == 0) { *bytes = 0; return 0; }
@@ -125,7 +126,7 @@ static inline int synth_illumina_device(hipStream_t s, u64 first, u64 count, u8*
 	else
 	{
 		hipMemcpyAsync(d_tot, tot, (size_t)n_chunks * 8, hipMemcpyHostToDevice, s);
-		hipLaunchKernelGGL(k_synth_write, dim3(n_chunks), dim3(256), 0, s, first, count, d_tot, d_out, (u64)0xD5C0FFEEull, (u32)(getenv("DSRC_SYNTH_BINNED") != nullptr));
+		hipLaunchKernelGGL(k_synth_write, dim3(n_chunks), dim3(256), 0, s, first, count, d_tot, d_out, (u64)0xD5C0FFEEull, binned);
 		hipStreamSynchronize(s);
 	}
 	free(tot); hipFree(d_tot);

@@ -38,8 +38,10 @@ def illumina_title(i: int) -> bytes:
     return b"@SRRSYN.%d HWI-ST1234:100:C0ABCACXX:%d:%d:%d:%d 1:N:0:ATCACG" % (i, lane, tile, x, y)
 
 
-def illumina_bases_quals(first: int, count: int, read_len: int = 150, seed: int = SEED):
-    """(count, read_len) uint8 arrays of bases and Phred+33 qualities for records first..first+count-1."""
+def illumina_bases_quals(first: int, count: int, read_len: int = 150, seed: int = SEED, binned: bool = False):
+    """(count, read_len) uint8 arrays of bases and Phred+33 qualities for records first..first+count-1.
+    binned: the qualities quantised to four levels (2 / 12 / 23 / 37), as current instruments write them
+    (flavour 1 of dsrcgpu_synth_fastq, csrc/k_synth.h)."""
     with np.errstate(over="ignore"):
         i = np.arange(first, first + count, dtype=np.uint64)[:, None]
         p = np.arange(read_len, dtype=np.uint64)[None, :]
@@ -51,19 +53,21 @@ def illumina_bases_quals(first: int, count: int, read_len: int = 150, seed: int 
     z4 = np.floor_divide((s - 1020) * 4 + 104, 209)
     q = 38 - (6 * p.astype(np.int64)) // 100 + z4
     q = np.clip(q, 2, 40)
+    if binned:
+        q = np.where(q < 3, 2, np.where(q < 18, 12, np.where(q < 30, 23, 37)))
     base = np.where(is_n, np.uint8(ord("N")), base)
     q = np.where(is_n, 2, q)
     return base.astype(np.uint8), (q + 33).astype(np.uint8)
 
 
-def illumina_fastq(n_reads: int, first: int = 1, read_len: int = 150, seed: int = SEED, crlf: bool = False) -> bytes:
+def illumina_fastq(n_reads: int, first: int = 1, read_len: int = 150, seed: int = SEED, crlf: bool = False, binned: bool = False) -> bytes:
     """Config 1-4 shape: Illumina-like fixed-length reads, Phred+33, '+' line bare, LF newlines."""
     nl = b"\r\n" if crlf else b"\n"
     out = []
     step = 65536
     for lo in range(first, first + n_reads, step):
         cnt = min(step, first + n_reads - lo)
-        b, q = illumina_bases_quals(lo, cnt, read_len, seed)
+        b, q = illumina_bases_quals(lo, cnt, read_len, seed, binned)
         for k in range(cnt):
             out.append(illumina_title(lo + k)); out.append(nl)
             out.append(b[k].tobytes()); out.append(nl + b"+" + nl)

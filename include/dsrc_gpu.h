@@ -136,8 +136,9 @@ int dsrcgpu_decompress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d
  * size) overlaps the copies and the front end of the next; the block-to-block state goes from lane to lane in flush order through an
  * internal chain.  One handle: 7.4 -> 11.9 GB/s with host-resident chunks of 8 MiB, 192 per flush.  The second lane doubles the
  * handle's HBM; it is left out when the caller has given the handle a chain of his own (dsrcgpu_set_chain) or with
- * DSRC_GPU_QUEUE_LANES=1.  dsrcgpu_set_fields_capacity counts before the first flush; dsrcgpu_set_record_layout belongs to the batch
- * of the next flush. */
+ * DSRC_GPU_QUEUE_LANES=1.  dsrcgpu_set_fields_capacity counts before the first flush and between flushes once the queue has drained
+ * (DSRCGPU_E_STATE while batches are in flight); dsrcgpu_set_record_layout belongs to whichever comes first, the next flush or the
+ * next batch call, and travels with that batch: it may be set for the next flush while earlier batches are still running. */
 int dsrcgpu_submit(dsrcgpu_handle* h, int64_t part_id, const uint8_t* fastq, uint64_t size);
 int dsrcgpu_flush(dsrcgpu_handle* h);
 int dsrcgpu_collect(dsrcgpu_handle* h, int64_t* part_id, uint8_t** block, uint64_t* block_size,
@@ -219,6 +220,9 @@ int dsrcgpu_last_stage_timing(const dsrcgpu_handle* h, float* sort_ms, float* re
 /* Counter-based synthetic Illumina-like FASTQ generated directly in HBM (bench input; same bytes as
  * dsrc_amd/synth.py illumina_fastq).  Writes records first..first+count-1, returns the byte count. */
 int dsrcgpu_synth_illumina(dsrcgpu_handle* h, uint64_t first, uint64_t count, void* d_out, uint64_t cap, uint64_t* bytes);
+/* ... with a flavour: 0 = the generator above (BASELINE's configurations); 1 = the same records with the qualities quantised to four
+ * levels (Phred 2 / 12 / 23 / 37: what current instruments write) -- dsrc_amd/synth.py illumina_fastq(binned=True); bench.py's second line. */
+int dsrcgpu_synth_fastq(dsrcgpu_handle* h, uint32_t flavour, uint64_t first, uint64_t count, void* d_out, uint64_t cap, uint64_t* bytes);
 
 /* small HBM helpers so that non-HIP hosts (Python/ctypes, JNI ...) can stage device-resident batches */
 int dsrcgpu_dev_alloc(dsrcgpu_handle* h, uint64_t bytes, void** d_ptr);

@@ -8,27 +8,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
-from dataclasses import dataclass
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 
 
-@dataclass
-class Config:
-    dna_order: int = 0
-    quality_order: int = 0
-    lossy: bool = False
-    crc: bool = False
-    quality_offset: int = 33
-    plus_repetition: bool = False
-    color_space: bool = False
-    tag_flags: int = 0
-
-    @staticmethod
-    def from_levels(d: int, q: int, lossy: bool = False, crc: bool = False, offset: int = 33) -> "Config":
-        # IDsrcOperator::GetCompressionSettings (reference src/DsrcOperator.h:74-90)
-        return Config(dna_order=3 * d, quality_order=(3 * q if lossy else q), lossy=lossy, crc=crc, quality_offset=offset)
+from dsrc_amd.config import Config      # noqa: E402,F401  (the settings record is the product's; the tests' modules import it from here)
 
 
 class _OrcConfig(C.Structure):

@@ -28,3 +28,27 @@ def ref():
     if not have_ref():
         pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
     return Ref()
+
+
+HOOKS_LIB = os.path.join(ROOT, "dsrc_amd", "csrc", "libdsrc_gpu_hooks.so")
+
+
+@pytest.fixture
+def gpu_hooks():
+    """dsrc_amd._lib bound to libdsrc_gpu_hooks.so for one test: the product's sources built with -DDSRC_GPU_TEST_HOOKS, the only GPU
+    build in which the DSRC_GPU_* switches that FORCE a path exist (ballot ranking, the range coder's reference loop, the sort-and-replay
+    front end, arena fill ...).  The product library has none of them: it chooses by itself."""
+    from dsrc_amd import _lib
+    if not os.path.exists(HOOKS_LIB):
+        pytest.skip("libdsrc_gpu_hooks.so not built")
+    old_env, old_lib = os.environ.get("DSRC_GPU_LIB"), _lib._lib
+    os.environ["DSRC_GPU_LIB"] = HOOKS_LIB
+    _lib._lib = None
+    try:
+        yield _lib
+    finally:
+        _lib._lib = old_lib
+        if old_env is None:
+            os.environ.pop("DSRC_GPU_LIB", None)
+        else:
+            os.environ["DSRC_GPU_LIB"] = old_env

@@ -517,6 +517,78 @@ def test_queue_form_two_lanes_carry_the_state(emu, oracle, lanes, monkeypatch):
         assert [(g[1], g[2], g[3]) for g in got] == want, (lanes, seed)
 
 
+def _field_chunks(fields, n_rec=25, seed=7):
+    import random
+    rng = random.Random(seed)
+    chunks = []
+    for k, nf in enumerate(fields):
+        recs = []
+        for i in range(n_rec):
+            title = b"@r.%d" % (100 * k + i) + b"".join(b":%d" % ((7 * i + f) % 90 + 10) for f in range(nf - 2))
+            recs.append(title + b"\n" + bytes(rng.choice(b"ACGT") for _ in range(36)) + b"\n+\n" + bytes(33 + rng.randint(20, 40) for _ in range(36)))
+        chunks.append(b"\n".join(recs))
+    return chunks
+
+
+def test_queue_form_second_lane_takes_the_first_batches(emu, oracle, monkeypatch):
+    """Which lane runs which batch must not matter (advisor, round 4): lane 0 -- the handle itself -- starts late, so the twin takes
+    batch 0, publishes the capacity it leaves (17 fields: 32) and stays busy; the next flush falls into that window.  It used to
+    take `lane 0 has not run a batch yet` for `the user made batch calls` and wrote the handle's stale capacity over the published one."""
+    import time
+    monkeypatch.setenv("DSRC_GPU_HOOK_LANE0_DELAY_MS", "2500")
+    monkeypatch.setenv("DSRC_GPU_HOOK_BATCH_HOLD_MS", "700")
+    chunks = _field_chunks((17, 5, 9, 17))
+    cfg = Config.from_levels(0, 1)
+    want = oracle.compress_blocks_state(cfg, chunks)
+    h = emu.Handle(cfg.dna_order, cfg.quality_order)
+    got = []
+    assert h.submit(0, chunks[0]); h.flush()
+    time.sleep(0.35)                                            # batch 0 has published and is being held
+    assert h.submit(1, chunks[1]); h.flush()
+    for i in (2, 3):
+        assert h.submit(i, chunks[i]); h.flush()
+        while True:
+            r = h.collect()
+            if r is None:
+                break
+            got.append(r)
+    assert h.get_fields_capacity() == oracle.last_fields_cap
+    h.close()
+    assert [g[0] for g in got] == [0, 1, 2, 3]
+    assert [(g[1], g[2], g[3]) for g in got] == want
+
+
+@pytest.mark.parametrize("lanes", ["2", "1"])
+def test_queue_form_record_layout_set_while_a_batch_runs(emu, oracle, lanes, monkeypatch):
+    """dsrcgpu_set_record_layout belongs to the batch of the next flush (include/dsrc_gpu.h) -- also when it is set while an earlier
+    batch is still running on the handle's own lane (advisor, round 4: the scheduler thread used to clear the user's field when
+    that batch ended)."""
+    import time
+    monkeypatch.setenv("DSRC_GPU_QUEUE_LANES", lanes)
+    monkeypatch.setenv("DSRC_GPU_HOOK_BATCH_HOLD_MS", "500")
+    a = synth.illumina_fastq(40, first=7)[:-1]
+    b = synth.illumina_fastq(30, first=900)[:-1]
+    cfg = Config(dna_order=0, quality_order=0, lossy=False)
+    w0, cap = oracle.compress_records_block(cfg, a, 111)
+    w1, cap = oracle.compress_records_block(cfg, b, 222, cap)
+    w2 = oracle.compress_blocks_state(cfg, [a], fields_cap=cap)[0][0]
+    h = emu.Handle(cfg.dna_order, cfg.quality_order)
+    h.set_record_layout([111])
+    assert h.submit(0, a); h.flush()
+    time.sleep(0.1)                                             # batch 0 is running (held)
+    h.set_record_layout([222])
+    assert h.submit(1, b); h.flush()
+    assert h.submit(2, a); h.flush()                            # one-shot: text layout again
+    got = []
+    while True:
+        r = h.collect()
+        if r is None:
+            break
+        got.append(r)
+    h.close()
+    assert [g[1] for g in got] == [w0, w1, w2]
+
+
 def test_queue_form_then_batch_calls_on_one_handle(emu, oracle):
     """Batch calls on a handle whose queue form runs two lanes: refused while flushed batches are in flight, allowed once the queue
     has drained -- and the block-to-block state goes on from one form to the other and back."""

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def gpu():
-    if not os.environ.get("DSRC_TEST_KEEP_GPU_LIB"):          # tools/r03_prep_write_repro.sh runs this suite on a variant build
+    if not os.environ.get("DSRC_TEST_KEEP_GPU_LIB"):          # (set to run this suite on a variant build: tools/variant_bench.sh)
         os.environ.pop("DSRC_GPU_LIB", None)
     from dsrc_amd import _lib
     _lib._lib = None
@@ -116,13 +116,13 @@ def test_rle_quality_alphabets(gpu, oracle):
         _check(gpu, oracle, Config.from_levels(d, q, lossy), chunks)
 
 
-def test_range_coder_reference_loop_path(gpu, oracle, monkeypatch):
+def test_range_coder_reference_loop_path(gpu_hooks, oracle, monkeypatch):
     """The carry-clamp fallback of k_rc (reference loop + byte re-dealing) must give the same stream as the fast
     path; DSRC_GPU_FORCE_EXACT_RC sends every 16-symbol group through it."""
     monkeypatch.setenv("DSRC_GPU_FORCE_EXACT_RC", "1")
     chunks = [synth.illumina_fastq(20000, first=1 + 20000 * k)[:-1] for k in range(3)]
     for d, q, lossy in [(3, 2, False), (2, 1, True)]:
-        _check(gpu, oracle, Config.from_levels(d, q, lossy), chunks)
+        _check(gpu_hooks, oracle, Config.from_levels(d, q, lossy), chunks)
 
 
 def test_concurrent_scheduler_instances(gpu, oracle):
@@ -201,25 +201,25 @@ def test_full_size_iontorrent_lossy(gpu, oracle):
         assert lines[0::4][:-1] == src[0::4] and [len(x) for x in lines[1::4]] == [len(x) for x in src[1::4]]
 
 
-def test_sort_ballot_variant(gpu, oracle, monkeypatch):
+def test_sort_ballot_variant(gpu_hooks, oracle, monkeypatch):
     """k_sort ranks with LDS atomics on a device that passed k_lds_order_test (the self-test below fails if MI355X ever does
     not) and with ballots otherwise; DSRC_GPU_SORT_BALLOT=1 forces the second variant: identical blocks, both equal to the oracle."""
     chunks = [synth.illumina_fastq(3000, first=1 + 3000 * i)[:-1] for i in range(3)] + [fuzz_fastq(77, 3000)[0]]
     for d, q, lossy in [(3, 2, False), (2, 1, True)]:
         cfg = Config.from_levels(d, q, lossy)
         want = [oracle.compress_block(cfg, c) for c in chunks]
-        h = gpu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
+        h = gpu_hooks.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
         atomic = [h.compress_block(c) for c in chunks]
         h.close()
         monkeypatch.setenv("DSRC_GPU_SORT_BALLOT", "1")
-        h = gpu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
+        h = gpu_hooks.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
         ballot = [h.compress_block(c) for c in chunks]
         h.close()
         monkeypatch.delenv("DSRC_GPU_SORT_BALLOT")
         assert atomic == want and ballot == want
 
 
-def test_no_kernel_reads_unwritten_arena_bytes(gpu, oracle, monkeypatch):
+def test_no_kernel_reads_unwritten_arena_bytes(gpu_hooks, oracle, monkeypatch):
     """DSRC_GPU_DEBUG_FILL=<byte> fills the arena before every batch: the blocks must not depend on the byte (nothing reads
     what nobody wrote) and equal the oracle's."""
     chunks = [synth.illumina_fastq(4000, first=1 + 4000 * i)[:-1] for i in range(3)] + [fuzz_fastq(91, 3000)[0]]
@@ -229,7 +229,7 @@ def test_no_kernel_reads_unwritten_arena_bytes(gpu, oracle, monkeypatch):
         ref = None
         for fill in ("0", "255", "90"):
             monkeypatch.setenv("DSRC_GPU_DEBUG_FILL", fill)
-            h = gpu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
+            h = gpu_hooks.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset)
             got = h.compress_batch(chunks) + h.compress_batch(chunks[::-1])
             h.close()
             assert got[0] == want0, (d, q, fill)
@@ -339,7 +339,7 @@ def test_bucketed_path_alphabet_sizes(gpu, oracle, n_sym):
         _check(gpu, oracle, Config.from_levels(d, q), [data])
 
 
-def test_bucketed_path_hand_backs_and_switches(gpu, oracle, monkeypatch, capfd):
+def test_bucketed_path_hand_backs_and_switches(gpu_hooks, oracle, monkeypatch, capfd):
     """Streams the bucketed path hands back to k_sort / k_replay inside a batch of streams it keeps: independent uniform qualities
     (k_model runs out of counter rows), a context with most of a 4 M-symbol stream (k_model finds a bucket too large for one wave);
     then the same batch with the path off and with k_model scattering to stream order itself."""
@@ -351,14 +351,14 @@ def test_bucketed_path_hand_backs_and_switches(gpu, oracle, monkeypatch, capfd):
     chunks = [synth.illumina_fastq(6000)[:-1], alphabet_fastq(30, n_rec=6000, L=100, spread=True), hot, synth.illumina_fastq(6000, first=7001)[:-1]]
     cfg = Config.from_levels(3, 2)
     monkeypatch.setenv("DSRC_GPU_DEBUG", "1")
-    _check(gpu, oracle, cfg, chunks)
+    _check(gpu_hooks, oracle, cfg, chunks)
     err = capfd.readouterr().err
     assert "8 of 8 streams tried, 2 handed back" in err, err          # the spread qualities (rows) and the hot block's bases (a bucket > BK_LIMIT); its qualities
                                                                       # (contexts of ~470 k symbols, fourteen rescales each) stay in their buckets
     for env in ({"DSRC_GPU_BUCKETS": "0"}, {"DSRC_GPU_BUCKETS_BINNED": "0"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        _check(gpu, oracle, cfg, chunks)
+        _check(gpu_hooks, oracle, cfg, chunks)
         for k in env:
             monkeypatch.delenv(k)
 
