@@ -87,6 +87,13 @@ struct QBatch
 	std::vector<u32> layout;         // dsrcgpu_set_record_layout at the time of the flush: it belongs to this batch, whichever lane runs it
 };
 #define DSRC_QUEUE_DEPTH 3
+// HBM of the element slice: the streams of a batch go through k_part / k_model / k_place (or k_sort / k_replay) this many MiB of
+// elements at a time.  A stream handed back to k_sort needs two 8-byte buffers (16 B per symbol), so 1792 MiB are ~32 streams of an
+// 8 MiB chunk per launch group (rounds 1-4: 7 GiB = 128 streams, sized when every stream took that road; the bucketed path writes
+// 4-byte elements into the same place).  Launches of 32 streams still fill the GPU: k_part 13 k workgroups, k_model 8-16 k.
+#ifndef DSRC_SORT_SLICE_MB
+#define DSRC_SORT_SLICE_MB 1792
+#endif
 
 } // namespace
 
@@ -141,6 +148,7 @@ struct dsrcgpu_handle
 	u64 dec_table_budget = 0;        // dsrcgpu_set_table_budget: HBM a decoding pass may take for model tables (0 = automatic)
 	u32* dec_tables = nullptr; u64 dec_tables_cap = 0;     // model tables of the range-decoded levels (bytes), kept between passes
 	std::vector<DecHint> verify_hints;                     // run_batch -> verify_blocks: where the DNA stream of every block it wrote lies
+	bool rc_caps_worst = false;      // a range-coded stream has outgrown the estimate of its staging once: two bytes per symbol from now on (run_batch)
 };
 
 namespace
@@ -167,7 +175,19 @@ int ensure_arena(dsrcgpu_handle* h, size_t need)
 		return fail(h, DSRCGPU_E_NOMEM, "batch needs %zu bytes of HBM scratch, arena is fixed at %llu", need, (unsigned long long)h->arena_fixed);
 	if (h->arena.base) { HIPCHK(hipFree(h->arena.base)); h->arena.base = nullptr; h->arena.cap = 0; }
 	size_t want = h->arena_fixed ? (size_t)h->arena_fixed : need + need / 64;
-	hipError_t e = hipMalloc((void**)&h->arena.base, want);
+	hipError_t e;
+	{
+		// One arena at a time, process-wide.  HBM that another process (or an earlier handle) has released is wiped by the driver at
+		// ~35 GB/s, and an allocation that lands on memory still waiting for that is held until it is clean
+		// (profiles/r05_alloc_probe.txt: 0 ms or seconds, depending on the device's recent past).  Four instances asking at once
+		// all came back together after 3.3 s (4 x 24 GB, profiles/r05_e2e_first.txt); asking in turn lets the first one start its
+		// batch while the others' arenas are still being cleaned.
+		static std::mutex alloc_turn;
+		std::lock_guard<std::mutex> g(alloc_turn);
+		const auto t0 = std::chrono::steady_clock::now();
+		e = hipMalloc((void**)&h->arena.base, want);
+		if (getenv("DSRC_GPU_DEBUG")) fprintf(stderr, "[dsrc_gpu] %p arena of %.1f GB: hipMalloc took %.0f ms\n", (void*)h, want / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+	}
 	if (e != hipSuccess) return fail(h, DSRCGPU_E_NOMEM, "hipMalloc(%zu) for the batch arena failed: %s", want, hipGetErrorString(e));
 	h->arena.cap = want; h->arena.top = 0; h->arena.failed = false;
 	if (fill) HIPCHK(hipMemsetAsync(h->arena.base, atoi(fill), h->arena.cap, h->stream));
@@ -186,8 +206,10 @@ size_t estimate_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
 	const bool rc = h->set.dna_order > 0 || h->set.quality_order > 0;
 	size_t tot = 0, mx = 0;
 	for (u32 i = 0; i < n; ++i) { tot += (size_t)sizes[i] + 4096; mx = std::max(mx, (size_t)sizes[i]); }
-	const size_t sort_slice = std::min(tot * 14, ((size_t)7168 << 20) + mx * 16);       // see slice_lo in run_batch
-	return tot * 21 / 2 + (rc ? sort_slice : 0) + (size_t)n * (1u << 20) + (16u << 20);  // measured: 10.04 x input + slice at -d3 -q2 (8-byte records)
+	const size_t sort_slice = std::min(tot * 14, ((size_t)DSRC_SORT_SLICE_MB << 20) + mx * 16);       // see slice_lo in run_batch
+	// measured at -d3 -q2 (round 5: streams carved from the statistics, one byte and a sixteenth of staging per range-coded symbol):
+	// 8.6 x the input + the slice; a batch that needs more -- other data, worst-case staging -- says so and is run again
+	return tot * (h->rc_caps_worst ? 21 : 18) / 2 + (rc ? sort_slice : 0) + (size_t)n * (1u << 20) + (16u << 20);
 }
 size_t estimate_decode_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes, bool own_text);
 
@@ -266,7 +288,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	mark("S1");
 
 	// ---- phase 2: index, statistics, symbol streams --------------------------------------------------
-	u64 lines = 0, recs = 0, qbytes = 0; u32 max_rec_cap = 1;
+	u64 lines = 0, recs = 0; u32 max_rec_cap = 1;
 	for (u32 b = 0; b < B; ++b)
 	{
 		const u32 n_lines = st[b].n_term + 1;
@@ -274,7 +296,6 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		desc[b].rec_cap = (n_lines + 3) / 4;
 		desc[b].rec_base = (u32)recs; recs += desc[b].rec_cap + 1;
 		max_rec_cap = std::max(max_rec_cap, desc[b].rec_cap);
-		desc[b].q_base = qbytes; desc[b].d_base = qbytes; qbytes += al(desc[b].in_size / 2 + 64, 64);
 		if (lines >= (1ull << 32) || recs >= (1ull << 32)) return fail(h, DSRCGPU_E_ARG, "batch too large for 32-bit record indices; submit fewer chunks per batch");
 	}
 	const size_t o_lines = A.alloc(lines * 4);
@@ -283,10 +304,20 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	rp.title_len = AP<u16>(h, A.alloc(recs * 2)); rp.len = AP<u16>(h, A.alloc(recs * 2));
 	rp.kept = AP<u16>(h, A.alloc(recs * 2)); rp.trunc = AP<u16>(h, A.alloc(recs * 2));
 	rp.q_off = AP<u32>(h, A.alloc(recs * 4)); rp.d_off = AP<u32>(h, A.alloc(recs * 4));
-	const size_t o_q = A.alloc(qbytes), o_qp = A.alloc(qbytes), o_d = A.alloc(qbytes);
+	// With a field filter k_tag_poke overwrites the first base of a sequence line (the title that swallowed its terminator ends there), and
+	// it has to run in front of the readback (record 0's template reads that byte): the symbol streams are then written first, into room
+	// for the worst case, as in rounds 1-4.  Otherwise they are carved behind the readback, from the statistics (see there).
+	const bool streams_early = prm.tag_flags != 0;
+	u8* d_q = nullptr; u8* d_qp = nullptr; u8* d_d = nullptr;
+	if (streams_early)
+	{
+		u64 qbytes = 0;
+		for (u32 b = 0; b < B; ++b) { desc[b].q_base = qbytes; desc[b].d_base = qbytes; qbytes += al(desc[b].in_size / 2 + 64, 64); }
+		const size_t o_q = A.alloc(qbytes), o_qp = A.alloc(qbytes), o_d = A.alloc(qbytes);
+		d_q = AP<u8>(h, o_q); d_qp = AP<u8>(h, o_qp); d_d = AP<u8>(h, o_d);
+	}
 	if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (phase 2): need > %zu bytes", A.top);
 	u32* d_lines = AP<u32>(h, o_lines);
-	u8* d_q = AP<u8>(h, o_q); u8* d_qp = AP<u8>(h, o_qp); u8* d_d = AP<u8>(h, o_d);
 	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(BlkDesc) * B, hipMemcpyHostToDevice, s));
 	hipLaunchKernelGGL(k_index_lines, dim3(prm.max_tiles, B), dim3(WG), 0, s, d_in, d_desc, d_tiles, d_lines, prm); KCHK();
 	hipLaunchKernelGGL(k_records, dim3((max_rec_cap + WG - 1) / WG, B), dim3(WG), 0, s, d_in, d_desc, d_state, d_lines, rp); KCHK();
@@ -301,10 +332,8 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	hipLaunchKernelGGL(k_prep_stats, dim3(B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, prm); KCHK();
 	if (prm.color_space) { hipLaunchKernelGGL(k_cs_reduce, dim3((max_rec_cap + WG - 1) / WG, B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, prm); KCHK(); }
 	hipLaunchKernelGGL(k_rec_offsets, dim3(B), dim3(WG), 0, s, d_desc, d_state, rp); KCHK();
-	{
-		const u32 gx = std::max(1u, std::min(64u, (max_rec_cap + 4 * WAVES - 1) / (4 * WAVES)));
-		hipLaunchKernelGGL(k_prep_write, dim3(gx, B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, d_q, d_qp, d_d, prm); KCHK();
-	}
+	const u32 prep_gx = std::max(1u, std::min(64u, (max_rec_cap + 4 * WAVES - 1) / (4 * WAVES)));
+	if (streams_early) { hipLaunchKernelGGL(k_prep_write, dim3(prep_gx, B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, d_q, d_qp, d_d, prm); KCHK(); }
 	if (crc && !prm.color_space) { hipLaunchKernelGGL(k_crc, dim3(B, 3), dim3(WG), 0, s, d_in, d_desc, d_state, rp, h->d_crc_tab, prm); KCHK(); }
 	if (prm.tag_flags || prm.record_layout) { hipLaunchKernelGGL(k_tag_poke, dim3((max_rec_cap + WG - 1) / WG, B), dim3(WG), 0, s, const_cast<u8*>(d_in), d_desc, d_state, rp, prm); KCHK(); }
 	hipLaunchKernelGGL(k_tag_template, dim3((B + 63) / 64), dim3(64), 0, s, d_in, d_desc, d_state, rp, B); KCHK();
@@ -315,6 +344,24 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	// ---- phase 3: scheme selection and buffer carving (host) -------------------------------------------
 	for (u32 b = 0; b < B; ++b)
 		if (st[b].err) return fail(h, DSRCGPU_E_INPUT, "chunk %u cannot be coded (error bits 0x%x, %u records)", b, st[b].err, st[b].n_recs);
+
+	// The symbol streams are carved now that the statistics say how long they are (round 5; before: three arrays of half the chunk each,
+	// 12.6 MB per 8 MiB chunk for 6.7 MB of symbols): transformed qualities, kept base indices, and -- only if some block's reads differ
+	// in length -- the position contexts (reads of one length: a closed form of t, qua_pctx).  k_prep_write runs behind this readback
+	// instead of in front of it: nothing the host decides depends on the streams themselves.
+	if (!streams_early)
+	{
+		u64 qb = 0, db = 0; bool any_var = false;
+		for (u32 b = 0; b < B; ++b)
+		{
+			desc[b].q_base = qb; qb += al((size_t)st[b].q_total + 64, 64);
+			desc[b].d_base = db; db += al((size_t)st[b].d_total + 64, 64);
+			any_var = any_var || st[b].min_len != st[b].max_len;
+		}
+		const size_t o_q = A.alloc(qb + 64), o_d = A.alloc(db + 64), o_qp = any_var ? A.alloc(qb + 64) : 0;
+		if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (symbol streams): need > %zu bytes", A.top);
+		d_q = AP<u8>(h, o_q); d_d = AP<u8>(h, o_d); d_qp = any_var ? AP<u8>(h, o_qp) : d_q;      // (never touched when every block's reads have one length)
+	}
 
 	std::vector<TagPlan> tplan(B);
 	std::vector<QuaPlan> qplan(B), dplan(B);
@@ -417,6 +464,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 
 	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(BlkDesc) * B, hipMemcpyHostToDevice, s));
 	HIPCHK(hipMemcpyAsync(d_tplan, tplan.data(), sizeof(TagPlan) * B, hipMemcpyHostToDevice, s));
+	if (!streams_early) { hipLaunchKernelGGL(k_prep_write, dim3(prep_gx, B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, d_q, d_qp, d_d, prm); KCHK(); }
 	hipLaunchKernelGGL(k_tag_scan, dim3(B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, wpool, d_tplan); KCHK();
 	hipLaunchKernelGGL(k_tag_numeric, dim3(B), dim3(WG), 0, s, d_desc, d_state, wpool, spool, d_tplan); KCHK();
 	hipLaunchKernelGGL(k_tag_finalize, dim3(B), dim3(64), 0, s, d_state); KCHK();
@@ -471,7 +519,12 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		}
 	}
 	size_t zero_hi = al(A.top, 256); A.top = zero_hi;
-	// plain (not zeroed) staging + work buffers
+	// plain (not zeroed) staging + work buffers.  Room for a range-coded stream: a symbol can cost two bytes (freq 1 of a total
+	// just under 2^16), but no stream costs that on average -- a row starts at 1 per symbol and gains 2 per hit, i.e. it is the KT
+	// estimator, whose code length stays within (N - 1) / 2 * log2(n) bits of n * log2(N) per context: <= 7.1 bits per symbol for the
+	// alphabets here.  So: a byte and a sixteenth per symbol; k_rc never writes past a stream's limit, it reports
+	// DSRC_ERR_OUT_OVERFLOW, and the batch is then run again with the two bytes per symbol that cannot be exceeded (sticky per handle).
+	auto rc_bytes_bound = [&](u32 n) -> size_t { return h->rc_caps_worst ? (size_t)n * 2 : (size_t)n + n / 16; };
 	for (u32 b = 0; b < B; ++b)
 	{
 		const BlkState& S = st[b]; BlkDesc& D = desc[b];
@@ -482,7 +535,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		}
 		if (qo > 0)
 		{
-			D.qua_cap = (u32)((1024 + (size_t)S.q_total * 2) / 4 + 4);
+			D.qua_cap = (u32)((1024 + rc_bytes_bound(S.q_total)) / 4 + 4);
 			D.plain_mask |= 1u;
 			D.qua_out = A.alloc((size_t)D.qua_cap * 4) / 4;
 		}
@@ -490,7 +543,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		if (dna_order > 0 && D.d_scheme != 255) D.plain_mask |= 2u;
 		if (dna_order > 0 || D.d_scheme == 255)
 		{
-			D.dna_cap = (u32)((1024 + (size_t)S.d_total * 2) / 4 + 4);
+			D.dna_cap = (u32)((1024 + rc_bytes_bound(S.d_total)) / 4 + 4);
 			D.dna_out = A.alloc((size_t)D.dna_cap * 4) / 4;
 		}
 	}
@@ -579,7 +632,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		// ~128 streams of an 8 MiB chunk per slice.  Larger slices (one k_sort workgroup per CU) are no faster for one
 		// instance, and with several instances sharing the GPU shorter launches interleave better (measured: 14 GiB
 		// 17.5, 7 GiB 19.6, 3.5 GiB 19.0 GB/s with four instances)
-		const size_t budget = (env ? (size_t)atol(env) : (size_t)7168) << 20;
+		const size_t budget = (env ? (size_t)atol(env) : (size_t)DSRC_SORT_SLICE_MB) << 20;
 		size_t need_max = 128;
 		for (u32 i = 0; i < NJ; ++i) need_max = std::max(need_max, ((size_t)jobs[i].n * 8 + 64) * 2);
 		const u32 max_jobs = (u32)std::max<size_t>(1, budget / need_max);
@@ -906,6 +959,12 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	for (u32 b = 0; b < B; ++b)
 	{
 		const BlkState& S = st[b];
+		if ((S.err & DSRC_ERR_OUT_OVERFLOW) && !h->rc_caps_worst && NJ)
+		{	// (see rc_bytes_bound) again, with the staging sized for the worst case: with_arena_retry_ re-runs a batch that reports
+			// a short arena
+			h->rc_caps_worst = true; A.failed = true;
+			return fail(h, DSRCGPU_E_NOMEM, "chunk %u: a range-coded stream outgrew its staging estimate; the batch is run again with worst-case staging", b);
+		}
 		if (S.err) return fail(h, DSRCGPU_E_INPUT, "chunk %u cannot be coded (error bits 0x%x)", b, S.err);
 		if (S.tag_bytes > (u64)desc[b].tag_cap * 4 || S.qua_bytes > (u64)desc[b].qua_cap * 4 || S.dna_bytes > (u64)desc[b].dna_cap * 4)
 			return fail(h, DSRCGPU_E_INPUT, "chunk %u: staging overflow (tag %u/%u qua %u/%u dna %u/%u)", b, S.tag_bytes, desc[b].tag_cap * 4, S.qua_bytes, desc[b].qua_cap * 4, S.dna_bytes, desc[b].dna_cap * 4);
@@ -1075,6 +1134,11 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 {
 	const u32 B = io.n;
 	if (B == 0) return DSRCGPU_OK;
+	// DSRC_GPU_DEBUG=2: host-side timeline of the phases of this pass (ms since the call)
+	static const bool trace = getenv("DSRC_GPU_DEBUG") && atoi(getenv("DSRC_GPU_DEBUG")) >= 2;
+	const auto t_call = std::chrono::steady_clock::now();
+	std::string tl;
+	auto mark = [&](const char* what) { if (trace) { char b[64]; snprintf(b, sizeof b, " %s %.1f", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count()); tl += b; } };
 	hipStream_t s = h->stream;
 	Arena& A = h->arena;
 	DecParams prm; memset(&prm, 0, sizeof(prm));
@@ -1101,6 +1165,7 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 	hipLaunchKernelGGL(k_dec_meta, dim3((B + 63) / 64), dim3(64), 0, s, io.d_in, d_desc, d_state, prm); KCHK();
 	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(DecState) * B, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
+	mark("meta");
 
 	// what the device says about the blocks so far (mid-pass and final)
 	auto check_blocks = [&](bool final) -> int
@@ -1179,6 +1244,7 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 		{
 			HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(DecState) * B, hipMemcpyDeviceToHost, s));
 			HIPCHK(hipStreamSynchronize(s));
+			mark("tags");
 			const int rc = check_blocks(false);
 			if (rc) return rc;
 			u64 sum = 0;
@@ -1273,6 +1339,7 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 		{
 			HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(DecState) * B, hipMemcpyDeviceToHost, s));
 			HIPCHK(hipStreamSynchronize(s));
+			mark("quality");
 			const int rc = check_blocks(false);
 			if (rc) return rc;
 			std::vector<DecTab> dtabs;
@@ -1320,8 +1387,11 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 	if (prm.crc && io.crc_ok) { hipLaunchKernelGGL(k_dec_crc, dim3(B, 3), dim3(WG), 0, s, d_desc, d_state, rp, d_out, h->d_crc_tab, prm); KCHK(); }
 	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(DecState) * B, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipEventRecord(h->ev[1], s));
+	if (trace) { HIPCHK(hipStreamSynchronize(s)); mark("dna+layout"); }
 	if (io.host_out) HIPCHK(hipMemcpyAsync(io.host_out, d_out, text_total, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
+	mark("copied");
+	if (trace) fprintf(stderr, "[dsrc_gpu] %p decode timeline (%u blocks):%s\n", (void*)h, B, tl.c_str());
 	{
 		const int rc = check_blocks(true);
 		if (rc) return rc;

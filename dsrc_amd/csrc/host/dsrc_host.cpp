@@ -160,8 +160,30 @@ void ArchiveWriter::WriteAt(uint64 off, const void* p, uint64 n) const
 	}
 }
 
+void ArchiveWriter::ReserveAhead(uint64 expect)
+{
+	struct stat sb;
+	if (fd < 0 || reserver.joinable() || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return;
+	reserver = std::thread([this, expect]()
+	{
+		const uint64 piece = 256ull << 20;
+		for (uint64 o = 0; o < expect && !reserveStop.load(); o += piece)
+		{
+			if (fallocate(fd, 0, (off_t)o, (off_t)std::min(piece, expect - o)) != 0) return;       // not supported / no space: the writes report it
+			reserved.store(o + std::min(piece, expect - o));
+		}
+	});
+}
+
+void ArchiveWriter::StopReserver()
+{
+	reserveStop.store(true);
+	if (reserver.joinable()) reserver.join();
+}
+
 void ArchiveWriter::Abandon()
 {
+	StopReserver();
 	if (fd >= 0) { close(fd); fd = -1; }
 	if (!name.empty()) { unlink(name.c_str()); name.clear(); }
 }
@@ -203,6 +225,9 @@ void ArchiveWriter::Finish(const fq::FastqDatasetType& type, const CompressionSe
 	PutBE(head, foot.size(), 4); PutBE(head, footerOffset, 8); PutBE(head, 0, 8); PutBE(head, blockSizes.size(), 8);
 	for (int i = 0; i < 8; ++i) head.push_back(0xAA);
 	WriteAt(0, head.data(), head.size());
+	StopReserver();
+	if (reserved.load() > footerOffset + foot.size() && ftruncate(fd, (off_t)(footerOffset + foot.size())) != 0)
+		throw DsrcException("Error writing the archive: " + name);
 	const int g = fd; fd = -1;
 	if (close(g) != 0) throw DsrcException("Error writing the archive (disk full?): " + name);
 	name.clear();
@@ -441,6 +466,8 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 		const uint32 instances = (uint32)std::max<uint64>(1, std::min<uint64>((uint64)std::min<uint32>(std::max(1u, args.threadNum), 8u) * devs.size(), nBatchesMax));
 		if (dsrcgpu_chain_create(&chain) != DSRCGPU_OK) throw DsrcException("cannot create the batch chain");
 		writer.Start(args.outputFilename);
+		// typical archives are 0.2-0.35 of the text; what lies beyond the reservation is written like before
+		writer.ReserveAhead(fileSize / 100 * (settings.lossy ? 28 : 36) + (64ull << 20));
 
 		const bool trace = getenv("DSRC_HOST_TRACE") != nullptr;
 		// ---- workers ------------------------------------------------------------------------------------------
@@ -752,8 +779,15 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 	std::vector<std::thread> workers;
 	std::mutex m; std::condition_variable cv;
 	std::string error;
+	const auto tProc = std::chrono::steady_clock::now();
+	std::vector<std::thread> warm;                   // HIP start-up runs beside the opening of the archive and the sizing of the output
+	struct WarmGuard { std::vector<std::thread>& th; ~WarmGuard() { for (auto& t : th) if (t.joinable()) t.join(); } } warmGuard{warm};
 	try
 	{
+		{
+			const std::vector<int> d0 = args.devices.empty() ? std::vector<int>(1, args.device) : args.devices;
+			for (int dev : d0) warm.emplace_back([dev]() { (void)dsrcgpu_prepare(dev); });
+		}
 		rd.Open(args.inputFilename);
 		if (args.useFastqStdIo) out = stdout;
 		else { out = fopen(args.outputFilename.c_str(), "w+b"); if (!out) throw DsrcException("Cannot open file to write:" + args.outputFilename); }      // readable too: the output is mapped
@@ -805,12 +839,15 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 		std::vector<uint64> mapAt(batches.size(), 0);
 		std::vector<std::vector<uint64_t> > mapCaps(batches.size());
 		std::vector<std::thread> faulters;
-		std::atomic<bool> mapBroken(false);
+		std::atomic<bool> mapBroken(false), faultStop(false);
+		std::atomic<uint64> reservedUpTo(0);             // bytes of the output file whose pages exist (fallocate, in file order)
+		uint32 instancesReady = 0;                       // (m) workers whose scheduler instance exists: the helper threads start behind them
 		struct MapGuard          // whatever way this scope is left: helper threads joined, mapping gone
 		{
 			std::vector<std::thread>& th; uchar*& p; uint64& n;
-			~MapGuard() { for (auto& t : th) if (t.joinable()) t.join(); if (p) munmap(p, n); p = nullptr; }
-		} mapGuard{faulters, map, mapBytes};
+			std::atomic<bool>& stop; std::condition_variable& cv;
+			~MapGuard() { stop.store(true); cv.notify_all(); for (auto& t : th) if (t.joinable()) t.join(); if (p) munmap(p, n); p = nullptr; }
+		} mapGuard{faulters, map, mapBytes, faultStop, cv};
 		if (regular && !getenv("DSRC_HOST_NO_MMAP") && nBlocks)
 		{
 			std::vector<uint32> words(nBlocks); std::vector<uint64_t> bsz(nBlocks);
@@ -837,27 +874,60 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 					mapAt[k] = total;
 					for (uint64 i = batches[k].first; i < batches[k].second; ++i) { mapCaps[k].push_back((uint64)words[i] + 1); total += (uint64)words[i] + 1; }
 				}
-				// the space is reserved, not just declared: a full disk shows here (and the buffered path reports it) instead of as a
-				// SIGBUS in the middle of a copy into the mapping; a file system without fallocate takes the buffered path as well
-				if (total && fallocate(fileno(out), 0, 0, (off_t)total) == 0)
+				// The space is reserved, not just declared: a full disk shows as a failed fallocate (and the buffered path reports it)
+				// instead of as a SIGBUS in the middle of a copy into the mapping; a file system without fallocate takes the buffered
+				// path as well.  Round 5: the reservation no longer stands in front of everything -- one helper thread reserves the
+				// file 256 MiB at a time in file order (tmpfs: 18 GB/s, the whole 37.7 GB set in 2.1 s, while the HIP runtime comes up and
+				// the first passes run) and a batch waits for ITS range only; and the threads that map the pages into this process start
+				// once every scheduler instance exists (six of them hammering the address space from the first millisecond had held the
+				// runtime's own mmaps back: an instance was ready after 1.46 s instead of 0.16 s, profiles/r05_e2e_first.txt).
+				const uint64 first = std::min<uint64>(total, 256ull << 20);
+				if (total && fallocate(fileno(out), 0, 0, (off_t)first) == 0)
 				{
 					void* q = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fileno(out), 0);
 					if (q != MAP_FAILED)
 					{
 						map = (uchar*)q; mapBytes = total;
+						reservedUpTo.store(first);
+						faulters.emplace_back([&, total, first]()
+						{
+							const uint64 piece = 256ull << 20;
+							for (uint64 o = first; o < total && !faultStop.load(); o += piece)
+							{
+								const uint64 len = std::min<uint64>(piece, total - o);
+								if (fallocate(fileno(out), 0, (off_t)o, (off_t)len) != 0)
+								{	// disk full (or the file system changed its mind): nobody may touch the mapping beyond this point
+									std::lock_guard<std::mutex> g(m);
+									mapBroken = true; cv.notify_all();
+									return;
+								}
+								{ std::lock_guard<std::mutex> g(m); reservedUpTo.store(o + len); }
+								cv.notify_all();
+							}
+						});
 						auto fault = [&, total](uint32 t, uint32 nt)
-						{	// 64 MiB pieces, in file order, round-robin over the threads
-							const uint64 piece = 64ull << 20;
+						{	// 32 MiB pieces (a piece holds the address space's lock against the runtime's mmaps for a few ms), in file order,
+							// round-robin over the threads, behind the reservation
+							{
+								std::unique_lock<std::mutex> g(m);
+								cv.wait(g, [&] { return faultStop.load() || mapBroken.load() || !error.empty() || instancesReady >= instances; });
+							}
+							const uint64 piece = 32ull << 20;
 							for (uint64 o = (uint64)t * piece; o < total; o += (uint64)nt * piece)
 							{
 								const uint64 len = std::min<uint64>(piece, total - o);
+								{
+									std::unique_lock<std::mutex> g(m);
+									cv.wait(g, [&] { return faultStop.load() || mapBroken.load() || reservedUpTo.load() >= o + len; });
+									if (faultStop.load() || mapBroken.load()) return;
+								}
 #ifdef MADV_POPULATE_WRITE
 								if (madvise(map + o, len, MADV_POPULATE_WRITE) == 0) continue;
 #endif
 								for (uint64 x = 0; x < len; x += 4096) (void)((volatile const uchar*)map)[o + x];      // a read: the decoded bytes may be there already
 							}
 						};
-						for (uint32 t = 0; t < 6; ++t) faulters.emplace_back(fault, t, 6u);
+						for (uint32 t = 0; t < 4; ++t) faulters.emplace_back(fault, t, 4u);
 					}
 					else if (ftruncate(fileno(out), 0) != 0) throw DsrcException("Error writing FASTQ output");
 				}
@@ -866,7 +936,8 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 		}
 
 		const bool trace = getenv("DSRC_HOST_TRACE") != nullptr;
-		const auto t0 = std::chrono::steady_clock::now();
+		const auto t0 = tProc;
+		if (trace) fprintf(stderr, "[dsrc-amd d] archive open, output sized and mapped %8.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 		auto mark = [&](uint32 idx, uint64 k, const char* what)
 		{
 			if (trace) fprintf(stderr, "[dsrc-amd d] worker %u batch %llu %-10s %8.1f ms\n", idx, (unsigned long long)k, what,
@@ -885,6 +956,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 					h = CreateDecodeInstance(devs[idx % devs.size()], rd.Settings(), rd.Type());
 					mark(idx, 0, "instance");
 				}
+				{ std::lock_guard<std::mutex> g(m); ++instancesReady; cv.notify_all(); }
 				if (tableShare) dsrcgpu_set_table_budget(h, tableShare);
 				Pinned in, text;
 				for (;;)
@@ -933,6 +1005,13 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 					if (map && !mapBroken)
 					{
 						uint64 cap = 0; for (uint64 c : mapCaps[k]) cap += c;
+						{	// the pages of this batch's range exist (see the reservation above)
+							std::unique_lock<std::mutex> g(m);
+							cv.wait(g, [&] { return mapBroken.load() || !error.empty() || reservedUpTo.load() >= mapAt[k] + cap; });
+							if (!error.empty()) break;
+						}
+						if (mapBroken) throw DsrcException("__remap__");
+						mark(idx, k, "reserved");
 						rc = dsrcgpu_decompress_batch(h, n, ptrs.data(), sizes.data(), mapCaps[k].data(), map + mapAt[k], cap, offs.data(), tsz.data(), nullptr);
 						bool exact = rc == DSRCGPU_OK;
 						for (uint32 i = 0; i < n && exact; ++i) exact = tsz[i] == mapCaps[k][i];
@@ -1031,8 +1110,10 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 		for (auto& t : workers) t.join();
 		workers.clear();
 		mark(0, batches.size(), "all decoded");
+		faultStop.store(true); cv.notify_all();          // whatever has not been mapped by now is of no use to anybody
 		for (auto& t : faulters) t.join();
 		faulters.clear();
+		mark(0, batches.size(), "helpers joined");
 		if (args.exitWhenDone && error.empty() && !mapBroken && regular)
 		{	// the text is in the page cache (through the mapping or pwrite); unmapping, closing and the HIP teardown are the
 			// kernel's job at exit, where nobody waits for them one after the other
