@@ -257,7 +257,17 @@ struct Pinned
 		// DSRC_HOST_PINNED=1 brings the page-locked buffers back.
 		static const bool usePageable = getenv("DSRC_HOST_PINNED") == nullptr;
 		void* q = nullptr;
-		if (usePageable) { if (posix_memalign(&q, 2u << 20, n) != 0) throw DsrcException("out of memory"); pageable = true; }
+		if (usePageable)
+		{
+			if (posix_memalign(&q, 2u << 20, n) != 0) throw DsrcException("out of memory");
+			pageable = true;
+#ifdef MADV_HUGEPAGE
+			// 2 MiB pages where the kernel hands them out on request: a 1.6 GB batch buffer is 800 page faults instead of 400 k when it is
+			// first filled, the runtime pins 800 pages for the copy, and the process frees 800 when it leaves (six such buffers of
+			// 4 KiB pages: 0.7 s between "archive closed" and the end of the process, profiles/r05_e2e_second.txt)
+			(void)madvise(q, n, MADV_HUGEPAGE);
+#endif
+		}
 		else if (dsrcgpu_host_alloc(n, &q) != DSRCGPU_OK) throw DsrcException("cannot allocate page-locked host memory");
 		p = (uchar*)q; cap = n;
 	}
@@ -908,9 +918,10 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 						auto fault = [&, total](uint32 t, uint32 nt)
 						{	// 32 MiB pieces (a piece holds the address space's lock against the runtime's mmaps for a few ms), in file order,
 							// round-robin over the threads, behind the reservation
-							{
+							{	// behind the runtime's start-up and behind the WHOLE reservation: mapping pages in while fallocate hands them out
+								// slowed the reservation from 18 to 4.5 GB/s (the third batch waited 8.4 s for its range, profiles/r05_e2e_second.txt)
 								std::unique_lock<std::mutex> g(m);
-								cv.wait(g, [&] { return faultStop.load() || mapBroken.load() || !error.empty() || instancesReady >= instances; });
+								cv.wait(g, [&] { return faultStop.load() || mapBroken.load() || !error.empty() || (instancesReady >= instances && reservedUpTo.load() >= total); });
 							}
 							const uint64 piece = 32ull << 20;
 							for (uint64 o = (uint64)t * piece; o < total; o += (uint64)nt * piece)
@@ -927,7 +938,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 								for (uint64 x = 0; x < len; x += 4096) (void)((volatile const uchar*)map)[o + x];      // a read: the decoded bytes may be there already
 							}
 						};
-						for (uint32 t = 0; t < 4; ++t) faulters.emplace_back(fault, t, 4u);
+						for (uint32 t = 0; t < 6; ++t) faulters.emplace_back(fault, t, 6u);
 					}
 					else if (ftruncate(fileno(out), 0) != 0) throw DsrcException("Error writing FASTQ output");
 				}
@@ -982,7 +993,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 							catch (...) { bad = true; }
 						};
 						std::vector<std::thread> rs;
-						for (uint32 t = 1; t < std::min<uint32>(4, n); ++t) rs.emplace_back(get);
+						for (uint32 t = 1; t < std::min<uint32>(8, n); ++t) rs.emplace_back(get);
 						get();
 						for (auto& t : rs) t.join();
 						if (bad) throw DsrcException("Error reading the DSRC archive");

@@ -29,6 +29,9 @@ __device__ __forceinline__ void dec_vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F
 #ifndef DEC_SWIZZLE
 #define DEC_SWIZZLE 0
 #endif
+#ifndef DEC_QRC_LEAN
+#define DEC_QRC_LEAN 1          // alphabets of <= 64 symbols take qrc_decode_lean (round 5); 0: the loop of rounds 3-4 for every alphabet
+#endif
 
 struct DecTab            // one model table of one block in the table region (host -> device)
 {
@@ -154,6 +157,18 @@ __device__ __forceinline__ u32 qrc_up1(u32 v)
 	u32 r = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
 	asm volatile("" : "+v"(r));
 	return r;
+#endif
+}
+
+// lane (l mod 64) of `old` becomes the wave-uniform v.  (No builtin for v_writelane in this compiler; the lane select goes through M0:
+// a VOP3 instruction of gfx9 reads one SGPR besides it.)
+__device__ __forceinline__ u32 qrc_writelane(u32 v, u32 l, u32 old)
+{
+#ifdef DSRC_EMU_BUILD
+	return lane_id() == (l & 63u) ? v : old;
+#else
+	asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(v), "s"(l) : "m0");
+	return old;
 #endif
 }
 
@@ -393,6 +408,247 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 	if (lane == 0) S->d_total = d_total;
 }
 
+// ---- quality, the lean loop (round 5) -------------------------------------------------------------------------------------------
+// The loop above is what the compiler makes of the straightforward formulation: ~110 instructions per symbol, two thirds of them
+// scalar control flow and 64-bit scalar arithmetic, and a wave issues one instruction per ~4.6 cycles -- the stage saturates at
+// ~12 GB/s however many blocks are in flight.  This one is written for instruction count, N <= 64 (one counter per lane):
+//   * 32-bit coder value: on every stream an encoder writes, buffer - low < range <= 2^32 (the first four bytes of the stream are
+//     zero); anything else is refused (DEC_ERR_FORMAT) instead of being decoded the reference's undefined way.  Products are
+//     32 bits (count * r <= total * r <= range), the search is one v_mul_lo + one compare;
+//   * a symbol whose cumulative counts never exceed the value (no encoder writes that) ends the block with DEC_ERR_FORMAT;
+//   * the coder's bytes come from a 64-bit window in scalar registers (FWin): a renormalisation of one or two bytes is a handful
+//     of shifts, decided from clz(range) -- unless the carry clamp of src/RangeCoder.h:122-129 can fire (bits 24..39 of low all
+//     set), which takes the reference's loop byte by byte;
+//   * every lane holds a counter of the row (lane l the one numbered l mod N) and keeps it up to date, so the row is stored by all
+//     lanes without touching the execution mask, at the byte offset it was loaded from (one VGPR, SGPR base);
+//   * the position contexts of 64 consecutive positions are computed by the 64 lanes at once, once per 64 symbols; a symbol reads
+//     its own with one v_readlane instead of stepping quotient and remainder in scalar registers.
+// Same segments as above (to the next multiple of 64, to the symbol before the record's last, the last one).
+// "this wave-uniform value lives in a scalar register from here on": the compiler knows which values are uniform, but it keeps them
+// in vector registers once a vector-only instruction (a byte swap, an alignbit it has matched, a conversion) has touched them, and
+// everything computed from them follows.  An empty asm with an SGPR constraint makes it move the value back (v_readfirstlane) there.
+#define DEC_SGPR(x) ((x) = (u32)__builtin_amdgcn_readfirstlane((int)(x)))
+// ... and the same for a value that IS in a scalar register, to keep the compiler from matching a vector-only pattern across it
+#ifdef DSRC_EMU_BUILD
+#define DEC_OPAQUE_S(x) ((void)0)
+#else
+#define DEC_OPAQUE_S(x) asm volatile("" : "+s"(x))
+#endif
+struct FWin { const CONST_AS u32* p4; u64 wq; u32 wbits, q0, q1, nextw, lastw, origin; };
+// the byte swap is a vector instruction (v_perm_b32); its result is wave-uniform and goes back to a scalar register, or everything
+// downstream of the window -- the coder's value, the search -- ends up in vector registers with it
+__device__ __forceinline__ u32 fw_bswap(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)__builtin_bswap32(x)); }
+
+__device__ __forceinline__ void fw_refill(FWin& w)
+{	// 32 more bits behind the wbits (< 32... <= 32) that are left
+	w.wq |= (u64)fw_bswap(w.q0) << (32u - w.wbits);
+	w.wbits += 32u;
+	w.q0 = w.q1;
+	w.q1 = w.p4[w.nextw < w.lastw ? w.nextw : w.lastw];
+	++w.nextw;
+}
+__device__ __forceinline__ void fw_start(FWin& w, const BitSrc& s)
+{
+	const u64 a = (u64)s.p, x = a + (s.bit >> 3);
+	const u64 w0 = x & ~3ull;
+	const u32 mis = (u32)(x & 3ull);
+	w.p4 = (const CONST_AS u32*)w0;
+	w.lastw = (u32)((((a + s.size - 1) & ~3ull) - w0) >> 2);
+	w.origin = (u32)(s.bit >> 3) - mis;                             // block position of byte 0 of dword 0
+	w.wq = (u64)(fw_bswap(w.p4[0]) << (8 * mis)) << 32; w.wbits = 32u - 8u * mis;
+	w.q0 = w.p4[1 < w.lastw ? 1 : w.lastw]; w.q1 = w.p4[2 < w.lastw ? 2 : w.lastw];
+	w.nextw = 3;
+	fw_refill(w);
+}
+// the next nbits (8 or 16) of the stream; at least 32 are in the window before and after
+__device__ __forceinline__ u32 fw_take(FWin& w, u32 nbits)
+{
+	const u32 v = (u32)(w.wq >> (64u - nbits));
+	w.wq <<= nbits; w.wbits -= nbits;
+	if (__builtin_expect(w.wbits < 32u, 0)) fw_refill(w);
+	return v;
+}
+// bytes of the block consumed so far, as a position inside the block: (nextw - 2) dwords have been folded into the window
+__device__ __forceinline__ u64 fw_pos(const FWin& w) { return (u64)w.origin + (u64)(w.nextw - 2) * 4 - w.wbits / 8; }
+
+template <u32 N>
+__device__ __forceinline__ void qrc_decode_lean(BitSrc& s, u32* table, u32 ord, u32 rescale, u32 cnt, bool translate, const u8* sym_tab, u32 lossy,
+												const DecDesc& d, DecState* S, RecPools rp, u8* text)
+{
+	static_assert(N <= 64, "one counter per lane");
+	constexpr u32 LIM = (1u << 16) - 2 * N;
+	const u32 lane = lane_id();
+	const u32 lanemod = lane & (N - 1);
+	const u32 abits = dec_int_log2(N);
+	const u32 rs_shift = dec_int_log2(rescale);                         // rescale is 8 or N: a power of two
+	const u32 bits_lo = (ord / 2) * abits, bits_hi = (ord / 2 + 1) * abits;
+	const u32 hash_mask = (1u << (ord * abits)) - 1u;                   // ord * abits <= 21 for every scheme
+	const u32 swap_mask = (((1u << bits_lo) - 1u) | ~((1u << bits_hi) - 1u)) & hash_mask;
+	const u32 row_shift = abits + 1;                                    // a row is N counters of two bytes
+	const u32 lane2 = lanemod * 2u;
+	u8* tabb = (u8*)table;
+	const u32 tr_v = translate ? (u32)sym_tab[lanemod] : lanemod;       // symbol value of counter i, in lane i
+
+	const u64 g0 = d.rec_base;
+	const u32 n_recs = S->n_recs;
+	u32 k = 0, d_total = 0, err = 0;
+	u32 ql = 0;
+	for (; k < n_recs; ++k)
+	{	// records without a quality line code nothing
+		ql = rp.len[g0 + k];
+		if (ql) break;
+		if (lane == 0) { rp.kept[g0 + k] = 0; rp.d_off[g0 + k] = d_total; }
+	}
+	// RangeDecoder::Start (src/RangeCoder.h:97-106): eight bytes into the buffer, of which the first four are zero
+	FWin win; fw_start(win, s);
+	u32 buf, range = 0xFFFFFFFFu; u64 low = 0;
+	{
+		const u32 b0 = fw_take(win, 16), b1 = fw_take(win, 16), b2 = fw_take(win, 16), b3 = fw_take(win, 16);
+		if (k < n_recs && (b0 | b1)) err |= DEC_ERR_FORMAT;
+		buf = (b2 << 16) | b3;
+	}
+	if (k < n_recs && !err)
+	{
+		u8* q = text + rp.qual_off[g0 + k];
+		u32 hpre = 0, sym_buf = 0, j = 0, ncount = 0, mine = 0, max_idx = 0;
+		u64 all_m = ~0ull;
+		u32 ri = 0, off_cur = lane2;                                  // row of the symbol being decoded and this lane's place in it
+		u32 cur = lanemod + 1;                                        // row 0 of a fresh table is 1, 2, .., N
+		double nf = dec_div_prep(range);
+		dec_vm_drain();
+		// position contexts floor(p * rescale / ql) of the positions p = g + 2 + lane, g = the group of 64 the symbol being decoded is
+		// in: the symbol at position j prepares the row of position j + 2 (its own row and the next one's base are known by then)
+		u32 v_pn = 0, pn = 0, base_next = 0;
+#define QL_GROUP(g_) do { v_pn = dec_div(dec_div_prep(((g_) + 2u + lane) << rs_shift), ql); } while (0)
+#define QL_PN(j_) ((u32)__builtin_amdgcn_readlane((int)v_pn, (int)((j_) & 63u)))
+		// the row base of the symbol after the next one, up to that symbol's predecessor: hash slots from hpre | idx and sym_buf
+#define QL_PREP(idx_, pn_) do { \
+			const u32 h2_ = (hpre | (idx_)) << abits; \
+			const u32 nb_ = (h2_ >> bits_lo) & (N - 1); \
+			hpre = (h2_ & swap_mask) | (((nb_ + sym_buf) >> 1) << bits_lo); \
+			sym_buf = nb_; \
+			pn = (pn_); \
+			base_next = (hpre << rs_shift) + pn; } while (0)
+		// before the first symbol: its own row is row 0 (hash 0, position 0); the second symbol's base has an empty hash and position 1
+		QL_GROUP(0u - 2u + 0u);                                         // lane l: position l (group "-2": positions 0 .. 63)
+		pn = (u32)__builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane((int)v_pn, 1));
+		if (ql == 1) pn = 0;                                          // the second symbol is the next record's first
+		base_next = pn;
+		QL_GROUP(0u);
+		for (;;)
+		{
+			u32 stop = (j | 63u) + 1u;
+			if (j + 1 < ql) { if (stop > ql - 1) stop = ql - 1; }
+			else { stop = ql; base_next -= pn; pn = 0; }              // the row after the LAST symbol is the next record's first: position 0
+			DEC_SGPR(buf); DEC_SGPR(base_next); DEC_SGPR(pn); DEC_SGPR(ri); DEC_SGPR(hpre); DEC_SGPR(sym_buf);
+#pragma unroll 2
+			do
+			{
+				// ---- the row has arrived: symbol index -----------------------------------------------------------------
+				const u32 total = (u32)__builtin_amdgcn_readlane((int)cur, N - 1);
+				const u32 r = dec_div(nf, total);
+				const u32 r_s = (u32)__builtin_amdgcn_readfirstlane((int)r);
+				const u64 m = __ballot(cur * r > buf);
+				// value >= total * r (no lane of the row says yes): no encoder writes that.  The loop has no exit in its middle (the
+				// compiler keeps wave-uniform state that lives across such an exit in vector registers): the symbol becomes the row's
+				// last one -- every access stays inside the row and the table -- and the lanes' answers are AND-ed up; bit N - 1 of
+				// the result is tested once per segment.
+				all_m &= m;
+				const u32 idx = (u32)__ffsll((long long)(m | (1ull << (N - 1)))) - 1u;
+				// ---- request the next row ------------------------------------------------------------------------------
+				const u32 ri_next = base_next + (idx << rs_shift);
+				const u32 off_next = (ri_next << row_shift) + lane2;
+				u32 nxt = (u32)*(const u16*)(tabb + off_next);
+				// ---- in its shadow: coder state ------------------------------------------------------------------------
+				const u32 hi = (u32)__builtin_amdgcn_readlane((int)cur, (int)idx);
+				const u32 lo = (u32)__builtin_amdgcn_readlane((int)qrc_up1(cur), (int)idx);
+				const u32 rr = lo * r_s;
+				buf -= rr; low += rr;
+				range = r_s * (hi - lo);
+				// RangeDecoder::DecodeFrequency's loop as written (src/RangeCoder.h:122-135): one or two bytes (range >= 2^8: r >= 2^8,
+				// freq >= 1), one symbol in three.  (A two-byte step decided from clz(range) with the loop as its fallback made the
+				// compiler shuffle a dozen registers where the two roads meet: more instructions than the loop itself.)
+				while (range <= 0x00FFFFFFu)
+				{
+					if (__builtin_expect(((low ^ (low + range)) & 0xFF00000000000000ull) != 0, 0))
+					{	// the carry clamp; a range it leaves empty is no encoder's
+						const u32 l32 = (u32)low;
+						range = (l32 | 0x00FFFFFFu) - l32;
+						if (range == 0) { all_m = 0; range = 0x00FFFFFFu; }
+					}
+					u32 byte = fw_take(win, 8);
+					DEC_OPAQUE_S(byte);                                   // (or the compiler fuses shift and or into a v_alignbit, and the value follows it)
+					buf = (buf << 8) | byte;
+					low <<= 8; range <<= 8;
+				}
+				nf = dec_div_prep(range);
+				// ---- the row: +2 on the symbol = +2 on every cumulative count from it on; Rescale() now instead of at the next visit
+				u32 upd = cur + (lanemod >= idx ? 2u : 0u);
+				if (__builtin_expect(total >= LIM - 2, 0))
+				{
+					u32 p = __shfl_up(upd, 1); if (lanemod == 0) p = 0;
+					u32 c = upd - p;                                    // (lanes past the row repeat it: their scan restarts at their own counter 0)
+					c -= c >> 1;
+					u32 inc = dec_wave_scan(c);
+					if (N < 64) { const u32 tot2 = (u32)__builtin_amdgcn_readlane((int)inc, N - 1); inc -= tot2 * (lane / N); }
+					upd = inc;
+				}
+				*(u16*)(tabb + off_cur) = (u16)upd;
+				// ---- the symbol: lane (j mod 64) keeps it until 64 are together or the record ends ----------------------
+				mine = qrc_writelane(idx, j, mine);
+				max_idx = max_idx > idx ? max_idx : idx;                // a symbol the block's alphabet does not have: tested once at the end
+				// a row that is visited twice in a row was requested before it was written
+				if (ri_next == ri) nxt = upd;
+				cur = nxt; ri = ri_next; off_cur = off_next;
+				QL_PREP(idx, QL_PN(j));
+			} while (++j < stop);
+			if (!((all_m >> (N - 1)) & 1ull)) err |= DEC_ERR_FORMAT;
+			if (err) break;
+			// ---- the segment's end ------------------------------------------------------------------------------------------
+			if ((j & 63u) == 0 || j == ql)
+			{
+				const u32 base = (j - 1) & ~63u;
+				const bool in = lane < j - base;
+				const u32 qv = (u32)__shfl((int)tr_v, (int)(mine & 63u));
+				if (in) q[base + lane] = (u8)qv;
+				ncount += (u32)__popcll(__ballot(in && q_special(qv, lossy)));
+				if (j < ql) QL_GROUP(j);
+			}
+			if (j == ql)
+			{
+				if (lane == 0) { rp.kept[g0 + k] = (u16)(ql - ncount); rp.d_off[g0 + k] = d_total; }
+				d_total += ql - ncount;
+				for (++k; k < n_recs; ++k)
+				{
+					ql = rp.len[g0 + k];
+					if (ql) break;
+					if (lane == 0) { rp.kept[g0 + k] = 0; rp.d_off[g0 + k] = d_total; }
+				}
+				if (k == n_recs) break;
+				q = text + rp.qual_off[g0 + k];
+				j = 0; ncount = 0;
+				// the base prepared by the record's last symbol was for a position behind the record's end; the first symbol's own row
+				// (position 0) is the one made above, so only what follows it is prepared again, with the new length: position 1
+				QL_GROUP(0u - 2u + 0u);
+				{
+					u32 p1 = (u32)__builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane((int)v_pn, 1));
+					if (ql == 1) p1 = 0;
+					base_next += p1 - pn; pn = p1;
+				}
+				QL_GROUP(0u);
+			}
+		}
+#undef QL_GROUP
+#undef QL_PN
+#undef QL_PREP
+		if (max_idx >= cnt) err |= DEC_ERR_FORMAT;
+	}
+	s.bit = fw_pos(win) * 8;
+	if (s.bit > (u64)s.size * 8) s.err |= DEC_ERR_TRUNC;
+	s.err |= err;
+	if (lane == 0) S->d_total = d_total;
+}
+
 // the scheme byte and the alphabet of an order-context quality stream: IQualityModelerProxy::Decode (src/QualityModelerProxy.h:59-69;
 // the lossy order proxy has no scheme byte, :156-159), TTranslationalQualityEncoder::Read (src/QualityEncoder.h:344-357)
 struct QrcScheme { u32 n, ord, rescale, translate; };
@@ -456,6 +712,10 @@ __global__ void __launch_bounds__(64) k_dec_qrc(const u8* in, const DecDesc* des
 	{
 		u32* table = tables + tb.off;
 		u8* text = out + d.out_off;
+#if DEC_QRC_LEAN
+		if constexpr (NSEL <= 64) qrc_decode_lean<NSEL>(s, table, qs.ord, qs.rescale, cnt, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text);
+		else
+#endif
 		qrc_decode<NSEL>(s, table, qs.ord, qs.rescale, cnt, swz_seed, qs.translate != 0, s_sym, prm.lossy, d, S, rp, text);
 	}
 	if (threadIdx.x == 0)
