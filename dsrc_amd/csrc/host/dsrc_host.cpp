@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cerrno>
 #include <cstring>
 #include <deque>
 #include <iomanip>
@@ -484,12 +485,75 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 		auto work = [&](uint32 idx)
 		{
 			dsrcgpu_handle* h = nullptr;
-			Pinned out;
+			// Two output buffers and a writer thread of the worker's own (round 5): the blocks of batch s go into the archive while the
+			// instance already compresses its next batch (a worker that wrote its blocks itself spent 60-250 ms per 200-ms batch in the
+			// write, profiles/r05_e2e_third.txt: all writers of one tmpfs file share the inode's lock).
+			Pinned outs[2];
+			struct WriteTask { std::unique_ptr<Job> job; Pinned* buf = nullptr; std::chrono::steady_clock::time_point t0, t1; };
+			std::mutex wm; std::condition_variable wcv;
+			std::deque<WriteTask> wq; bool wDone = false; bool busy[2] = {false, false};
+			std::thread writerThread([&]()
+			{
+				try
+				{
+					for (;;)
+					{
+						WriteTask t;
+						{
+							std::unique_lock<std::mutex> g(wm);
+							wcv.wait(g, [&] { return wDone || !wq.empty(); });
+							if (wq.empty()) return;
+							t = std::move(wq.front()); wq.pop_front();
+						}
+						Job* job = t.job.get();
+						const uint32 n = (uint32)job->sizes.size();
+						// the archive position of this batch is known once the batches before it have claimed theirs (sizes only:
+						// nobody waits for anybody's bytes); the blocks lie back to back in the buffer and go out in one positioned write
+						uint64 fileOff = 0, total = 0;
+						bool failed = false;
+						{
+							std::unique_lock<std::mutex> g(pl.m);
+							pl.cv.wait(g, [&] { return !pl.error.empty() || pl.claimTurn == job->seq; });
+							failed = !pl.error.empty();
+							if (!failed)
+							{
+								fileOff = writer.Claim(n, job->osz.data(), job->raw.data(), job->comp.data());
+								++pl.claimTurn;
+								pl.cv.notify_all();
+							}
+						}
+						if (!failed)
+						{
+							for (uint32 i = 0; i < n; ++i) total += job->osz[i];
+							writer.WriteAt(fileOff, t.buf->p + job->offs[0], total);
+							std::lock_guard<std::mutex> g(pl.m);
+							++pl.written; pl.cv.notify_all();
+						}
+						if (trace && !failed)
+						{
+							const auto t2 = std::chrono::steady_clock::now();
+							auto ms = [&](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+							fprintf(stderr, "[dsrc-amd] batch %llu (%u chunks, %.2f GB): start %.0f ms, compress %.0f ms, written %.0f ms after that\n", (unsigned long long)job->seq, n, job->inBytes / 1e9, ms(tStart, t.t0), ms(t.t0, t.t1), ms(t.t1, t2));
+						}
+						{
+							std::lock_guard<std::mutex> g(wm);
+							busy[t.buf == &outs[1] ? 1 : 0] = false;
+						}
+						wcv.notify_all();
+					}
+				}
+				catch (const std::exception& e) { pl.Fail(e.what()); std::lock_guard<std::mutex> g(wm); busy[0] = busy[1] = false; wcv.notify_all(); }
+			});
+			struct WriterJoin
+			{
+				std::thread& th; std::mutex& m; std::condition_variable& cv; bool& done;
+				~WriterJoin() { { std::lock_guard<std::mutex> g(m); done = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+			} writerJoin{writerThread, wm, wcv, wDone};
 			try
 			{
 				h = CreateInstance(args, settings, type, devs[idx % devs.size()]);
 				if (trace) fprintf(stderr, "[dsrc-amd] instance %u ready at %.0f ms\n", idx, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tStart).count());
-				for (;;)
+				for (uint32 turn = 0;; ++turn)
 				{
 					Job* job = nullptr;
 					{	// batches start in order: the chain makes batch s+1 wait for batch s early in its course
@@ -500,6 +564,11 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 						pl.cv.notify_all();
 					}
 					std::unique_ptr<Job> owner(job);
+					Pinned& out = outs[turn & 1];
+					{	// the buffer's previous batch is in the archive
+						std::unique_lock<std::mutex> g(wm);
+						wcv.wait(g, [&] { return !busy[turn & 1]; });
+					}
 					const auto t0 = std::chrono::steady_clock::now();
 					const uint32 n = (uint32)job->sizes.size();
 					const uint64 inBytes = job->inBytes;
@@ -522,34 +591,18 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 						pl.cv.notify_all();
 					}
 					if (rc != DSRCGPU_OK) throw DsrcException(dsrcgpu_last_error(h));
-					const auto t1 = std::chrono::steady_clock::now();
-					// the archive position of this batch is known once the batches before it have claimed theirs (sizes only:
-					// nobody waits for anybody's bytes); the blocks lie back to back in `out` and go out in one positioned write
-					uint64 fileOff = 0, total = 0;
 					{
-						std::unique_lock<std::mutex> g(pl.m);
-						pl.cv.wait(g, [&] { return !pl.error.empty() || pl.claimTurn == job->seq; });
-						if (!pl.error.empty()) break;
-						fileOff = writer.Claim(n, job->osz.data(), job->raw.data(), job->comp.data());
-						++pl.claimTurn;
-						pl.cv.notify_all();
+						std::lock_guard<std::mutex> g(wm);
+						busy[turn & 1] = true;
+						wq.push_back(WriteTask{std::move(owner), &out, t0, std::chrono::steady_clock::now()});
 					}
-					for (uint32 i = 0; i < n; ++i) total += job->osz[i];
-					writer.WriteAt(fileOff, out.p + job->offs[0], total);
-					{
-						std::lock_guard<std::mutex> g(pl.m);
-						++pl.written; pl.cv.notify_all();
-					}
-					if (trace)
-					{
-						const auto t2 = std::chrono::steady_clock::now();
-						auto ms = [&](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-						fprintf(stderr, "[dsrc-amd] batch %llu (%u chunks, %.2f GB): start %.0f ms, compress %.0f ms, write %.0f ms\n", (unsigned long long)job->seq, n, inBytes / 1e9, ms(tStart, t0), ms(t0, t1), ms(t1, t2));
-					}
+					wcv.notify_all();
 				}
 			}
 			catch (const std::exception& e) { pl.Fail(e.what()); }
-			if (h) dsrcgpu_destroy(h);
+			// the instance's HBM goes back in this thread, next to the other instances' last batches (see DsrcDecompressorGPU::Process)
+			if (h && args.exitWhenDone) (void)dsrcgpu_release_memory(h);
+			if (h && !args.exitWhenDone) dsrcgpu_destroy(h);
 		};
 		for (uint32 i = 0; i < instances; ++i) workers.emplace_back(work, i);
 
@@ -677,7 +730,10 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 		LogSizes(writer);
 		stamp("archive closed");
 		if (args.exitWhenDone)
-		{	// a command-line process has nothing left to do: skip unmapping ~100 GB of arenas and page-locked buffers
+		{	// a command-line process has nothing left to do: the instances have handed their HBM back in their own threads, the batch
+			// buffers go here, from several threads (pageable ones only: a page-locked buffer belongs to the runtime)
+			// (dropping the batch buffers from eight threads first -- madvise(MADV_DONTNEED) -- was measured: 0.45 s for that and the
+			// exit no shorter, profiles/r05_e2e_5.txt)
 			if (args.verboseLog) fputs(GetLog().c_str(), stderr);
 			fflush(nullptr);
 			_exit(0);
@@ -808,21 +864,19 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 
 		const uint64 nBlocks = rd.BlockCount();
 		// A decoding pass is a chain per block: it takes about as long for 1000 blocks as for 10, so
-		// passes are LARGE -- up to 1600 blocks, 5 GiB of archive -- and few handles run at a time: with an order model every block
-		// in flight holds a model table of up to 64 MiB, three handles per device share the HBM for them (38.5 GB set: 18.3 s with
-		// two handles and 1024-block passes, 15.4 s with three, 18.2 s with four).  (Still larger passes decode
-		// faster on the device -- two concurrent passes of 3600 blocks: 6.8 GB/s, of 1024: < 4 -- but then nothing overlaps the
-		// 19 GB a pass copies into the mapped output: 38.5 GB set, batches of 2300 blocks 16.9 s, of 1024 blocks 15.2 s.)
+		// passes are LARGE -- up to 4800 blocks, 14 GiB of archive -- and few handles run at a time: with an order model every
+		// block in flight holds a model table of up to 64 MiB, and the handles of a device share the HBM for them.
 		const std::vector<int> devs = args.devices.empty() ? std::vector<int>(1, args.device) : args.devices;
 		const bool tables = rd.Settings().dnaOrder > 0 || rd.Settings().qualityOrder > 0;
-		const uint32 perDev = std::min<uint32>(std::max(1u, args.threadNum), tables ? 3u : 4u);
+		// (round 5, with the lean quality loop: the 37.7 GB set in two passes of 2250 blocks 8.2-8.3 s, in three of 1500 8.2-9.4 s, in one 8.0-8.2 s)
+		const uint32 perDev = std::min<uint32>(std::max(1u, args.threadNum), tables ? 2u : 4u);
 		const uint32 wanted = perDev * (uint32)devs.size();
 		std::vector<std::pair<uint64, uint64> > batches;
 		{
-			// as few rounds of `wanted` concurrent passes as passes of <= 1600 blocks allow, all of one size
-			const uint64 rounds = std::max<uint64>(1, (nBlocks + (uint64)wanted * 1600 - 1) / ((uint64)wanted * 1600));
+			// as few rounds of `wanted` concurrent passes as passes of <= 4800 blocks (14 GiB of archive) allow, all of one size
+			const uint64 rounds = std::max<uint64>(1, (nBlocks + (uint64)wanted * 4800 - 1) / ((uint64)wanted * 4800));
 			const uint64 maxBlocks = args.batchBlocks ? args.batchBlocks : std::max<uint64>(1, (nBlocks + wanted * rounds - 1) / (wanted * rounds));
-			const uint64 budget = 5120ull << 20;
+			const uint64 budget = 14336ull << 20;
 			uint64 lo = 0, bytes = 0;
 			for (uint64 i = 0; i < nBlocks; ++i)
 			{
@@ -848,16 +902,23 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 		uchar* map = nullptr; uint64 mapBytes = 0;
 		std::vector<uint64> mapAt(batches.size(), 0);
 		std::vector<std::vector<uint64_t> > mapCaps(batches.size());
-		std::vector<std::thread> faulters;
+		std::vector<std::thread> faulters, unmappers;
 		std::atomic<bool> mapBroken(false), faultStop(false);
 		std::atomic<uint64> reservedUpTo(0);             // bytes of the output file whose pages exist (fallocate, in file order)
 		uint32 instancesReady = 0;                       // (m) workers whose scheduler instance exists: the helper threads start behind them
 		struct MapGuard          // whatever way this scope is left: helper threads joined, mapping gone
 		{
-			std::vector<std::thread>& th; uchar*& p; uint64& n;
+			std::vector<std::thread>& th; std::vector<std::thread>& th2; uchar*& p; uint64& n;
 			std::atomic<bool>& stop; std::condition_variable& cv;
-			~MapGuard() { stop.store(true); cv.notify_all(); for (auto& t : th) if (t.joinable()) t.join(); if (p) munmap(p, n); p = nullptr; }
-		} mapGuard{faulters, map, mapBytes, faultStop, cv};
+			~MapGuard()
+			{
+				stop.store(true); cv.notify_all();
+				for (auto& t : th) if (t.joinable()) t.join();
+				for (auto& t : th2) if (t.joinable()) t.join();
+				if (p) munmap(p, n);
+				p = nullptr;
+			}
+		} mapGuard{faulters, unmappers, map, mapBytes, faultStop, cv};
 		if (regular && !getenv("DSRC_HOST_NO_MMAP") && nBlocks)
 		{
 			std::vector<uint32> words(nBlocks); std::vector<uint64_t> bsz(nBlocks);
@@ -934,7 +995,9 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 								}
 #ifdef MADV_POPULATE_WRITE
 								if (madvise(map + o, len, MADV_POPULATE_WRITE) == 0) continue;
+								if (errno != EINVAL) continue;       // (ENOMEM: a batch that is through has given its range back already)
 #endif
+								if (args.exitWhenDone) continue;      // ... which is why nothing is touched by hand in that mode
 								for (uint64 x = 0; x < len; x += 4096) (void)((volatile const uchar*)map)[o + x];      // a read: the decoded bytes may be there already
 							}
 						};
@@ -970,6 +1033,14 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 				{ std::lock_guard<std::mutex> g(m); ++instancesReady; cv.notify_all(); }
 				if (tableShare) dsrcgpu_set_table_budget(h, tableShare);
 				Pinned in, text;
+				// device buffers of the mapped road (blocks in, text out), kept from pass to pass
+				struct DevBuf
+				{
+					dsrcgpu_handle*& h; void* p = nullptr; uint64 cap = 0;
+					bool Reserve(uint64 n) { if (n <= cap) return true; Release(); if (dsrcgpu_dev_alloc(h, n + n / 32, &p) != DSRCGPU_OK) { p = nullptr; return false; } cap = n + n / 32; return true; }
+					void Release() { if (p) dsrcgpu_dev_free(h, p); p = nullptr; cap = 0; }
+					~DevBuf() { Release(); }
+				} dBlocks{h}, dText{h};
 				for (;;)
 				{
 					uint64 k;
@@ -993,7 +1064,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 							catch (...) { bad = true; }
 						};
 						std::vector<std::thread> rs;
-						for (uint32 t = 1; t < std::min<uint32>(8, n); ++t) rs.emplace_back(get);
+						for (uint32 t = 1; t < std::min<uint32>(16, n); ++t) rs.emplace_back(get);
 						get();
 						for (auto& t : rs) t.join();
 						if (bad) throw DsrcException("Error reading the DSRC archive");
@@ -1015,20 +1086,29 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 					int rc = DSRCGPU_OK;
 					if (map && !mapBroken)
 					{
+						// Round 5: the pass is device-resident -- blocks up, decode, text down as three calls of the C ABI -- so that the
+						// only thing that needs this batch's range of the output file, the copy down, is the only thing that waits for it
+						// (the reservation of the whole file takes 2 s; the third batch used to start 1.3 s late for it)
 						uint64 cap = 0; for (uint64 c : mapCaps[k]) cap += c;
-						{	// the pages of this batch's range exist (see the reservation above)
-							std::unique_lock<std::mutex> g(m);
-							cv.wait(g, [&] { return mapBroken.load() || !error.empty() || reservedUpTo.load() >= mapAt[k] + cap; });
-							if (!error.empty()) break;
-						}
-						if (mapBroken) throw DsrcException("__remap__");
-						mark(idx, k, "reserved");
-						rc = dsrcgpu_decompress_batch(h, n, ptrs.data(), sizes.data(), mapCaps[k].data(), map + mapAt[k], cap, offs.data(), tsz.data(), nullptr);
+						if (!dBlocks.Reserve(inBytes + 64) || !dText.Reserve(cap + 64)) throw DsrcException(dsrcgpu_last_error(h));
+						if (dsrcgpu_dev_upload(h, dBlocks.p, in.p, inBytes) != DSRCGPU_OK) throw DsrcException(dsrcgpu_last_error(h));
+						mark(idx, k, "uploaded");
+						rc = dsrcgpu_decompress_batch_device(h, n, dBlocks.p, at.data(), sizes.data(), mapCaps[k].data(), dText.p, cap, offs.data(), tsz.data(), nullptr);
 						bool exact = rc == DSRCGPU_OK;
 						for (uint32 i = 0; i < n && exact; ++i) exact = tsz[i] == mapCaps[k][i];
 						if (exact)
 						{
 							mark(idx, k, "decoded");
+							{	// the pages of this batch's range exist (see the reservation above)
+								std::unique_lock<std::mutex> g(m);
+								cv.wait(g, [&] { return mapBroken.load() || !error.empty() || reservedUpTo.load() >= mapAt[k] + cap; });
+								if (!error.empty()) break;
+							}
+							if (mapBroken) throw DsrcException("__remap__");
+							if (dsrcgpu_dev_download(h, map + mapAt[k], dText.p, cap) != DSRCGPU_OK) throw DsrcException(dsrcgpu_last_error(h));
+							mark(idx, k, "copied");
+							// (Giving a finished batch's range of the mapping back at once, on a thread of its own, was measured: munmap of 18.8 GB of
+							// dirty shared pages takes 1.4 s there against 0.55 s of the process's exit, profiles/r05_e2e_6_t2.txt.)
 							std::lock_guard<std::mutex> g(m);
 							++mappedDone; cv.notify_all();
 							continue;
@@ -1110,8 +1190,11 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 				}
 			}
 			catch (const std::exception& e) { std::lock_guard<std::mutex> g(m); if (error.empty()) error = e.what(); cv.notify_all(); }
+			// the worker's HBM goes back here, in its own thread, next to the other workers' last passes: what a process still holds when
+			// it leaves is released by the driver one allocation after the other (1.4 s for ~150 GB, profiles/r05_e2e_third.txt)
+			if (h && args.exitWhenDone) (void)dsrcgpu_release_memory(h);
 		};
-		// a command-line process that is about to leave keeps its handles: freeing ~100 GB of arenas and tables takes seconds
+		// a command-line process that is about to leave keeps its handles (the memory behind them has gone back above)
 		struct HandleGuard
 		{
 			std::vector<dsrcgpu_handle*>& hs; std::vector<std::thread>& th; bool keep;

@@ -35,11 +35,11 @@ for i in 1 2 3; do
 done
 ls -l /dev/shm/t.dsrc
 echo "== traced decompress =="; sleep 6; rm -f /dev/shm/t_back.fastq
-wall env DSRC_HOST_TRACE=1 dsrc_amd/csrc/dsrc-amd d -t4 /dev/shm/t.dsrc /dev/shm/t_back.fastq > $OUT/d_trace.txt 2>&1; tail -1 $OUT/d_trace.txt
+wall env DSRC_HOST_TRACE=1 dsrc_amd/csrc/dsrc-amd d ${DARGS:--t4} /dev/shm/t.dsrc /dev/shm/t_back.fastq > $OUT/d_trace.txt 2>&1; tail -1 $OUT/d_trace.txt
 head -60 $OUT/d_trace.txt
 for i in 1 2 3; do
   sleep 6; rm -f /dev/shm/t_back.fastq
-  wall dsrc_amd/csrc/dsrc-amd d -t4 /dev/shm/t.dsrc /dev/shm/t_back.fastq 2>&1 | tail -1 | tee -a $OUT/d_runs.txt
+  wall dsrc_amd/csrc/dsrc-amd d ${DARGS:--t4} /dev/shm/t.dsrc /dev/shm/t_back.fastq 2>&1 | tail -1 | tee -a $OUT/d_runs.txt
 done
 cmp /dev/shm/t.fastq /dev/shm/t_back.fastq && echo "round trip identical"
 rm -f /dev/shm/t.fastq /dev/shm/t.dsrc /dev/shm/t_back.fastq
