@@ -32,13 +32,32 @@ sys.path.insert(0, ROOT)
 BUF = 8 << 20                     # -b8 (reference default, src/Common.h:156)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 RECS_PER_BLOCK = 22300
-# round 4 (profiles/r04_pmc_b512_p1_tiles.txt, KiB per 512-block batch; traffic = FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md):
-PMC_RC_BYTES_PER_BLOCK = (13.353e6 * 2 + 1.295e6) * 1024 / 512      # k_rc: the 8-byte records read once, the stream bytes written once
-PMC_PART_BYTES_PER_BLOCK = (1.706e6 * 2 + 14.180e6) * 1024 / 512    # k_part, eight launches
-PMC_MODEL_BYTES_PER_BLOCK = ((0.419e6 + 5.447e6 + 3.741e6 + 13.390e6) * 2 + 0.835e6 + 18.995e6 + 15.006e6 + 26.694e6) * 1024 / 512   # k_binoff + k_model<32> + k_model<4> + k_place
-PMC_ALL_BYTES_PER_BLOCK = 205.6e6 * 1024 / 512      # every compression kernel of the batch: 411 MB per block = 37 x the algorithmic 11.06 MB (round 2: 69 x)
-DECODE_TRAFFIC_PER_BLOCK = 663e6  # HBM bytes per decoded block at -d3 -q2: (FETCH_SIZE + WRITE_SIZE of k_dec_qrc and k_dec_dnarc) x 1 KiB / 2400 blocks (profiles/r03_pmc_decode_b2400.txt)
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_final.json")   # written by tools/r05_pmc.sh from rocprofv3 --pmc passes of the library it names
 MAX_RESIDENT = 3                  # distinct input shards kept in HBM per scheduler instance (2 when N > 1: rank 0 also holds the gathered streams)
+
+
+def csrc_sha() -> str:
+    """What the counter file is valid for: the kernel sources (dsrc_amd/csrc/*.h, *.hip) it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "dsrc_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc():
+    """L2 <-> fabric traffic per block from the PMC passes (FETCH_SIZE doubled for the 16 B/lane streaming reads, as MI355X_MICROARCH.md
+    prescribes, + WRITE_SIZE; separate passes).  A file measured on other kernel sources is refused: every traffic figure is then null."""
+    try:
+        with open(PMC_FILE) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        return None, f"{os.path.relpath(PMC_FILE, ROOT)} missing"
+    if pmc.get("csrc_sha") != csrc_sha():
+        return None, f"{os.path.relpath(PMC_FILE, ROOT)} is stale (measured on kernel sources {pmc.get('csrc_sha')}, commit {pmc.get('commit')}; these are {csrc_sha()}): run tools/r05_pmc.sh"
+    return pmc, f"{os.path.relpath(PMC_FILE, ROOT)} (commit {pmc.get('commit')})"
 
 
 def title_len(i: np.ndarray) -> np.ndarray:
@@ -115,7 +134,7 @@ def cpu_baseline(write_sample, d: int, q: int):
 class Lane:
     """One scheduler instance: own handle (HIP stream + arena) and its sub-batches."""
 
-    def __init__(self, cfg, device, sub_blocks, n_sub, rank, lane_id, n_lanes, alloc_out, n_out=1):
+    def __init__(self, cfg, device, sub_blocks, n_sub, rank, lane_id, n_lanes, alloc_out, n_out=1, binned=False):
         from dsrc_amd._lib import Handle
         self.h = Handle(cfg.dna_order, cfg.quality_order, quality_offset=33, device=device)
         self.sub = []
@@ -129,7 +148,7 @@ class Lane:
             gid = (rank * n_lanes + lane_id) * MAX_RESIDENT + k     # disjoint record range per (rank, lane, shard)
             first = 1 + gid * recs
             d_in = self.h.dev_alloc(cap_in)
-            nbytes = self.h.synth_illumina(first, recs, d_in, cap_in)
+            nbytes = self.h.synth_illumina(first, recs, d_in, cap_in, binned=binned)
             off = record_offsets(first, recs)
             assert off[-1] == nbytes, (off[-1], nbytes)
             starts, sizes = cut_blocks(off, sub_blocks)
@@ -143,6 +162,17 @@ class Lane:
 
     def shard(self, k):
         return self.sub[k % self.n_res]
+
+    def free(self):
+        """Inputs, outputs and the handle go back to the device (dsrcgpu_destroy frees the handle's own arena, not what dev_alloc gave out)."""
+        if getattr(self.h, "h", None):
+            for d_in, _, _ in self.sub:
+                self.h.dev_free(d_in)
+            for ptr, tensor in self.outs:
+                if tensor is None:
+                    self.h.dev_free(ptr)
+            self.sub = []; self.outs = []
+            self.h.close()
 
     def run(self, k):
         d_in, starts, sizes = self.shard(k)
@@ -182,7 +212,7 @@ class StepGates:
             self.gathered.add(s); self.cv.notify_all()
 
 
-def measure_decode(lanes, cfg, n_blocks, last_step, n_inst=int(os.environ.get("DSRC_BENCH_DECODE_INST", "2")), passes=int(os.environ.get("DSRC_BENCH_DECODE_PASSES", "3"))):
+def measure_decode(lanes, cfg, n_blocks, last_step, pmc, n_inst=int(os.environ.get("DSRC_BENCH_DECODE_INST", "2")), passes=int(os.environ.get("DSRC_BENCH_DECODE_PASSES", "3"))):
     """Secondary line: the same blocks back through the GPU decompressor (dsrcgpu_decompress_batch_device), everything in
     HBM.  The blocks are the ones instance 0 wrote in its last sub-batch, taken as many times as needed to make
     `n_blocks` per pass (every copy is decoded into its own text; the decoder's work does not depend on the data being distinct).
@@ -248,8 +278,8 @@ def measure_decode(lanes, cfg, n_blocks, last_step, n_inst=int(os.environ.get("D
             "roofline": {"bound": "hbm", "kernel": "k_dec_qrc (one wavefront per block: range decoding of the quality stream; the DNA stream follows in k_dec_dnarc, one lane per block)",
                          "achieved": round(alg / dt / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 6), "pass_ms": round(pass_ms, 1), "launch_bytes": int(text_bytes + sum(szs)),
-                         "traffic": int(DECODE_TRAFFIC_PER_BLOCK * n_blocks) if cfg.dna_order == 9 and cfg.quality_order == 2 else None,
-                         "note": "algorithmic bytes = block bytes in + text bytes out of a pass; a decoded stream is a chain of dependent model-row accesses, one 64-byte row fetched and written back per symbol (traffic: rocprofv3 FETCH_SIZE + WRITE_SIZE of k_dec_qrc + k_dec_dnarc per block, profiles/r03_pmc_decode_b2400.txt), and the kernels are bound by instruction issue and latency x blocks in flight, not by bandwidth (DESIGN section 11)"}}
+                         "traffic": int(pmc["decode"]["bytes_per_block"] * n_blocks) if pmc and pmc.get("decode") and cfg.dna_order == 9 and cfg.quality_order == 2 else None,
+                         "note": "algorithmic bytes = block bytes in + text bytes out of a pass; a decoded stream is a chain of dependent model-row accesses, one 64-byte row fetched and written back per symbol (traffic: rocprofv3 FETCH_SIZE + WRITE_SIZE of every decoding kernel per block, profiles/r05_pmc_final.json), and the kernels are bound by latency x blocks in flight and instruction issue, not by bandwidth (DESIGN section 11)"}}
 
 
 def measure_queue_form(cfg, device, chunks, n_handles, batches=4, per_batch=192):
@@ -348,16 +378,85 @@ def measure_verify(cfg, ln, n_inst):
     return round(sum(done) / dt / 1e6, 1), len(ln.shard(0)[1])
 
 
-def measure_host_e2e(src, size, td, inst=4, runs=3, gap=6.0):
-    """`dsrc-amd c` and `dsrc-amd d` (C++ host over the C ABI), file in tmpfs -> archive in tmpfs -> file in tmpfs, separated runs."""
+def measure_binned(cfg, device, sub_blocks, P, steps=3):
+    """Second line (task 5): the same workload with the qualities quantised to four levels, as current instruments
+    write them (flavour 1 of dsrcgpu_synth_fastq): a third of a quality stream then lies in one context.  Same scheduler instances,
+    same step; one block of the timed region is compared with the oracle."""
+    def alloc_out(h, cap):
+        return h.dev_alloc(cap), None
+    lanes = [Lane(cfg, device, sub_blocks, steps + 1, 0, i, P, alloc_out, binned=True) for i in range(P)]
+    try:
+        for ln in lanes:
+            ln.run(0)
+        t_sub = lanes[0].timing[-1][0] / 1e3
+        errors = []
+
+        def worker(idx):
+            try:
+                if idx:
+                    time.sleep(t_sub * idx / P)
+                for s_ in range(1, steps + 1):
+                    lanes[idx].run(s_)
+            except Exception as e:      # noqa: BLE001
+                errors.append(e)
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(P)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        wall = time.perf_counter() - t0
+        if errors:
+            raise errors[0]
+        in_bytes = sum(sum(ln.shard(s_)[2]) + len(ln.shard(s_)[2]) for ln in lanes for s_ in range(1, steps + 1))
+        out_bytes = sum(sum(ln.results[s_][1]) for ln in lanes for s_ in range(1, steps + 1))
+        from tests._oracle import Oracle
+        ln = lanes[-1]; d_in, starts, sizes = ln.shard(steps); o_offs, o_sizes, _, _ = ln.results[steps]
+        i = len(starts) - 1
+        chunk = ln.h.dev_download(d_in + starts[i], sizes[i])
+        got = ln.h.dev_download(ln.outs[0][0] + o_offs[i], o_sizes[i])
+        assert got == Oracle().compress_block(cfg, chunk)[0], "bench parity check failed on the four-level data"
+        return {"metric": f"raw FASTQ MB/s compressed (bit-identical .dsrc) at -d{cfg.dna_order // 3} -q{cfg.quality_order}, four-level qualities",
+                "value": round(in_bytes / wall / 1e6, 1), "unit": "MB/s", "steps": steps, "blocks_per_step": sub_blocks * P, "pipeline": P,
+                "ms_per_step": round(wall / steps * 1e3, 2), "ratio_out_in": round(out_bytes / in_bytes, 4), "parity_checked_blocks": 1,
+                "data": "the synthetic Illumina records with Phred quantised to 2 / 12 / 23 / 37 (dsrc_amd/synth.py illumina_fastq(binned=True)), in HBM"}
+    finally:
+        for ln in lanes:
+            ln.free()
+
+
+def write_config3_file(path, device, reads=100_000_000):
+    """BASELINE configs[2]'s own file: records 1 .. 100 M of the counter-based generator (37.7 GB), generated in HBM 4 M reads at a time."""
+    from dsrc_amd._lib import Handle
+    h = Handle(device=device)
+    total = 0; first = 1; piece = 4_000_000
+    try:
+        with open(path, "wb") as f:
+            while first <= reads:
+                n_rec = min(piece, reads - first + 1)
+                cap = n_rec * 400
+                d = h.dev_alloc(cap)
+                n = h.synth_illumina(first, n_rec, d, cap)
+                f.write(h.dev_download(d, n)); h.dev_free(d)
+                total += n; first += n_rec
+    finally:
+        h.close()
+    return total
+
+
+def measure_host_e2e(src, size, td, inst=4, runs=3, gap=6.0, first_gap=12.0):
+    """`dsrc-amd c` and `dsrc-amd d` (C++ host over the C ABI), file in tmpfs -> archive in tmpfs -> file in tmpfs, separated runs.
+    The gaps are for the driver, not for the tool: HBM that a process has released is wiped at ~35 GB/s and an allocation that lands
+    on memory still waiting for that is held until it is clean (profiles/r05_alloc_probe2.txt) -- this process has just released
+    ~200 GB, a `dsrc-amd c` run ~70 GB, a `dsrc-amd d` run ~150 GB."""
     import subprocess
     cli = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dsrc_amd", "csrc", "dsrc-amd")
     arc = os.path.join(td, "e2e.dsrc"); back = os.path.join(td, "e2e_back.fastq")
     res = {"c": [], "d": []}
-    for _ in range(runs):
+    for k in range(runs):
         if os.path.exists(arc):
             os.unlink(arc)
-        time.sleep(gap)                          # the driver is still reclaiming the previous process's HBM otherwise
+        time.sleep(first_gap if k == 0 else gap)
         t = time.time(); subprocess.check_call([cli, "c", "-d3", "-q2", f"-t{inst}", src, arc]); res["c"].append(size / (time.time() - t) / 1e6)
     for _ in range(runs):
         if os.path.exists(back):
@@ -374,7 +473,8 @@ def measure_host_e2e(src, size, td, inst=4, runs=3, gap=6.0):
             "compress": {"min": round(min(res["c"]), 1), "median": round(med(res["c"]), 1), "all": [round(x, 1) for x in res["c"]]},
             "decompress": {"min": round(min(res["d"]), 1), "median": round(med(res["d"]), 1), "all": [round(x, 1) for x in res["d"]]},
             "round_trip_identical": bool(ok),
-            "note": "dsrc-amd c -d3 -q2 / dsrc-amd d, file in tmpfs to file in tmpfs, process start to exit, PCIe and file I/O included; runs separated by %.0f s" % gap}
+            "spread_compress": round((max(res["c"]) - min(res["c"])) / med(res["c"]), 3), "spread_decompress": round((max(res["d"]) - min(res["d"])) / med(res["d"]), 3),
+            "note": "dsrc-amd c -d3 -q2 / dsrc-amd d on BASELINE configs[2]'s own file (100 M reads), file in tmpfs to file in tmpfs, process start to exit, PCIe and file I/O included; runs separated by %.0f s (%.0f s before the first)" % (gap, first_gap)}
 
 
 def main():
@@ -607,6 +707,10 @@ def main():
         n_sub_total = world * P * args.steps
         alg = (in_bytes + out_bytes) / n_sub_total               # chunk read once + block written once, per sub-batch launch
         achieved = alg / (rc_ms / 1e3) / 1e9 if rc_ms > 0 else 0.0
+        pmc, pmc_note = load_pmc()
+        pc = pmc["compress"] if pmc and args.dna == 3 and args.qua == 2 else None
+        step_alg = (in_bytes + out_bytes) / (world * args.steps)               # algorithmic bytes of one step of one GPU
+        step_frac = step_alg / (wall / args.steps) / 1e9 / HBM_PEAK_GBS
         line = {
             "metric": f"raw FASTQ MB/s compressed (bit-identical .dsrc) at -d{args.dna} -q{args.qua}", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 2),
@@ -615,35 +719,38 @@ def main():
             "config": {"workload": f"Synthetic Illumina 150 bp FASTQ, 100M-read data set shape (BASELINE configs[2]), -d{args.dna} -q{args.qua} -b8; "
                                    f"step = {args.blocks} consecutive 8 MiB chunks per GPU, device-resident, {P} scheduler instances per GPU",
                        "blocks_per_step": args.blocks, "pipeline": P,
-                       "parallelism": (f"{world} process(es), one per GPU: contiguous partId ranges, no data-path collective; per step the block sizes are all-gathered and "
+                       "parallelism": (f"{world} process(es), one per GPU ({dist.get_world_size()} ranks in the RCCL group): contiguous partId ranges, no data-path collective; per step the block sizes are all-gathered and "
                                        f"every rank's block stream goes to rank 0 by point-to-point send (RCCL), overlapped with the next step") if dist is not None else "1 GPU",
                        **({"per_rank_MB_per_s": per_rank, "gather_verified": gather_verified} if dist is not None else {}),
                        "ratio_out_in": round(out_bytes / in_bytes, 4), "parity_checked_blocks": checked},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         # L2<->fabric bytes of one k_rc launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), 512-block launch:
-                         # FETCH 13.353e6 KiB x 2 (gfx950 counts 16 B/lane streaming reads at half) + WRITE 1.295e6 KiB = 56 MB per block,
-                         # i.e. exactly the 8-byte records read once + the stream bytes written once (profiles/r04_pmc_b512_p1_tiles.txt)
-                         "traffic": int(PMC_RC_BYTES_PER_BLOCK * sub_blocks), "kernel": "k_rc (range-coder arithmetic, one lane per stream; its loader waves turn the per-symbol codes into the stream bytes)",
+                         # L2<->fabric bytes of one k_rc launch: FETCH_SIZE x 2 (gfx950 counts 16 B/lane streaming reads at half) + WRITE_SIZE,
+                         # separate rocprofv3 --pmc passes of a 512-block batch (profiles/r05_pmc_final.json; null when that file is not of this library)
+                         "traffic": int(pc["k_rc_bytes_per_block"] * sub_blocks) if pc else None,
+                         "kernel": "k_rc (range-coder arithmetic, one lane per stream; its loader waves turn the per-symbol codes into the stream bytes)",
                          "kernel_ms": round(rc_ms, 2), "launch_bytes": int(alg), "batch_ms": round(batch_ms, 2),
-                         "note": "algorithmic bytes = chunk bytes in + block bytes out of one sub-batch launch (SURVEY 8d); kernel_ms = k_rc from HIP events on the range-coder stream, measured while other scheduler instances share the GPU (alone: 118 ms)"},
+                         # what bounds the RUN, not the longest launch: algorithmic bytes of a step over the step's time, and what the kernels really move
+                         "step_frac": round(step_frac, 5), "step_achieved": round(step_frac * HBM_PEAK_GBS, 2),
+                         "traffic_ratio": round(pc["all_bytes_per_block"] * sub_blocks / alg, 2) if pc else None,
+                         "all_kernels_traffic": int(pc["all_bytes_per_block"] * sub_blocks) if pc else None,
+                         "traffic_source": pmc_note,
+                         "note": "algorithmic bytes = chunk bytes in + block bytes out (SURVEY 8d), of one sub-batch launch for achieved / frac (k_rc, HIP events on the range-coder stream, measured while the other scheduler instances share the GPU) and of one step for step_frac (wall time of the step: all instances, all kernels); traffic_ratio = counter traffic of every compression kernel of a batch / its algorithmic bytes"},
         }
         sort_ms = sum(x[3] for x in tm) / max(1, len(tm)); replay_ms = sum(x[4] for x in tm) / max(1, len(tm))
         if sort_ms > 0:
-            # the kernel that bounds the THROUGHPUT (k_rc above is the longest launch, but it is hidden behind the other
-            # instances' front ends): the context sort.  Same algorithmic bytes per launch group, its own summed HIP-event time
+            # the kernels that bound the THROUGHPUT (k_rc above is the longest launch, but it is hidden behind the other
+            # instances' front ends): the front end of the order models.  Same algorithmic bytes per launch group, its own summed HIP-event time
             line["roofline_frontend"] = {
                 "bound": "hbm", "kernel": "k_part (the (context key, symbol, t) elements of every 8192-symbol tile of a stream, grouped by <= 1024 buckets; all launches of one sub-batch)",
                 "achieved": round(alg / (sort_ms / 1e3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(alg / (sort_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5), "kernel_ms": round(sort_ms, 2), "model_ms": round(replay_ms, 2),
-                "launch_bytes": int(alg), "traffic": int(PMC_PART_BYTES_PER_BLOCK * sub_blocks),
-                "model_traffic": int(PMC_MODEL_BYTES_PER_BLOCK * sub_blocks), "all_kernels_traffic": int(PMC_ALL_BYTES_PER_BLOCK * sub_blocks),
-                "note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE of the k_part launches of a 512-block batch / 512 (profiles/r04_pmc_b512_p1_tiles.txt); "
-                        "model_ms / model_traffic = k_binoff + k_model (adaptive counter rows in LDS, one wave per bucket) + k_place (time bins into stream order) of the same sub-batch; "
-                        "all_kernels_traffic: every compression kernel, 37 x the algorithmic bytes (round 2, with the two-pass sort and the scattering replay: 69 x)"}
+                "launch_bytes": int(alg), "traffic": int(pc["k_part_bytes_per_block"] * sub_blocks) if pc else None,
+                "model_traffic": int(pc["model_bytes_per_block"] * sub_blocks) if pc else None,
+                "note": "traffic = FETCH_SIZE x 2 + WRITE_SIZE of the k_part launches of a 512-block batch / 512; model_ms / model_traffic = k_binoff + k_model (adaptive counter rows in LDS, one wave per bucket) + k_place (time bins into stream order) of the same sub-batch"}
         decode_line = None
         if args.decode_blocks > 0 and world == 1:
-            decode_line = measure_decode(lanes, cfg, args.decode_blocks, total_steps - 1)
+            decode_line = measure_decode(lanes, cfg, args.decode_blocks, total_steps - 1, pmc)
             if decode_line:
                 line["decompress"] = decode_line
         if not args.no_cpu and world == 1:
@@ -685,16 +792,17 @@ def main():
                     q["what"] = "dsrcgpu_submit / flush / collect / release with host-resident 8 MiB chunks, 192 chunks per flush, one submitting and one collecting thread per handle; host copy into the page-locked ring, PCIe both ways and the compression inside; a handle runs consecutive batches on two scheduler lanes of its own (round 4)"
                     line["queue_form"] = q
                     del chunks
-                    # the CLI: a >= 16 GB file in tmpfs; every GPU resource of this process is released first
+                    # every GPU resource of the headline run is released; the same step on four-level qualities
+                    dev0 = ln.h.device
+                    for l2 in lanes:
+                        l2.free()
+                    line["binned"] = measure_binned(cfg, dev0, sub_blocks, P)
+                    # the CLI on configs[2]'s own 37.7 GB file in tmpfs
                     import tempfile
-                    e2e_blocks = int(os.environ.get("DSRC_BENCH_E2E_BLOCKS", "1920"))
+                    e2e_reads = int(os.environ.get("DSRC_BENCH_E2E_READS", "100000000"))
                     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
                         src = os.path.join(td, "e2e.fastq")
-                        need = e2e_blocks
-                        with open(src, "wb") as f:
-                            size = write_sample(f)
-                        for l2 in lanes:
-                            l2.h.close()
+                        size = write_config3_file(src, dev0, e2e_reads)
                         line["host_e2e"] = measure_host_e2e(src, size, td)
                 except Exception as e:          # noqa: BLE001  (secondary measurements must not take the headline line with them)
                     line["forms_error"] = repr(e)

@@ -16,6 +16,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <dlfcn.h>
 #include <mutex>
 #ifndef DSRC_REPLAY_WHATIF
 #define DSRC_REPLAY_WHATIF 0     // experiments only: a k_replay PROBE mode for the whole run (wrong output)
@@ -54,6 +55,32 @@ const char* hook_env(const char* name) { return getenv(name); }
 const char* hook_env(const char*) { return nullptr; }
 #endif
 long hook_int(const char* name, long dflt) { const char* v = hook_env(name); return v ? atol(v) : dflt; }
+
+// DSRC_GPU_TRACE=1: roctx ranges around the stages of a batch / a decoding pass, for rocprofv3 --marker-trace timelines.
+// The marker library is looked up when the switch is set and only then (rocprofiler-sdk's librocprofiler-sdk-roctx.so, else the older
+// libroctx64.so); without it, or without the switch, a range costs one predictable branch.
+struct Roctx
+{
+	int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+	Roctx()
+	{
+#ifndef DSRC_EMU_BUILD
+		if (!getenv("DSRC_GPU_TRACE")) return;
+		void* lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+		if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+		if (!lib) return;
+		push = (int (*)(const char*))dlsym(lib, "roctxRangePushA"); pop = (int (*)())dlsym(lib, "roctxRangePop");
+		if (!push || !pop) { push = nullptr; pop = nullptr; }
+#endif
+	}
+};
+const Roctx& roctx() { static const Roctx r; return r; }
+struct TraceRange          // one stage; the previous one ends where the next begins
+{
+	bool open = false;
+	void stage(const char* name) { const Roctx& r = roctx(); if (!r.push) return; if (open) r.pop(); r.push(name); open = true; }
+	~TraceRange() { if (open) roctx().pop(); }
+};
 
 struct Arena
 {
@@ -272,6 +299,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	const u8* d_in = io.d_in;
 
 	HIPCHK(hipEventRecord(h->ev[0], s));
+	TraceRange tr; tr.stage("dsrc batch: line index");
 
 	// ---- phase 1: line counts ------------------------------------------------------------------
 	const size_t o_desc = A.alloc(sizeof(BlkDesc) * B), o_state = A.alloc(sizeof(BlkState) * B);
@@ -285,7 +313,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	hipLaunchKernelGGL(k_scan_tiles, dim3(B), dim3(WG), 0, s, d_desc, d_tiles, prm); KCHK();
 	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
-	mark("S1");
+	mark("S1"); tr.stage("dsrc batch: records, statistics");
 
 	// ---- phase 2: index, statistics, symbol streams --------------------------------------------------
 	u64 lines = 0, recs = 0; u32 max_rec_cap = 1;
@@ -339,7 +367,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	hipLaunchKernelGGL(k_tag_template, dim3((B + 63) / 64), dim3(64), 0, s, d_in, d_desc, d_state, rp, B); KCHK();
 	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
-	mark("S2");
+	mark("S2"); tr.stage("dsrc batch: schemes, streams, tag statistics");
 
 	// ---- phase 3: scheme selection and buffer carving (host) -------------------------------------------
 	for (u32 b = 0; b < B; ++b)
@@ -719,7 +747,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	// ---- tags: dictionary resources are sized from the finalized field kinds ----------------------------------
 	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
-	mark("S3");
+	mark("S3"); tr.stage("dsrc batch: tags, order models, range coder");
 	std::vector<TagFieldRes> tres((size_t)B * DSRC_MAX_FIELDS);
 	memset(tres.data(), 0, sizeof(TagFieldRes) * tres.size());
 	size_t tz_lo = al(A.top, 256); A.top = tz_lo;
@@ -948,7 +976,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	std::vector<u32> bk_flags;
 	if (use_bk && getenv("DSRC_GPU_DEBUG")) { bk_flags.resize(NJ); HIPCHK(hipMemcpyAsync(bk_flags.data(), AP<u32>(h, o_bk), NJ * 4, hipMemcpyDeviceToHost, s)); }
 	HIPCHK(hipStreamSynchronize(s));
-	mark("S4");
+	mark("S4"); tr.stage("dsrc batch: assemble");
 	if (!bk_flags.empty())
 	{
 		u32 on = 0, back = 0;
@@ -1161,11 +1189,12 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 	if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (decode, phase 1)");
 	DecDesc* d_desc = AP<DecDesc>(h, o_desc); DecState* d_state = AP<DecState>(h, o_state);
 	HIPCHK(hipEventRecord(h->ev[0], s));
+	TraceRange tr; tr.stage("dsrc decode: headers");
 	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(DecDesc) * B, hipMemcpyHostToDevice, s));
 	hipLaunchKernelGGL(k_dec_meta, dim3((B + 63) / 64), dim3(64), 0, s, io.d_in, d_desc, d_state, prm); KCHK();
 	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(DecState) * B, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
-	mark("meta");
+	mark("meta"); tr.stage("dsrc decode: titles");
 
 	// what the device says about the blocks so far (mid-pass and final)
 	auto check_blocks = [&](bool final) -> int
@@ -1244,7 +1273,7 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 		{
 			HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(DecState) * B, hipMemcpyDeviceToHost, s));
 			HIPCHK(hipStreamSynchronize(s));
-			mark("tags");
+			mark("tags"); tr.stage("dsrc decode: quality");
 			const int rc = check_blocks(false);
 			if (rc) return rc;
 			u64 sum = 0;
@@ -1339,7 +1368,7 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 		{
 			HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(DecState) * B, hipMemcpyDeviceToHost, s));
 			HIPCHK(hipStreamSynchronize(s));
-			mark("quality");
+			mark("quality"); tr.stage("dsrc decode: DNA, layout");
 			const int rc = check_blocks(false);
 			if (rc) return rc;
 			std::vector<DecTab> dtabs;
