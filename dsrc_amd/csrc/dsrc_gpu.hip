@@ -121,6 +121,10 @@ struct QBatch
 #ifndef DSRC_SORT_SLICE_MB
 #define DSRC_SORT_SLICE_MB 1792
 #endif
+// ... unless the batch is large anyway: with >= 2.5 GB of chunks (300 of 8 MiB) the slice is the 7 GiB of rounds 1-4 -- launch groups of
+// 128 streams are 3 % faster than groups of 32 (4 x 450 blocks: 54.1 against 52.3 GB/s, profiles/r05_sweep_slice.txt), and 7 GiB are a
+// sixth of such a batch's arena, not a third of it as for the 192-chunk batches of the command line
+static size_t slice_budget(size_t in_total) { return (size_t)(in_total >= ((size_t)2560 << 20) ? 7168 : DSRC_SORT_SLICE_MB) << 20; }
 
 } // namespace
 
@@ -233,7 +237,7 @@ size_t estimate_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
 	const bool rc = h->set.dna_order > 0 || h->set.quality_order > 0;
 	size_t tot = 0, mx = 0;
 	for (u32 i = 0; i < n; ++i) { tot += (size_t)sizes[i] + 4096; mx = std::max(mx, (size_t)sizes[i]); }
-	const size_t sort_slice = std::min(tot * 14, ((size_t)DSRC_SORT_SLICE_MB << 20) + mx * 16);       // see slice_lo in run_batch
+	const size_t sort_slice = std::min(tot * 14, slice_budget(tot) + mx * 16);       // see slice_lo in run_batch
 	// measured at -d3 -q2 (round 5: streams carved from the statistics, one byte and a sixteenth of staging per range-coded symbol):
 	// 8.6 x the input + the slice; a batch that needs more -- other data, worst-case staging -- says so and is run again
 	return tot * (h->rc_caps_worst ? 21 : 18) / 2 + (rc ? sort_slice : 0) + (size_t)n * (1u << 20) + (16u << 20);
@@ -660,7 +664,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		// ~128 streams of an 8 MiB chunk per slice.  Larger slices (one k_sort workgroup per CU) are no faster for one
 		// instance, and with several instances sharing the GPU shorter launches interleave better (measured: 14 GiB
 		// 17.5, 7 GiB 19.6, 3.5 GiB 19.0 GB/s with four instances)
-		const size_t budget = (env ? (size_t)atol(env) : (size_t)DSRC_SORT_SLICE_MB) << 20;
+		const size_t budget = env ? (size_t)atol(env) << 20 : slice_budget(in_total);
 		size_t need_max = 128;
 		for (u32 i = 0; i < NJ; ++i) need_max = std::max(need_max, ((size_t)jobs[i].n * 8 + 64) * 2);
 		const u32 max_jobs = (u32)std::max<size_t>(1, budget / need_max);
