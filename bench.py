@@ -34,6 +34,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 RECS_PER_BLOCK = 22300
 PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_final.json")   # written by tools/r05_pmc.sh from rocprofv3 --pmc passes of the library it names
 MAX_RESIDENT = 3                  # distinct input shards kept in HBM per scheduler instance (2 when N > 1: rank 0 also holds the gathered streams)
+MAX_RESIDENT_BOX = [MAX_RESIDENT]   # ... lowered by main() when the device has less free HBM than the run would take
 
 
 def csrc_sha() -> str:
@@ -143,7 +144,7 @@ class Lane:
         self.cap_out = cap_in // 2
         # all inputs of the timed region stay resident in HBM; beyond MAX_RESIDENT distinct shards per lane they are
         # reused cyclically (a shard is ~3.4 GB, far beyond any cache)
-        self.n_res = min(n_sub, MAX_RESIDENT if n_out == 1 else 2)
+        self.n_res = min(n_sub, MAX_RESIDENT_BOX[0] if n_out == 1 else min(2, MAX_RESIDENT_BOX[0]))
         for k in range(self.n_res):
             gid = (rank * n_lanes + lane_id) * MAX_RESIDENT + k     # disjoint record range per (rank, lane, shard)
             first = 1 + gid * recs
@@ -484,6 +485,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--blocks", type=int, default=int(os.environ.get("DSRC_BENCH_BLOCKS", "1800")), help="8 MiB chunks per step per GPU")
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DSRC_BENCH_PIPELINE", "4")), help="scheduler instances per GPU (round 4: four batches of 450 blocks: 39-40 GB/s; five of 300: 35-37)")
+    ap.add_argument("--buf-mb", type=int, default=8, help="chunk size (the reference's -b; 8 = BASELINE's configurations; -m1 / -m2 of the reference's command line are 64 / 256)")
     ap.add_argument("--dna", type=int, default=3)
     ap.add_argument("--qua", type=int, default=2)
     ap.add_argument("--no-cpu", action="store_true")
@@ -493,6 +495,9 @@ def main():
     ap.add_argument("--check", type=int, default=2, help="blocks of the first sub-batch to verify against the oracle")
     ap.add_argument("--dump-step", default=None, help="N > 1 code path only (tests): rank 0 writes the gathered block stream of the last step as an archive (gathered.dsrc) and the FASTQ text of that step (step.fastq) into this directory")
     args = ap.parse_args()
+    global BUF, RECS_PER_BLOCK
+    if args.buf_mb != 8:
+        BUF = args.buf_mb << 20; RECS_PER_BLOCK = RECS_PER_BLOCK * args.buf_mb // 8
 
     # Every scheduler instance drives two HIP streams (front end + range coder).  The HIP runtime multiplexes streams onto
     # 4 hardware queues by default, which serialises unrelated instances behind each other's 0.25 s range-coder kernel
@@ -500,7 +505,7 @@ def main():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(2 * max(1, args.pipeline) + 6))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None; torch = None
+    dist = None; torch = None; size_group = None
     if world > 1 or os.environ.get("DSRC_BENCH_FORCE_DIST"):      # FORCE_DIST: exercise the N > 1 code path with one rank
         import torch as torch_
         import torch.distributed as dist_
@@ -508,6 +513,7 @@ def main():
         torch.cuda.set_device(local)
         dist_.init_process_group("nccl", device_id=torch.device("cuda", local))
         dist = dist_
+        size_group = dist.new_group(backend="gloo")        # the footer tables go over the host (dsrc_amd/dist.py: gather_block_stream)
 
     from dsrc_amd.config import Config
     cfg = Config.from_levels(args.dna, args.qua)
@@ -521,6 +527,25 @@ def main():
             return t.data_ptr(), t
         return h.dev_alloc(cap), None
 
+    # What the scheduler instances of this process will take of the device, against what is free: batch arena (~9 x the chunks of a
+    # sub-batch + the element slice), the resident input shards, the output buffers -- and on rank 0 of a multi-GPU run one receive
+    # buffer per peer.  Too much: fewer resident shards first, then smaller sub-batches (a step stays `--blocks` chunks: more of them).
+    def hbm_need(sb, n_res):
+        chunks = sb * RECS_PER_BLOCK * 1.02 * 384
+        per_lane = chunks * 9.0 + (7.5e9 if chunks >= 2.5e9 else 1.9e9) + n_res * chunks + (2 if dist is not None else 1) * chunks / 2
+        return P * per_lane + ((world - 1) * chunks / 2 if dist is not None and rank == 0 else 0)
+    try:
+        from dsrc_amd._lib import load as _load
+        import ctypes as _C
+        fr = _C.c_uint64(); tot_ = _C.c_uint64()
+        if _load().dsrcgpu_device_memory(local, _C.byref(fr), _C.byref(tot_)) == 0:
+            while MAX_RESIDENT_BOX[0] > 1 and hbm_need(sub_blocks, min(MAX_RESIDENT_BOX[0], 2 if dist is not None else 3)) > 0.92 * fr.value:
+                MAX_RESIDENT_BOX[0] -= 1
+            while sub_blocks > 64 and hbm_need(sub_blocks, MAX_RESIDENT_BOX[0]) > 0.92 * fr.value:
+                sub_blocks = sub_blocks * 3 // 4
+            args.blocks = sub_blocks * P
+    except OSError:
+        pass
     lanes = [Lane(cfg, local, sub_blocks, total_steps, rank, i, P, alloc_out, n_out=2 if dist is not None else 1) for i in range(P)]
 
     if dist is not None:
@@ -551,7 +576,7 @@ def main():
         from dsrc_amd.dist import gather_block_stream
         for li, ln in enumerate(lanes):
             _, o_sizes, _, _ = ln.results[step]
-            res = gather_block_stream(o_sizes, ln.outs[step % len(ln.outs)][1], recv_bufs=recv_bufs)
+            res = gather_block_stream(o_sizes, ln.outs[step % len(ln.outs)][1], recv_bufs=recv_bufs, size_group=size_group)
             if keep is not None:
                 keep(li, ln, res)
 
@@ -716,8 +741,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u16/u32 integer",
             "data": f"synthetic (counter-based generator, in HBM; {lanes[0].n_res} distinct ~{sub_blocks * 8.4 / 1e3:.1f} GB shards per scheduler instance = {P * lanes[0].n_res * sub_blocks * 8.4 / 1e3:.1f} GB of distinct records per GPU, cycled)",
-            "config": {"workload": f"Synthetic Illumina 150 bp FASTQ, 100M-read data set shape (BASELINE configs[2]), -d{args.dna} -q{args.qua} -b8; "
-                                   f"step = {args.blocks} consecutive 8 MiB chunks per GPU, device-resident, {P} scheduler instances per GPU",
+            "config": {"workload": f"Synthetic Illumina 150 bp FASTQ, 100M-read data set shape (BASELINE configs[2]), -d{args.dna} -q{args.qua} -b{args.buf_mb}; "
+                                   f"step = {args.blocks} consecutive {args.buf_mb} MiB chunks per GPU, device-resident, {P} scheduler instances per GPU",
                        "blocks_per_step": args.blocks, "pipeline": P,
                        "parallelism": (f"{world} process(es), one per GPU ({dist.get_world_size()} ranks in the RCCL group): contiguous partId ranges, no data-path collective; per step the block sizes are all-gathered and "
                                        f"every rank's block stream goes to rank 0 by point-to-point send (RCCL), overlapped with the next step") if dist is not None else "1 GPU",

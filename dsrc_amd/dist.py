@@ -28,12 +28,17 @@ def shard_range(n_parts: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def gather_block_stream(block_sizes: List[int], payload: torch.Tensor, group=None,
-                        recv_bufs: Optional[List[torch.Tensor]] = None) -> Optional[Tuple[List[int], List[torch.Tensor]]]:
+                        recv_bufs: Optional[List[torch.Tensor]] = None, size_group=None) -> Optional[Tuple[List[int], List[torch.Tensor]]]:
     """Gather every rank's (block_sizes, concatenated blocks) to rank 0.
 
     payload: 1-D uint8 tensor holding this rank's blocks back to back (on the device for nccl).
     recv_bufs: optional, rank 0 only: one pre-allocated uint8 tensor per rank (entry 0 unused) that the peers' streams are
     received into -- a caller that gathers inside a timed loop allocates them once.
+    size_group: optional host-side group (gloo) for the footer table.  The block sizes are host integers on every rank (the batch
+    call returned them); through the device group they travel as tensors and come back with a device synchronisation per
+    all-gather (`int()`, `.tolist()`), which in a loop that overlaps the gather with the next step's compression stalls the
+    thread behind kernels it has nothing to do with.  With a host group the table is a few KB over TCP and the device group carries
+    the payloads only.
     Returns on rank 0: (all block sizes in archive order, [payload tensor of rank 0, 1, ...]); None elsewhere.
     """
     world = dist.get_world_size(group)
@@ -41,17 +46,25 @@ def gather_block_stream(block_sizes: List[int], payload: torch.Tensor, group=Non
     dev = payload.device
     total = int(sum(block_sizes))
     assert payload.numel() >= total
-    # 1) footer table: counts, then sizes padded to the largest count
-    cnt = torch.tensor([len(block_sizes), total], dtype=torch.int64, device=dev)
-    cnts = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(cnts, cnt, group=group)
-    counts = [int(c[0]) for c in cnts]; totals = [int(c[1]) for c in cnts]
-    mx = max(counts) if counts else 0
-    mine = torch.zeros(max(mx, 1), dtype=torch.int64, device=dev)
-    if block_sizes:
-        mine[: len(block_sizes)] = torch.tensor(block_sizes, dtype=torch.int64, device=dev)
-    allsz = [torch.zeros(max(mx, 1), dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(allsz, mine, group=group)
+    # 1) footer table
+    if size_group is not None:
+        tables = [None] * world
+        dist.all_gather_object(tables, [int(x) for x in block_sizes], group=size_group)
+        counts = [len(t) for t in tables]; totals = [sum(t) for t in tables]
+        allsz = tables
+    else:
+        # counts, then sizes padded to the largest count
+        cnt = torch.tensor([len(block_sizes), total], dtype=torch.int64, device=dev)
+        cnts = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(cnts, cnt, group=group)
+        counts = [int(c[0]) for c in cnts]; totals = [int(c[1]) for c in cnts]
+        mx = max(counts) if counts else 0
+        mine = torch.zeros(max(mx, 1), dtype=torch.int64, device=dev)
+        if block_sizes:
+            mine[: len(block_sizes)] = torch.tensor(block_sizes, dtype=torch.int64, device=dev)
+        allsz = [torch.zeros(max(mx, 1), dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(allsz, mine, group=group)
+        allsz = [t[: counts[r]].tolist() for r, t in enumerate(allsz)]
     # 2) payloads: direct send to rank 0
     if rank == 0:
         if recv_bufs is not None:
@@ -65,7 +78,7 @@ def gather_block_stream(block_sizes: List[int], payload: torch.Tensor, group=Non
                 w.wait()
         sizes: List[int] = []
         for r in range(world):
-            sizes += [int(x) for x in allsz[r][: counts[r]].tolist()]
+            sizes += [int(x) for x in allsz[r][: counts[r]]]
         return sizes, bufs
     if total > 0:
         for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, payload[:total].contiguous(), 0, group)]):

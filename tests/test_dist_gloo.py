@@ -24,6 +24,7 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    side = dist.new_group(backend="gloo")
     from dsrc_amd import synth
     from dsrc_amd.dist import gather_block_stream, shard_range
     from tests._oracle import Config, Oracle
@@ -48,7 +49,10 @@ def _worker(rank, world, port, q):
         blocks = [b for b, _, _ in o.compress_blocks_state(cfg, chunks[lo:hi], fields_cap=seed)]
         payload = torch.frombuffer(bytearray(b"".join(blocks)), dtype=torch.uint8) if blocks else torch.zeros(0, dtype=torch.uint8)
         res = gather_block_stream([len(b) for b in blocks], payload)
+        # the same with the footer table on a host-side group of its own (what bench.py --gpus N does next to nccl)
+        res2 = gather_block_stream([len(b) for b in blocks], payload, size_group=side)
         if rank == 0:
+            assert res2[0] == res[0] and [bytes(t.numpy().tobytes()) for t in res2[1]] == [bytes(t.numpy().tobytes()) for t in res[1]]
             sizes, bufs = res
             arc = archive_bytes(sizes, [bytes(t.numpy().tobytes()) for t in bufs], dna_order=cfg.dna_order, quality_order=cfg.quality_order,
                                 lossy=False, crc=crc, tag_flags=0, quality_offset=33, plus_repetition=False, color_space=False)

@@ -42,6 +42,14 @@ def test_bench_dist_path_gathers_the_cli_archive(tmp_path):
     cli = str(tmp_path / "cli.dsrc")
     subprocess.check_call([CLI, "c", "-d3", "-q2", str(tmp_path / "step.fastq"), cli])
     assert _md5(str(tmp_path / "gathered.dsrc")) == _md5(cli)
+    # two timed steps: the gather of step s runs while step s + 1 is being compressed into the other output buffer (StepGates);
+    # rank 0's table and every rank's digest of its own stream are checked after the timed region
+    env["MASTER_PORT"] = str(_free_port())
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--pipeline", "2", "--blocks", "8", "--steps", "2", "--warmup", "1",
+                          "--no-cpu", "--decode-blocks", "0", "--check", "1"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=550)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([x for x in out.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["config"]["gather_verified"] is True and line["steps"] == 2 and "1 ranks in the RCCL group" in line["config"]["parallelism"]
 
 
 def _worker(rank, world, port, q):
