@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -145,7 +146,7 @@ struct dsrcgpu_handle
 	dsrcgpu_dataset ds;
 	int device = 0;
 	hipStream_t stream = nullptr;
-	hipStream_t rc_stream = nullptr;    // high priority: k_rc only
+	hipStream_t rc_stream = nullptr;    // k_rc only (and the DNA chains of a verifying pass)
 	Arena arena;
 	u64 arena_fixed = 0;
 	u32 fields_cap = 0;              // capacity of the reference's TagStats::fields vector, carried block to block
@@ -1535,9 +1536,12 @@ int dsrcgpu_create(const dsrcgpu_settings* settings, const dsrcgpu_dataset* data
 		// non-blocking: a host framework's work on the legacy default stream (torch, RCCL bookkeeping) must not
 		// serialise with the scheduler's streams.  (CUs reserved for k_rc through a CU mask were measured in rounds 2 and 4: no gain.)
 		HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-		int lo_p = 0, hi_p = 0;
-		HIPCHK(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
-		HIPCHK(hipStreamCreateWithPriority(&h->rc_stream, hipStreamNonBlocking, hi_p));
+		// k_rc has a stream of its own, of the SAME priority as the front end's (round 5).  Rounds 1-4 gave it the highest: its few waves
+		// were not to queue behind other instances' data-parallel kernels.  Since the coder wave has its SIMD to itself and eight loader
+		// waves feed it, k_rc takes its 118 ms whatever runs beside it -- and the priority only held the front ends back: 4 x 450 blocks
+		// 52.3 - 54.8 GB/s with the high-priority stream, 55.1 - 56.7 without (three runs each, profiles/r05_rcprio.txt; the same
+		// through a CU-mask stream over all CUs, and confining k_rc to 16 / 32 / 64 CUs of an instance's own changed nothing beyond that).
+		HIPCHK(hipStreamCreateWithFlags(&h->rc_stream, hipStreamNonBlocking));
 	}
 	for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreate(&h->ev[i]));
 	h->arena_fixed = arena_bytes;
