@@ -963,8 +963,8 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			}
 			stage_mark(1);
 		}
-		// the serial coder runs on its own high-priority stream: its few waves must not queue behind the
-		// data-parallel kernels of another scheduler instance sharing the GPU
+		// the serial coder runs on a stream of its own: its launch must not queue behind this instance's next kernels, nor they behind it (see dsrcgpu_create; the
+		// other instances' data-parallel kernels run beside it)
 		HIPCHK(hipEventRecord(h->ev[4], s));
 		HIPCHK(hipStreamWaitEvent(h->rc_stream, h->ev[4], 0));
 		HIPCHK(hipEventRecord(h->ev[2], h->rc_stream));
