@@ -219,7 +219,7 @@ def measure_decode(lanes, cfg, n_blocks, last_step, pmc, n_inst=int(os.environ.g
     `n_blocks` per pass (every copy is decoded into its own text; the decoder's work does not depend on the data being distinct).
     `n_inst` decoding instances run `passes` passes each, concurrently: a pass is a chain of stages (titles, quality, DNA,
     layout) of which the quality stage fills the SIMDs and the DNA stage (one lane per block) hardly uses them, so two passes in
-    flight overlap one's DNA stage with the other's quality stage (DESIGN section 11).
+    flight overlap one's DNA stage with the other's quality stage (DESIGN section 7).
     The compression instances are closed first: a decoding pass wants the HBM for model tables (one per block in flight)."""
     from dsrc_amd._lib import Handle
     ln = lanes[0]
@@ -280,7 +280,7 @@ def measure_decode(lanes, cfg, n_blocks, last_step, pmc, n_inst=int(os.environ.g
                          "achieved": round(alg / dt / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 6), "pass_ms": round(pass_ms, 1), "launch_bytes": int(text_bytes + sum(szs)),
                          "traffic": int(pmc["decode"]["bytes_per_block"] * n_blocks) if pmc and pmc.get("decode") and cfg.dna_order == 9 and cfg.quality_order == 2 else None,
-                         "note": "algorithmic bytes = block bytes in + text bytes out of a pass; a decoded stream is a chain of dependent model-row accesses, one 64-byte row fetched and written back per symbol (traffic: rocprofv3 FETCH_SIZE + WRITE_SIZE of every decoding kernel per block, profiles/r05_pmc_final.json), and the kernels are bound by latency x blocks in flight and instruction issue, not by bandwidth (DESIGN section 11)"}}
+                         "note": "algorithmic bytes = block bytes in + text bytes out of a pass; a decoded stream is a chain of dependent model-row accesses, one 64-byte row fetched and written back per symbol (traffic: rocprofv3 FETCH_SIZE + WRITE_SIZE of every decoding kernel per block, profiles/r05_pmc_final.json), and the kernels are bound by latency x blocks in flight and instruction issue, not by bandwidth (DESIGN section 7)"}}
 
 
 def measure_queue_form(cfg, device, chunks, n_handles, batches=4, per_batch=192):
@@ -347,20 +347,33 @@ def measure_queue_form(cfg, device, chunks, n_handles, batches=4, per_batch=192)
     return round(nbytes / dt / 1e6, 1), nbytes, dt
 
 
-def measure_verify(cfg, ln, n_inst):
+def measure_verify(cfg, ln, n_inst, blocks=None):
     """-c: the compressing call decodes on the device what it has just written and compares the checksums
     (dsrcgpu_settings::verify_after_compress; reference: DsrcCompressor::Process, src/DsrcWorker.cpp:53-62).  `n_inst` scheduler
-    instances run concurrently, each on one of instance 0's resident shards: a verifying pass is a chain of dependent reads per
-    block, so its rate is the number of blocks in flight over the chain's length."""
+    instances run concurrently, each on one of instance 0's resident shards -- or, with `blocks`, on a shard of that many chunks of
+    its own: a verifying pass is a chain of dependent reads per block, it takes about as long for 900 blocks as
+    for 450, so its rate is the number of blocks in flight over the chain's length."""
     from dsrc_amd._lib import Handle
     hs = [Handle(cfg.dna_order, cfg.quality_order, crc=True, quality_offset=33, device=ln.h.device, verify=True) for _ in range(n_inst)]
-    outs = [h.dev_alloc(ln.cap_out) for h in hs]
+    own = []
+    if blocks:
+        recs = int(blocks * RECS_PER_BLOCK * 1.02) + 1000
+        for i, h in enumerate(hs):
+            first = 1 + (900 + i) * recs                    # records no other shard of the run holds
+            d_in = h.dev_alloc(recs * 384)
+            nbytes = h.synth_illumina(first, recs, d_in, recs * 384)
+            off = record_offsets(first, recs)
+            assert off[-1] == nbytes
+            starts, sizes = cut_blocks(off, blocks)
+            own.append((d_in, starts, sizes))
+    cap_out = (int(blocks * RECS_PER_BLOCK * 1.02) + 1000) * 384 // 2 if blocks else ln.cap_out
+    outs = [h.dev_alloc(cap_out) for h in hs]
     done = [0] * n_inst
 
     def work(i, passes):
-        d_in, starts, sizes = ln.shard(i)
+        d_in, starts, sizes = own[i] if blocks else ln.shard(i)
         for _ in range(passes):
-            hs[i].compress_batch_device(d_in, starts, sizes, outs[i], ln.cap_out)
+            hs[i].compress_batch_device(d_in, starts, sizes, outs[i], cap_out)
             done[i] += sum(sizes)
     try:
         for i in range(n_inst):
@@ -375,8 +388,12 @@ def measure_verify(cfg, ln, n_inst):
         dt = time.perf_counter() - t0
     finally:
         for h, o in zip(hs, outs):
-            h.dev_free(o); h.close()
-    return round(sum(done) / dt / 1e6, 1), len(ln.shard(0)[1])
+            h.dev_free(o)
+        for h, (d_in, _, _) in zip(hs, own):
+            h.dev_free(d_in)
+        for h in hs:
+            h.close()
+    return round(sum(done) / dt / 1e6, 1), blocks or len(ln.shard(0)[1])
 
 
 def measure_binned(cfg, device, sub_blocks, P, steps=3):
@@ -804,7 +821,11 @@ def main():
                     ln.h.release_memory()                    # the decoding passes left ~100 GB of arena and model tables with instance 0
                     v1, nb = measure_verify(cfg, ln, 1)
                     v4, _ = measure_verify(cfg, ln, 4)
-                    line["verify"] = {"value": v4, "unit": "MB/s", "blocks_per_call": nb, "instances": 4, "one_instance": v1,
+                    big = None
+                    if sub_blocks * 2 * 2 * 8.4e6 * 11 < 230e9:          # two instances with calls of twice the blocks fit the device
+                        vb, nbb = measure_verify(cfg, ln, 2, blocks=2 * sub_blocks)
+                        big = {"value": vb, "unit": "MB/s", "blocks_per_call": nbb, "instances": 2}
+                    line["verify"] = {"value": v4, "unit": "MB/s", "blocks_per_call": nb, "instances": 4, "one_instance": v1, "larger_calls": big,
                                       "what": "-d3 -q2 -c: dsrcgpu_compress_batch_device with calculate_crc32 + verify_after_compress (the blocks are decoded on the device and the three CRC-32 compared), inputs and outputs in HBM",
                                       "cpu_baseline": crc_cpu}
                     d_in, starts, sizes = ln.shard(0)

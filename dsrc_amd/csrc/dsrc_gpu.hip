@@ -1270,7 +1270,7 @@ int run_decode(dsrcgpu_handle* h, DecodeIO io)
 	else
 	{
 		// A stream advances one symbol per dependent row read, so the rate of the range-decoded levels is (chains in flight) /
-		// latency: every block of the batch gets its own table, sized from the scheme byte of its stream (DESIGN section 11)
+		// latency: every block of the batch gets its own table, sized from the scheme byte of its stream (DESIGN section 7)
 		const u64 budget_words = dec_table_budget(h) / 4;
 		u64 region_words = 0;
 		std::vector<DecTab> qtabs;

@@ -863,7 +863,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 		if (out != stdout) { struct stat sb; regular = fstat(fileno(out), &sb) == 0 && S_ISREG(sb.st_mode); }
 
 		const uint64 nBlocks = rd.BlockCount();
-		// A decoding pass is a chain per block: it takes about as long for 1000 blocks as for 10 (DESIGN.md section 11), so
+		// A decoding pass is a chain per block: it takes about as long for 1000 blocks as for 10 (DESIGN.md section 7), so
 		// passes are LARGE -- up to 4800 blocks, 14 GiB of archive -- and few handles run at a time: with an order model every
 		// block in flight holds a model table of up to 64 MiB, and the handles of a device share the HBM for them.
 		const std::vector<int> devs = args.devices.empty() ? std::vector<int>(1, args.device) : args.devices;

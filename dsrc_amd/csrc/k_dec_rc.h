@@ -411,7 +411,7 @@ __device__ __forceinline__ void qrc_decode(BitSrc& s, u32* table, u32 ord, u32 r
 // ---- quality, the lean loop (round 5) -------------------------------------------------------------------------------------------
 // The loop above is what the compiler makes of the straightforward formulation: ~110 instructions per symbol, two thirds of them
 // scalar control flow and 64-bit scalar arithmetic, and a wave issues one instruction per ~4.6 cycles -- the stage saturates at
-// ~12 GB/s however many blocks are in flight (DESIGN section 11).  This one is written for instruction count, N <= 64 (one counter per lane):
+// ~12 GB/s however many blocks are in flight (DESIGN section 7).  This one is written for instruction count, N <= 64 (one counter per lane):
 //   * 32-bit coder value: on every stream an encoder writes, buffer - low < range <= 2^32 (the first four bytes of the stream are
 //     zero); anything else is refused (DEC_ERR_FORMAT) instead of being decoded the reference's undefined way.  Products are
 //     32 bits (count * r <= total * r <= range), the search is one v_mul_lo + one compare;

@@ -64,7 +64,7 @@ struct CtxJob     // one (block, stream)
 typedef u64 __attribute__((aligned(1))) u64_unaligned;
 typedef u32 __attribute__((aligned(1))) u32_unaligned;
 
-// floor(n / d) for n < 2^32, d <= 2^16 with m = ceil(2^48 / d) (same identity as rc_div, DESIGN.md section 5)
+// floor(n / d) for n < 2^32, d <= 2^16 with m = ceil(2^48 / d) (same identity as rc_div, DESIGN.md section 4)
 __device__ __forceinline__ u32 exact_div(u32 n, u32 m_lo, u32 m_hi)
 {
 	const u64 p = (u64)n * m_hi + __umulhi(n, m_lo);
@@ -1024,7 +1024,7 @@ __device__ __forceinline__ void rc_fetch(RcPack* r, const u8* base, u32 pitch, u
 	}
 }
 
-// ... and turns them into the coder's 12-byte records (reciprocal of the total, DESIGN.md section 5) in the rows of `buf`;
+// ... and turns them into the coder's 12-byte records (reciprocal of the total, DESIGN.md section 4) in the rows of `buf`;
 // a 3-dword stride over the lanes touches every LDS bank once
 __device__ __forceinline__ void rc_convert(LDS_AS U4* buf, const RcPack* r, u32 lw, u32 n_live)
 {

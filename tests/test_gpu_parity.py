@@ -282,7 +282,7 @@ def test_read_lengths_at_wave_boundaries(gpu, oracle, d, q, lossy):
     the first, last and 64th lane of a 64-base step: the per-base transform and the stream compaction of k_prep_stats / k_prep_write
     (LosslessRecordsProcessor::ProcessForward, src/RecordsProcessor.cpp:209-267; lossy :344-408) where a wave's `in the read`
     mask changes.  (Round 2 saw a GPU-only wrong quality stream from k_prep_write with the transform called under that mask,
-    DESIGN.md section 10; bit-exact blocks over these lengths pin the streams both kernels write.)"""
+    NOTES/rounds_1_to_4.md section 10; bit-exact blocks over these lengths pin the streams both kernels write.)"""
     import random
     rng = random.Random(11 * d + q)
     amb = b"N" if (d > 0 and not lossy) else b"NRYKMSW"          # lossless order-k DNA takes at most 8 symbols (SURVEY Appendix B)

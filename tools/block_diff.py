@@ -1,5 +1,5 @@
 """Compress one synthetic 20 k-read chunk at -d0 -q0 on the GPU and print where the block differs from the oracle's
-(section sizes, first differing byte).  Written while chasing the k_prep_write discrepancy of round 2:
+(section sizes, first differing byte).  Written while chasing the k_prep_write discrepancy of round 2 (NOTES/rounds_1_to_4.md section 10):
 build dsrc_amd/csrc with -DFAST_WRITE=true to reproduce it.  Usage: python tools/block_diff.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

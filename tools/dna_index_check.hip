@@ -1,6 +1,6 @@
 // Device check of transform_base / dna_index against a host restatement for every character (tools/; run on the GPU box:
 //   cd tools && hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -I../include -o /tmp/di dna_index_check.hip && /tmp/di).
-// Written while chasing the k_prep_write discrepancy of round 2: the function is identical on the device.
+// Written while chasing the k_prep_write discrepancy of round 2 (NOTES/rounds_1_to_4.md section 10): the function is identical on the device.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,4 +1,4 @@
-// Stand-alone reproducer for the round-2 k_prep_write discrepancy (task 5):
+// Stand-alone reproducer for the round-2 k_prep_write discrepancy (task 5; NOTES/rounds_1_to_4.md section 10):
 // the inner loop of k_prep_write (dsrc_amd/csrc/k_parse.h) in its two forms over synthetic records,
 //   GOOD: transform_base<true>() evaluated by every lane, `in_r` applied afterwards (what ships),
 //   BAD : transform_base<true>() called under `if (in_r)`                             (what miscompared on gfx950),
