@@ -600,9 +600,7 @@ bool DsrcCompressorGPU::Process(const InputParameters& args)
 				}
 			}
 			catch (const std::exception& e) { pl.Fail(e.what()); }
-			// the instance's HBM goes back in this thread, next to the other instances' last batches (see DsrcDecompressorGPU::Process)
-			if (h && args.exitWhenDone) (void)dsrcgpu_release_memory(h);
-			if (h && !args.exitWhenDone) dsrcgpu_destroy(h);
+			if (h && !args.exitWhenDone) dsrcgpu_destroy(h);       // (a command-line process leaves its HBM to the exit: see DsrcDecompressorGPU::Process)
 		};
 		for (uint32 i = 0; i < instances; ++i) workers.emplace_back(work, i);
 
@@ -1056,16 +1054,46 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 					mark(idx, k, "start");
 					in.Reserve(inBytes);
 					std::vector<const uint8_t*> ptrs(n); std::vector<uint32> words(n);
-					{	// the blocks of the batch, read by up to 4 threads (positioned reads)
+					// the mapped road sends the blocks up in eight parts, each as soon as its blocks have been read
+					const bool mappedRoad = map && !mapBroken;
+					bool uploaded = false;
+					{	// the blocks of the batch, read by up to 32 threads (positioned reads; 12 GB by 2 x 16 threads took 0.85 s of an 8.2 s run)
+						constexpr uint32 PARTS = 8;
 						std::atomic<uint32> nextBlock(0); std::atomic<bool> bad(false);
+						std::atomic<uint32> partDone[PARTS];
+						for (auto& x : partDone) x.store(0);
+						const uint32 per = (n + PARTS - 1) / PARTS;
+						std::mutex um; std::condition_variable ucv;
 						auto get = [&]()
 						{
-							try { for (uint32 i; (i = nextBlock++) < n;) rd.ReadBlock(lo + i, in.p + at[i]); }
-							catch (...) { bad = true; }
+							try
+							{
+								for (uint32 i; (i = nextBlock++) < n;)
+								{
+									rd.ReadBlock(lo + i, in.p + at[i]);
+									const uint32 pt = i / per, inPart = std::min(n, (pt + 1) * per) - pt * per;
+									if (++partDone[pt] == inPart) { std::lock_guard<std::mutex> g(um); ucv.notify_all(); }
+								}
+							}
+							catch (...) { bad = true; std::lock_guard<std::mutex> g(um); ucv.notify_all(); }
 						};
 						std::vector<std::thread> rs;
-						for (uint32 t = 1; t < std::min<uint32>(16, n); ++t) rs.emplace_back(get);
-						get();
+						for (uint32 t = 0; t < std::min<uint32>(32, n); ++t) rs.emplace_back(get);
+						if (mappedRoad && dBlocks.Reserve(inBytes + 64))
+						{
+							for (uint32 pt = 0; pt * per < n && !bad; ++pt)
+							{
+								const uint32 b0 = pt * per, b1 = std::min(n, b0 + per);
+								{
+									std::unique_lock<std::mutex> g(um);
+									ucv.wait(g, [&] { return bad.load() || partDone[pt].load() == b1 - b0; });
+								}
+								if (bad) break;
+								const uint64 o0 = at[b0], o1 = b1 < n ? at[b1] : inBytes;
+								if (dsrcgpu_dev_upload(h, (uchar*)dBlocks.p + o0, in.p + o0, o1 - o0) != DSRCGPU_OK) { bad = true; break; }
+							}
+							uploaded = !bad;
+						}
 						for (auto& t : rs) t.join();
 						if (bad) throw DsrcException("Error reading the DSRC archive");
 					}
@@ -1084,14 +1112,14 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 					}
 					mark(idx, k, "read");
 					int rc = DSRCGPU_OK;
-					if (map && !mapBroken)
+					if (mappedRoad && !mapBroken)
 					{
 						// Round 5: the pass is device-resident -- blocks up, decode, text down as three calls of the C ABI -- so that the
 						// only thing that needs this batch's range of the output file, the copy down, is the only thing that waits for it
 						// (the reservation of the whole file takes 2 s; the third batch used to start 1.3 s late for it)
 						uint64 cap = 0; for (uint64 c : mapCaps[k]) cap += c;
 						if (!dBlocks.Reserve(inBytes + 64) || !dText.Reserve(cap + 64)) throw DsrcException(dsrcgpu_last_error(h));
-						if (dsrcgpu_dev_upload(h, dBlocks.p, in.p, inBytes) != DSRCGPU_OK) throw DsrcException(dsrcgpu_last_error(h));
+						if (!uploaded && dsrcgpu_dev_upload(h, dBlocks.p, in.p, inBytes) != DSRCGPU_OK) throw DsrcException(dsrcgpu_last_error(h));
 						mark(idx, k, "uploaded");
 						rc = dsrcgpu_decompress_batch_device(h, n, dBlocks.p, at.data(), sizes.data(), mapCaps[k].data(), dText.p, cap, offs.data(), tsz.data(), nullptr);
 						bool exact = rc == DSRCGPU_OK;
@@ -1190,9 +1218,8 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 				}
 			}
 			catch (const std::exception& e) { std::lock_guard<std::mutex> g(m); if (error.empty()) error = e.what(); cv.notify_all(); }
-			// the worker's HBM goes back here, in its own thread, next to the other workers' last passes: what a process still holds when
-			// it leaves is released by the driver one allocation after the other (1.4 s for ~150 GB, profiles/r05_e2e_third.txt)
-			if (h && args.exitWhenDone) (void)dsrcgpu_release_memory(h);
+			// (Handing the worker's HBM back here, before the process leaves, was measured: 0.3-0.5 s for the calls and the exit -- 1.4 s,
+			// the output mapping's page tables -- no shorter: profiles/r05_e2e_third.txt against r05_e2e_4_t3.txt.)
 		};
 		// a command-line process that is about to leave keeps its handles (the memory behind them has gone back above)
 		struct HandleGuard

@@ -33,8 +33,12 @@ def _bench_helpers():
     return m
 
 
-@pytest.mark.parametrize("d,q", [(3, 2), (0, 0)])
-def test_full_size_blocks(gpu, oracle, d, q):
+@pytest.mark.parametrize("d,q,binned", [(3, 2, False), (0, 0, False), (3, 2, True), (0, 0, True)])
+def test_full_size_blocks(gpu, oracle, d, q, binned):
+    """24 full 8 MiB chunks of BASELINE's generator through the device entry point: header words of every block, sampled blocks
+    against the oracle (with the carried state) and the reference's decoder.  binned: the same records with four-level qualities
+    (flavour 1 of dsrcgpu_synth_fastq, bench.py's second line): a third of a quality stream in one context at -q2 (hot buckets,
+    Rescale() inside k_model), the RLE scheme at -q0."""
     bench = _bench_helpers()
     nblocks = 24
     cfg = Config.from_levels(d, q)
@@ -43,10 +47,13 @@ def test_full_size_blocks(gpu, oracle, d, q):
     cap = recs * 384
     d_in = h.dev_alloc(cap); d_out = h.dev_alloc(cap // 2)
     first = 123456789
-    nbytes = h.synth_illumina(first, recs, d_in, cap)
+    nbytes = h.synth_illumina(first, recs, d_in, cap, binned=binned)
     off = bench.record_offsets(first, recs)
     assert off[-1] == nbytes
     starts, sizes = bench.cut_blocks(off, nblocks)
+    if binned:          # the device generator's flavour 1 is synth.illumina_fastq(binned=True)
+        from dsrc_amd import synth
+        assert h.dev_download(d_in, 200000) == synth.illumina_fastq(1200, first=first, binned=True)[:200000]
     o_offs, o_sizes, raw, comp = h.compress_batch_device(d_in, starts, sizes, d_out, cap // 2)
     blob = h.dev_download(d_out, o_offs[-1] + o_sizes[-1])
     # header words: recordsCount, maxQuaLength, flags, chunkSize (StoreMetaData, reference src/BlockCompressor.cpp:403-443)
