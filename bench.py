@@ -462,11 +462,12 @@ def write_config3_file(path, device, reads=100_000_000):
     return total
 
 
-def measure_host_e2e(src, size, td, inst=4, runs=3, gap=6.0, first_gap=12.0):
+def measure_host_e2e(src, size, td, inst=4, runs=3, gap=10.0, first_gap=14.0):
     """`dsrc-amd c` and `dsrc-amd d` (C++ host over the C ABI), file in tmpfs -> archive in tmpfs -> file in tmpfs, separated runs.
     The gaps are for the driver, not for the tool: HBM that a process has released is wiped at ~35 GB/s and an allocation that lands
     on memory still waiting for that is held until it is clean (profiles/r05_alloc_probe2.txt) -- this process has just released
-    ~200 GB, a `dsrc-amd c` run ~70 GB, a `dsrc-amd d` run ~150 GB."""
+    ~200 GB, a `dsrc-amd c` run ~70 GB, a `dsrc-amd d` run ~150 GB (a run that follows another within 6 s: 8.5 instead of 7.4 s,
+    profiles/r05_e2e_7.txt)."""
     import subprocess
     cli = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dsrc_amd", "csrc", "dsrc-amd")
     arc = os.path.join(td, "e2e.dsrc"); back = os.path.join(td, "e2e_back.fastq")

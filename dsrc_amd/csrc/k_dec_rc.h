@@ -541,8 +541,9 @@ __device__ __forceinline__ void qrc_decode_lean(BitSrc& s, u32* table, u32 ord, 
 			if (j + 1 < ql) { if (stop > ql - 1) stop = ql - 1; }
 			else { stop = ql; base_next -= pn; pn = 0; }              // the row after the LAST symbol is the next record's first: position 0
 			DEC_SGPR(buf); DEC_SGPR(base_next); DEC_SGPR(pn); DEC_SGPR(ri); DEC_SGPR(hpre); DEC_SGPR(sym_buf);
-#pragma unroll 2
-			do
+			// one symbol; the segment takes two per turn of its loop, so that what one symbol hands to the next (row, offset, context)
+			// changes registers by renaming instead of by copies at the loop's back edge (the compiler ignores `#pragma unroll` here)
+			auto symbol = [&](const u32 j) __attribute__((always_inline))
 			{
 				// ---- the row has arrived: symbol index -----------------------------------------------------------------
 				const u32 total = (u32)__builtin_amdgcn_readlane((int)cur, N - 1);
@@ -601,7 +602,9 @@ __device__ __forceinline__ void qrc_decode_lean(BitSrc& s, u32* table, u32 ord, 
 				if (ri_next == ri) nxt = upd;
 				cur = nxt; ri = ri_next; off_cur = off_next;
 				QL_PREP(idx, QL_PN(j));
-			} while (++j < stop);
+			};
+			for (; j + 2 <= stop; j += 2) { symbol(j); symbol(j + 1); }
+			if (j < stop) { symbol(j); ++j; }
 			if (!((all_m >> (N - 1)) & 1ull)) err |= DEC_ERR_FORMAT;
 			if (err) break;
 			// ---- the segment's end ------------------------------------------------------------------------------------------
