@@ -359,7 +359,8 @@ def measure_verify(cfg, ln, n_inst, blocks=None):
     if blocks:
         recs = int(blocks * RECS_PER_BLOCK * 1.02) + 1000
         for i, h in enumerate(hs):
-            first = 1 + (900 + i) * recs                    # records no other shard of the run holds
+            first = 200_000_001 + i * recs                   # records no other shard of the run holds; numbers stay below 10^9 (larger
+                                                             # numeric title fields are undefined in the reference's decoder and refused by ours)
             d_in = h.dev_alloc(recs * 384)
             nbytes = h.synth_illumina(first, recs, d_in, recs * 384)
             off = record_offsets(first, recs)
