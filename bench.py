@@ -463,7 +463,7 @@ def write_config3_file(path, device, reads=100_000_000):
     return total
 
 
-def measure_host_e2e(src, size, td, inst=4, runs=3, gap=10.0, first_gap=14.0):
+def measure_host_e2e(src, size, td, inst=4, runs=3, gap=15.0, first_gap=15.0):
     """`dsrc-amd c` and `dsrc-amd d` (C++ host over the C ABI), file in tmpfs -> archive in tmpfs -> file in tmpfs, separated runs.
     The gaps are for the driver, not for the tool: HBM that a process has released is wiped at ~35 GB/s and an allocation that lands
     on memory still waiting for that is held until it is clean (profiles/r05_alloc_probe2.txt) -- this process has just released
@@ -823,8 +823,8 @@ def main():
                     ln.h.release_memory()                    # the decoding passes left ~100 GB of arena and model tables with instance 0
                     v1, nb = measure_verify(cfg, ln, 1)
                     v4, _ = measure_verify(cfg, ln, 4)
-                    big = None
-                    if sub_blocks * 2 * 2 * 8.4e6 * 11 < 230e9:          # two instances with calls of twice the blocks fit the device
+                    big = None                       # (two instances with calls of 900 blocks: 3.66 GB/s, profiles/r05_bench_default_first.json; DSRC_BENCH_VERIFY_LARGE=1)
+                    if os.environ.get("DSRC_BENCH_VERIFY_LARGE") and sub_blocks * 2 * 2 * 8.4e6 * 11 < 230e9:
                         vb, nbb = measure_verify(cfg, ln, 2, blocks=2 * sub_blocks)
                         big = {"value": vb, "unit": "MB/s", "blocks_per_call": nbb, "instances": 2}
                     line["verify"] = {"value": v4, "unit": "MB/s", "blocks_per_call": nb, "instances": 4, "one_instance": v1, "larger_calls": big,
