@@ -701,6 +701,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	const u64 bk_elems_dna = 4096u;      // 512 buckets of 6.5 k bases: 512 rows of 8 bytes per wave, runs of 16 records per time bin
 	const u64 bk_elems_qua = 2048u;
 	const u32 bk_limit = (u32)hook_int("DSRC_GPU_BUCKET_LIMIT", (long)BK_LIMIT);
+	const u32 bk_big = (u32)hook_int("DSRC_GPU_BUCKET_BIG", (long)BK_BIG);
 	const bool use_bk = bk_enabled && NJ > 0 && h->lds64_ordered;      // k_model stands on the LDS applying atomics in lane order (k_lds_order_test)
 	size_t o_bk = 0, bk_zero_words = 0, o_bcnt = 0;
 	if (use_bk)
@@ -730,10 +731,10 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			if (j.key_bits > BK_MAX_LB) hb = std::max(hb, j.key_bits - BK_MAX_LB);
 			j.bk_hb = hb; j.bk_lb = j.key_bits - hb;
 			j.bk_mul = BK_HASH_MUL; j.bk_kmask = (u32)((1ull << j.key_bits) - 1ull);
-			j.bk_limit = bk_limit;
+			j.bk_limit = bk_limit; j.bk_big = bk_big;
 		}
 		bk_zero_words = cur;
-		o_bk = A.alloc((size_t)cur * 4 + 64);
+		o_bk = A.alloc(((size_t)cur + 2 + 128) * 4 + 64);            // + 64 records' worth of nowhere (k_model: the lanes of a short window store there)
 		// per (tile, bucket) element counts of k_part (u16); k_binoff turns the first row of every time bin into the buckets' offsets
 		size_t cnt_words = 0;
 		for (u32 i = 0; i < NJ; ++i)
@@ -866,7 +867,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 					if (!any) continue;
 					u32 lbm = 0; for (u32 i = g.lo; i < g.hi; ++i) if (jobs[i].bk_on) lbm = std::max(lbm, jobs[i].bk_lb);
 					// rows by key where a bucket's keys fit (in as little LDS as they need), else handed out on first use through a map
-#define BK_LAUNCH(NN, MB, RB) hipLaunchKernelGGL((k_model<NN, MB, RB>), dim3(((1u << hb) + MD_WAVES_FOR(RB) - 1) / MD_WAVES_FOR(RB), g.hi - g.lo), dim3(64 * MD_WAVES_FOR(RB)), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk, d_bcnt)
+#define BK_LAUNCH(NN, MB, RB) hipLaunchKernelGGL((k_model<NN, MB, RB>), dim3(((1u << hb) + MD_WAVES_FOR(RB) - 1) / MD_WAVES_FOR(RB), g.hi - g.lo), dim3(64 * MD_WAVES_FOR(RB)), 0, s, d_jobs + g.lo, lpool, AP<RcPack>(h, 0), d_bk, d_bcnt, (RcPack*)(d_bk + ((bk_zero_words + 1) & ~(size_t)1)))
 #define BK_FINISH(NN) { if ((1u << lbm) * 4 * MdRow<NN>::STRIDE <= 4096) BK_LAUNCH(NN, 0, 4096); \
 						else if ((1u << lbm) * 4 * MdRow<NN>::STRIDE <= MD_ROW_BYTES) BK_LAUNCH(NN, 0, MD_ROW_BYTES); \
 						else if (lbm <= 10) BK_LAUNCH(NN, 10, MD_ROW_BYTES); \
@@ -2064,6 +2065,15 @@ int dsrcgpu_release_memory(dsrcgpu_handle* h)
 	if (h->dec_tables) { HIPCHK(hipFree(h->dec_tables)); h->dec_tables = nullptr; h->dec_tables_cap = 0; }
 	h->last_d_out = nullptr;
 	return h->twin ? dsrcgpu_release_memory(h->twin) : DSRCGPU_OK;
+}
+
+int dsrcgpu_reserve_memory(dsrcgpu_handle* h, uint64_t arena_bytes, uint64_t table_bytes)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	HIPCHK(hipSetDevice(h->device));
+	if (arena_bytes > h->arena.cap) { const int rc = ensure_arena(h, (size_t)arena_bytes); if (rc) return rc; }
+	if (table_bytes) { const int rc = ensure_dec_tables(h, std::min<u64>(table_bytes, dec_table_budget(h))); if (rc) return rc; }
+	return DSRCGPU_OK;
 }
 
 int dsrcgpu_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? DSRCGPU_OK : DSRCGPU_E_HIP; }

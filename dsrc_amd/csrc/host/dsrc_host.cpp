@@ -1053,6 +1053,19 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 					for (uint32 i = 0; i < n; ++i) { sizes[i] = rd.BlockSizes()[lo + i]; at[i] = inBytes; inBytes += (sizes[i] + 64) & ~(uint64)63; }
 					mark(idx, k, "start");
 					in.Reserve(inBytes);
+					std::thread reserveHbm;
+					if (map && !mapBroken)
+					{	// what the pass will take of the device is asked for now, beside the reading of the archive: HBM that the previous
+						// process has just released is wiped before it is handed out, and the pass would wait for that in its middle
+						uint64 cap = 0; for (uint64 c : mapCaps[k]) cap += c;
+						const uint64 tab = rd.Settings().qualityOrder || rd.Settings().dnaOrder ? (uint64)n * (16ull << 20) : 0;
+						reserveHbm = std::thread([&, cap, tab]()
+						{
+							(void)dText.Reserve(cap + 64);
+							(void)dsrcgpu_reserve_memory(h, inBytes * 3 + (uint64)n * (1u << 20) + (32u << 20), tab);
+						});
+					}
+					struct JoinGuard { std::thread& t; ~JoinGuard() { if (t.joinable()) t.join(); } } reserveJoin{reserveHbm};
 					std::vector<const uint8_t*> ptrs(n); std::vector<uint32> words(n);
 					// the mapped road sends the blocks up in eight parts, each as soon as its blocks have been read
 					const bool mappedRoad = map && !mapBroken;
@@ -1110,6 +1123,7 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 						uchar hb[16];
 						if (rd.BlockSizes()[lo - 1] >= 16 && pread(rd.Fd(), hb, 16, (off_t)rd.BlockOffset(lo - 1)) == 16) { before = (uint32)GetBE(hb + 12, 4); haveBefore = true; }
 					}
+					if (reserveHbm.joinable()) reserveHbm.join();
 					mark(idx, k, "read");
 					int rc = DSRCGPU_OK;
 					if (mappedRoad && !mapBroken)

@@ -32,6 +32,7 @@
 #define BK_MAX_HB 10                   // bucket digit: <= 1024 buckets (k_part's LDS is k_sort's)
 #define BK_MAX_LB 11                   // key bits left inside a bucket (k_model's key -> row map)
 #define BK_LIMIT 524288                // largest bucket one wave is allowed to walk (8 K windows, a few ms)
+#define BK_BIG 16384                   // a bucket from which k_model looks for windows inside one tile's run first
 #ifndef BK_TB
 #define BK_TB 13                       // log2(records per time bin): 48 bits of record + the low bits of t fit the 8-byte slot; k_place holds a bin in LDS
 #endif                                 // (64 KB: with 14 bits and 128 KB a k_place workgroup needs a CU nearly to itself -- 1.5 ms alone, 6.9 ms next to three other instances)
@@ -422,7 +423,7 @@ template <> struct MdMapT<false> { typedef u16 T; static constexpr u32 NONE = 0x
 #endif
 //      MD_AHEAD:                     // windows of a bucket requested ahead of the one being coded
 template <int N, int MAPBITS, int ROW_BYTES>
-__global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const CtxJob* jobs, const u64* pool, RcPack* rec_pool, u32* bk, const u16* bcnt)
+__global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const CtxJob* jobs, const u64* pool, RcPack* rec_pool, u32* bk, const u16* bcnt, RcPack* nowhere)
 {
 	constexpr u32 STRIDE = MdRow<N>::STRIDE;
 	constexpr u32 ROWS = ROW_BYTES / (4 * STRIDE);
@@ -494,7 +495,7 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 	// A large bucket (a hot context: round 5 measured 75-170 k symbols with one or two rows, 2700 cycles per window, half of them the
 	// bookkeeping below) has hundreds of elements per tile, so most of its windows lie inside ONE tile's run: the tile that holds the
 	// group position g_pos is found with one ballot and the window is 64 consecutive elements of it.
-	const bool big = nb >= 16384u;
+	const bool big = nb >= j.bk_big;
 	// (s_setprio(3) for such a wave -- the launch's long pole, bound by instruction issue -- was measured: 36.2 / 35.3 against 35.9 / 35.4 GB/s)
 	auto next_window = [&]() -> u32
 	{
@@ -538,25 +539,42 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 	// the first windows are on their way while the rows are set up
 	u32 elq[MD_AHEAD], ixq[MD_AHEAD];                       // the elements of the next windows and where they lie
 #pragma unroll
-	for (u32 k = 0; k < MD_AHEAD; ++k) { ixq[k] = next_window(); elq[k] = ixq[k] != MD_NONE ? src[ixq[k]] : 0u; }
+	for (u32 k = 0; k < MD_AHEAD; ++k) { ixq[k] = next_window(); elq[k] = src[ixq[k] != MD_NONE ? ixq[k] : 0u]; }
 	if (MAPBITS) for (u32 i = lane; i < keys; i += 64) map[i] = (map_t)Map::NONE;
 	for (u32 i = lane; i < (MAPBITS ? ROWS : keys) * STRIDE; i += 64) rows[i] = md_init_word<N>(i % STRIDE);      // every counter 1
 	wave_fence();
 
 	u32 n_rows = 0;
 	// the walk in two instantiations: the rescale test costs registers and instructions that only buckets of > 32 K symbols need
+#ifdef MD_PROFILE
+	u64 pf[6] = {0, 0, 0, 0, 0, 0}; u32 pf_n = 0;
+#define MD_T(k, dep) { u64 t_; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_) : "s"(dep) : "memory"); pf[k] += t_ - pf_t; pf_t = t_; }
+#else
+#define MD_T(k, dep)
+#endif
 	auto walk = [&](auto resc_tag)
 	{
 	constexpr bool RESC = decltype(resc_tag)::value;
-	for (u32 coded = 0, dry = 0; coded < nb && dry <= MD_AHEAD;)
+	u32 coded = 0, dry = 0;
+	// one window: the elements of slot (el_slot, ix_slot) are coded and the slot takes the window MD_AHEAD further on.  The slots keep
+	// their registers (the loop below goes round them): moving a requested element to another register would wait for it -- and with
+	// it for every request made since (round 5: `s_waitcnt vmcnt(0)` at the head of the loop, a memory round trip per window)
+	auto step = [&](u32& el_slot, u32& ix_slot) -> bool
 	{
-		const u32 el = elq[0], ix = ixq[0];
+#ifdef MD_PROFILE
+		u64 pf_t; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(pf_t) :: "memory"); ++pf_n;
+#endif
+		const u32 el = el_slot, ix = ix_slot;
 		const bool valid = ix != MD_NONE;
 		const u32 n_valid = (u32)__popcll(__ballot(valid));
 		coded += n_valid;
 		dry = (n_valid || left) ? 0u : dry + 1u;               // (nothing left and nothing in flight: the counts did not add up -- not reached)
 		const u32 ix_new = next_window();
-		const u32 el_new = ix_new != MD_NONE ? src[ix_new] : 0u;
+		// (requests and stores are made by every lane, those without an element from / to a place that does not matter: a request
+		// or store under a branch cannot be counted on by the wait for an older request, which then waits for everything)
+		const u32 el_new = src[ix_new != MD_NONE ? ix_new : 0u];
+		MD_T(0, __builtin_amdgcn_readfirstlane((int)ix_new))                    // window bookkeeping, next load issued
+		MD_T(1, __builtin_amdgcn_readfirstlane((int)el))                        // the wait for this window's elements
 
 		const u32 key = el >> BK_EL_KEY_SHIFT, sym = (el >> BK_EL_SYM_SHIFT) & (u32)(N - 1);
 		u32 rid = key;
@@ -575,7 +593,7 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 				if (n_rows > ROWS)
 				{	// more contexts in this bucket than rows: the stream goes through k_sort / k_replay (their launches follow this one)
 					if (lane == 0) bk_fallback(j, bk);
-					return;
+					return false;
 				}
 				wave_fence();
 				if (leader) map[key] = (map_t)mine;
@@ -583,6 +601,7 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 				if (need) rid = (u32)map[key];
 			}
 		}
+		MD_T(2, __builtin_amdgcn_readfirstlane((int)rid))                       // key -> row
 		u64 rec = 0;
 		u32* row = rows + rid * STRIDE;
 		// Only a bucket with > 32 K symbols can bring a row to its rescale point.  There, a window in which some lane's row could get
@@ -605,18 +624,29 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 #ifdef DSRC_EMU_BUILD
 		(void)__ballot(true);                                         // the emulator runs lanes one after the other: keep them in step per window
 #endif
+		MD_T(3, __builtin_amdgcn_readfirstlane((int)(u32)rec))                  // the symbols on their rows
 		// the record takes the element's place (k_place puts the tile in stream order), or goes where it belongs at once
-		if (valid)
 		{
-			if (binned) recs[ix] = rec | ((u64)(el & (BK_BIN - 1u)) << 48);
-			else recs[(ix & ~(BK_BIN - 1u)) | (el & (BK_BIN - 1u))] = rec;
+			RcPack* to = binned ? recs + ix : recs + ((ix & ~(BK_BIN - 1u)) | (el & (BK_BIN - 1u)));
+			if (!valid) to = nowhere + lane;
+			*to = binned ? rec | ((u64)(el & (BK_BIN - 1u)) << 48) : rec;
 		}
+		el_slot = el_new; ix_slot = ix_new;
+		MD_T(4, 0)                                                               // the records stored (issue)
+		return coded < nb && dry <= MD_AHEAD;
+	};
+	for (bool go = nb != 0; go;)
+	{
 #pragma unroll
-		for (u32 k = 0; k + 1 < MD_AHEAD; ++k) { elq[k] = elq[k + 1]; ixq[k] = ixq[k + 1]; }
-		elq[MD_AHEAD - 1] = el_new; ixq[MD_AHEAD - 1] = ix_new;
+		for (u32 k = 0; k < MD_AHEAD; ++k) if (go) go = step(elq[k], ixq[k]);
 	}
 	};
 	if (may_rescale) walk(std::true_type()); else walk(std::false_type());
+#ifdef MD_PROFILE
+	if (lane == 0 && nb >= 65536u && (bucket & 3u) == 0)
+		printf("MD N=%d nb=%u rows=%u windows=%u cycles/window: book %u wait %u map %u code %u store %u\n", N, nb, n_rows, pf_n,
+			(u32)(pf[0] / pf_n), (u32)(pf[1] / pf_n), (u32)(pf[2] / pf_n), (u32)(pf[3] / pf_n), (u32)(pf[4] / pf_n));
+#endif
 }
 
 // ---- k_place: a time bin's records into stream order, in place ------------------------------------------------------------------------

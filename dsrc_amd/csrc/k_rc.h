@@ -54,7 +54,7 @@ struct CtxJob     // one (block, stream)
 	u32 bk_on, bk_binned;
 	u32 bk_hb, bk_lb;   // bucket digit bits / key bits sorted in LDS (bk_hb + bk_lb = key_bits)
 	u32 bk_mul, bk_kmask; // key = (ctx * bk_mul) & bk_kmask
-	u32 bk_boff;        // (unused since k_part works tile by tile)
+	u32 bk_big;         // a bucket of at least this many elements looks for its windows inside one tile's run first (BK_BIG; tests lower it)
 	u32 bk_fb;          // bk index of the fallback list of the stream's launch group: count, then job ids
 	u32 bk_cnt;         // index (u16 units) of the stream's per-tile bucket counts / per-bin bucket offsets (k_part, k_binoff)
 	u32 bk_limit;       // largest bucket a wave of k_model may walk (BK_LIMIT; tests lower it)

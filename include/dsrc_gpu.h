@@ -192,6 +192,12 @@ int dsrcgpu_device_memory(int device, uint64_t* free_bytes, uint64_t* total_byte
  * allocates again.  Not to be called while a call on this handle is in flight (queue form: after the last collect).  No
  * counterpart in the reference: its workers' buffers live as long as the workers. */
 int dsrcgpu_release_memory(dsrcgpu_handle* h);
+/* The opposite: a host that knows what its next call will need has the batch arena and / or the decoder's table region grown to at least
+ * these sizes NOW (nothing shrinks; the table figure is capped by the table budget) -- on a side thread, or while it is still reading its
+ * input.  Worth it where allocation is not free: HBM that another process has just released is wiped by the driver before it is handed
+ * out again (~20-35 GB/s on the measured box, NOTES/round_5.md), and the first call would otherwise wait for that in the middle of its
+ * course.  Not to be called while a call on this handle is in flight. */
+int dsrcgpu_reserve_memory(dsrcgpu_handle* h, uint64_t arena_bytes, uint64_t table_bytes);
 
 /* Optional: brings up the HIP runtime and the device context (the first HIP call of a process costs 0.3-1 s); call it on a
  * side thread while the host opens its files.  It is also the opt-in for the queue setting several handles per device need:

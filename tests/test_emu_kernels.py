@@ -385,6 +385,26 @@ def test_hot_contexts_cross_ranges(emu, oracle):
         assert run(emu, cfg, data) == oracle.compress_block(cfg, data), (d, q, lossy)
 
 
+def test_hot_buckets_windows_inside_a_run(emu, oracle, monkeypatch):
+    """Four-level qualities, skewed: a few contexts hold most of the stream.  The windows of a large bucket are looked for inside
+    one tile's run first (k_model, BK_BIG) and through the head / scatter bookkeeping otherwise; rescales in between.  The quality
+    contexts of a read of 250 split by position class, so the size from which a bucket counts as large is lowered to reach that
+    path with a block the emulator finishes in seconds (full size: tests/test_gpu_properties.py::test_full_size_blocks[binned])."""
+    import random
+    monkeypatch.setenv("DSRC_GPU_BUCKET_BIG", "512")
+    for seed, weights in [(3, (70, 15, 10, 5)), (4, (94, 3, 2, 1)), (5, (40, 30, 20, 10))]:
+        rng = random.Random(seed)
+        recs = []
+        for i in range(220):
+            seq = ''.join(rng.choice('ACGT') for _ in range(250))
+            q = ''.join(rng.choices('FA<,', weights=weights, k=250))
+            recs.append(f"@r.{i}\n{seq}\n+\n{q}")
+        data = '\n'.join(recs).encode()
+        for d, q, lossy in [(3, 2, False), (2, 2, True)]:
+            cfg = Config.from_levels(d, q, lossy)
+            assert run(emu, cfg, data) == oracle.compress_block(cfg, data), (seed, d, q, lossy)
+
+
 def test_rle_quality_alphabets(emu, oracle):
     """RLE quality scheme with 4 / 20 / 45 distinct values: LDS code tables and histograms, and their global fallbacks."""
     from tests.cases import rle_chunks
