@@ -482,15 +482,32 @@ __global__ void __launch_bounds__(WG) k_prep_write(const u8* in, const BlkDesc* 
 	const bool write_qp = st[b].min_len != st[b].max_len;      // reads of one length: the position context is a closed form of t (qua_pctx)
 	const u32 red = st[b].cs_reduced;      // k_cs_reduce: first quality and first kept base are not coded
 	const u32 waves_total = gridDim.x * (blockDim.x >> 6);
-	for (u32 r = blockIdx.x * (blockDim.x >> 6) + wave_id(); r < n_recs; r += waves_total)
+	// A record is a chain of dependent requests -- its pool entries, then its characters 64 at a time, each waited for at once: four
+	// memory round trips per read of 150, and the CU's 32 waves were too few to hide them (round 5: 5.1 ms per 512 blocks).  The
+	// next record's pool entries are requested a record ahead, and the first PW_AHEAD x 64 characters of a record all at once, by
+	// every lane (past the end of the read: the chunk's first byte).
+	constexpr u32 PW_AHEAD = 3;
+	u32 n_rlen = 0, n_so = 0, n_qo = 0, n_qoff = 0, n_doff = 0;
+	auto request = [&](u64 g) { n_rlen = rp.len[g]; n_so = rp.seq_off[g]; n_qo = rp.qual_off[g]; n_qoff = rp.q_off[g]; n_doff = rp.d_off[g]; };
+	const u32 r0 = blockIdx.x * (blockDim.x >> 6) + wave_id();
+	if (r0 < n_recs) request((u64)d.rec_base + r0);
+	for (u32 r = r0; r < n_recs; r += waves_total)
 	{
 		const u64 g = (u64)d.rec_base + r;
-		const u32 rlen = rp.len[g], len = rlen + red, so = rp.seq_off[g], qo = rp.qual_off[g] - red;
-		u8* qs = q_stream + d.q_base + rp.q_off[g];
-		u8* qps = qp_stream + d.q_base + rp.q_off[g];
-		u8* ds = d_stream + d.d_base + rp.d_off[g];
+		const u32 rlen = n_rlen, len = rlen + red, so = n_so, qo = n_qo - red;
+		u8* qs = q_stream + d.q_base + n_qoff;
+		u8* qps = qp_stream + d.q_base + n_qoff;
+		u8* ds = d_stream + d.d_base + n_doff;
+		u32 c_b[PW_AHEAD], c_q[PW_AHEAD];
+#pragma unroll
+		for (u32 k = 0; k < PW_AHEAD; ++k)
+		{
+			const u32 j = 64u * k + lane; const bool have = j < len;           // (without one: the chunk's first byte)
+			c_b[k] = p[have ? so + j : 0u]; c_q[k] = p[have ? qo + j : 0u];
+		}
+		if (r + waves_total < n_recs) request(g + waves_total);
 		u32 run = 0;
-		for (u32 j0 = 0; j0 < len; j0 += 64)
+		auto chunk = [&](const u32 j0, const u32 cb_in, const u32 cq_in)
 		{
 			const u32 j = j0 + lane;
 			const bool in_r = j < len;
@@ -499,7 +516,7 @@ __global__ void __launch_bounds__(WG) k_prep_write(const u8* in, const BlkDesc* 
 				// inside `if (in_r)` this kernel gave a wrong quality stream on the GPU once dna_index had become selects (DESIGN.md
 				// section 10; both forms as a stand-alone kernel: tools/prep_write_repro.hip) -- the emulator build, the function on its own and
 				// k_prep_stats with the same call were all right
-				const u32 cb = in_r ? (u32)p[so + j] : (u32)'A', cq = in_r ? (u32)p[qo + j] : prm.quality_offset + 40u;
+				const u32 cb = in_r ? cb_in : (u32)'A', cq = in_r ? cq_in : prm.quality_offset + 40u;
 				const u32 qq = transform_base<FAST_WRITE>(cb, cq, prm.quality_offset, prm.lossy, &sidx, &keep);
 				if (in_r) q = qq; else { keep = false; sidx = 0; }
 			}
@@ -509,6 +526,13 @@ __global__ void __launch_bounds__(WG) k_prep_write(const u8* in, const BlkDesc* 
 			const u32 at = run + (u32)__popcll(km & lanemask_lt());
 			if (k2 && at >= red) ds[at - red] = (u8)sidx;
 			run += (u32)__popcll(km);
+		};
+#pragma unroll
+		for (u32 k = 0; k < PW_AHEAD; ++k) if (64u * k < len) chunk(64u * k, c_b[k], c_q[k]);
+		for (u32 j0 = 64u * PW_AHEAD; j0 < len; j0 += 64)
+		{
+			const u32 j = j0 + lane; const bool have = j < len;
+			chunk(j0, (u32)p[have ? so + j : 0u], (u32)p[have ? qo + j : 0u]);
 		}
 	}
 }

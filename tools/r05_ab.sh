@@ -4,7 +4,7 @@
 # variant: one instance alone (512 blocks, default data) and the four-level-quality shards (1800 blocks, four instances).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp DSRC_BENCH_NO_FORMS=1
-prof() { local D=gpurun_out/prof_tmp_$$; rm -rf $D; rocprofv3 --kernel-trace --stats -d $D -- "$@" > $D.out 2> $D.err; local F=$(find $D -name "*.db" | head -1); python tools/prof_summary.py "$F" $D.txt > /dev/null; grep -E "k_model|k_part|k_place|k_rc" $D.txt | cut -c1-118; rm -rf $D $D.err $D.out $D.txt; }
+prof() { local D=gpurun_out/prof_tmp_$$; rm -rf $D; rocprofv3 --kernel-trace --stats -d $D -- "$@" > $D.out 2> $D.err; local F=$(find $D -name "*.db" | head -1); python tools/prof_summary.py "$F" $D.txt > /dev/null; grep -E "k_model|k_part|k_place|k_rc|k_prep|k_index|k_count|k_tag_emit|k_tag_scan|k_assemble" $D.txt | cut -c1-118; rm -rf $D $D.err $D.out $D.txt; }
 for v in "$@"; do
   L=$PWD/dsrc_amd/csrc/libdsrc_gpu.so; [ "$v" != built ] && L=$PWD/dsrc_amd/csrc/_var/lib_$v.so
   [ -f $L ] || continue
