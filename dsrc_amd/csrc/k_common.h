@@ -40,6 +40,18 @@ __device__ __forceinline__ u32 wave_incl_scan_dpp(u32 v)
 #endif
 }
 
+// lane i takes lane i - 1's value, lane 0 `first`: one DPP move (gfx9 wave_shr:1; lanes without a source keep the old value)
+// instead of a ds_bpermute round trip
+__device__ __forceinline__ u32 wave_shr1(u32 v, u32 first)
+{
+#ifdef DSRC_EMU_BUILD
+	const u32 t = __shfl_up(v, 1);
+	return lane_id() == 0 ? first : t;
+#else
+	return (u32)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);
+#endif
+}
+
 __device__ __forceinline__ u32 wave_max(u32 v)
 {
 	for (u32 d = 32; d >= 1; d >>= 1) { u32 t = __shfl_xor(v, (int)d); v = t > v ? t : v; }

@@ -233,10 +233,17 @@ __device__ __forceinline__ u32 lossy_bin(u32 q)
 #define FAST_WRITE true
 #endif
 // one base: returns transformed quality, sets *keep / *sidx
+__device__ __forceinline__ u32 transform_base_s(u32 s, u32 qual, u32 qoff, u32 lossy, u32* sidx, bool* keep);
 template <bool FAST = false>
 __device__ __forceinline__ u32 transform_base(u32 base, u32 qual, u32 qoff, u32 lossy, u32* sidx, bool* keep)
 {
-	const u32 s = dna_index_t<FAST>(base);
+	return transform_base_s(dna_index_t<FAST>(base), qual, qoff, lossy, sidx, keep);
+}
+// ... with the symbol index of the base looked up by the caller (k_prep_stats / k_prep_write: a 256-byte table in LDS -- the lanes of
+// a request meet in four or five of its bytes, which the LDS hands out in one go -- instead of ~20 selects per base)
+__device__ __forceinline__ void dna_index_table(u8* lut) { for (u32 i = threadIdx.x; i < 256; i += blockDim.x) lut[i] = (u8)dna_index(i); }
+__device__ __forceinline__ u32 transform_base_s(u32 s, u32 qual, u32 qoff, u32 lossy, u32* sidx, bool* keep)
+{
 	*sidx = s;
 	u32 q;
 	if (!lossy)
@@ -327,35 +334,44 @@ __global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* 
 
 	const u32 lane = lane_id();
 	u32 a_rle = 0, a_th = 0, a_raw = 0, a_min = 0xFFFFFFFFu, a_max = 0, a_tag = 0, a_bad = 0;
-	// the next record's pool entries and first 64 characters are requested while the current one is processed
+	// The next record's pool entries and its first PS_AHEAD x 64 characters are requested while the current one is processed.  A
+	// request made inside the record's own loop is waited for at once, and that wait (vmcnt(0)) also covers whatever has been asked
+	// for the next record: with the characters beyond the first 64 and the title length fetched where they were needed, a read of 150
+	// cost three memory round trips (round 5).  Every lane asks (past the end of the read for the chunk's first byte): a request
+	// under a branch cannot be counted on by a later wait.
+	constexpr u32 PS_AHEAD = 3;
 	const u32 wstep = blockDim.x >> 6;
-	u32 n_len = 0, n_so = 0, n_qo = 0, n_b = 0, n_q = 0;
-	if (wave_id() < n_recs)
+	u32 n_len = 0, n_so = 0, n_qo = 0, n_tl = 0, n_b[PS_AHEAD], n_q[PS_AHEAD];
+#pragma unroll
+	for (u32 k = 0; k < PS_AHEAD; ++k) { n_b[k] = 'A'; n_q[k] = 0; }
+	auto request = [&](u64 g)
 	{
-		const u64 g0 = (u64)d.rec_base + wave_id();
-		n_len = rp.len[g0]; n_so = rp.seq_off[g0]; n_qo = rp.qual_off[g0];
-		if (lane < n_len) { n_b = p[n_so + lane]; n_q = p[n_qo + lane]; }
-	}
+		n_len = rp.len[g]; n_so = rp.seq_off[g]; n_qo = rp.qual_off[g]; n_tl = rp.title_len[g];
+#pragma unroll
+		for (u32 k = 0; k < PS_AHEAD; ++k)
+		{
+			const u32 j = 64u * k + lane; const bool have = j < n_len;         // (without one: the chunk's first byte)
+			n_b[k] = p[have ? n_so + j : 0u]; n_q[k] = p[have ? n_qo + j : 0u];
+		}
+	};
+	if (wave_id() < n_recs) request((u64)d.rec_base + wave_id());
 	for (u32 r = wave_id(); r < n_recs; r += wstep)
 	{
 		const u64 g = (u64)d.rec_base + r;
-		const u32 len = n_len, so = n_so, qo = n_qo;
-		const u32 c_b = n_b, c_q = n_q;
-		if (r + wstep < n_recs)
-		{
-			n_len = rp.len[g + wstep]; n_so = rp.seq_off[g + wstep]; n_qo = rp.qual_off[g + wstep];
-			if (lane < n_len) { n_b = p[n_so + lane]; n_q = p[n_qo + lane]; }
-		}
+		const u32 len = n_len, so = n_so, qo = n_qo, tl = n_tl;
+		u32 c_b[PS_AHEAD], c_q[PS_AHEAD];
+#pragma unroll
+		for (u32 k = 0; k < PS_AHEAD; ++k) { c_b[k] = n_b[k]; c_q[k] = n_q[k]; }
+		if (r + wstep < n_recs) request(g + wstep);
 		u32 kept = 0, th = 0, rle = 0, carry = 255, lastq = 255;
-		for (u32 j0 = 0; j0 < len; j0 += 64)
+		auto chunk = [&](const u32 j0, const u32 cb_in, const u32 cq_in)
 		{
 			const u32 j = j0 + lane;
 			const bool in_r = j < len;
 			u32 sidx = 0, q = 0; bool keep = false;
 			{	// the transform on every lane, `in_r` applied afterwards: the form k_prep_write needed on gfx950 (see there); lanes past the
 				// end of the read take a harmless stand-in
-				u32 cb = 'A', cq = prm.quality_offset + 40u;
-				if (in_r) { cb = j0 ? (u32)p[so + j] : c_b; cq = j0 ? (u32)p[qo + j] : c_q; }
+				const u32 cb = in_r ? cb_in : (u32)'A', cq = in_r ? cq_in : prm.quality_offset + 40u;
 				const u32 qq = transform_base<FAST_STATS>(cb, cq, prm.quality_offset, prm.lossy, &sidx, &keep);
 				if (in_r) q = qq; else { keep = false; sidx = 0; }
 			}
@@ -364,21 +380,27 @@ __global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* 
 			if (in_r && sidx >= 20) a_bad = 1;
 			if (k2 && sidx < 20) atomicAdd(&s_df[sidx], 1u);
 			kept += (u32)__popcll(__ballot(k2));
-			u32 prev = __shfl_up(q, 1);
-			if (lane == 0) prev = carry;
+			const u32 prev = wave_shr1(q, carry);
 			rle += (u32)__popcll(__ballot(in_r && q != prev));
 			const u64 m2 = __ballot(in_r && q != 2);
 			if (m2) th = j0 + 63u - (u32)__clzll((long long)m2);
-			carry = __shfl(q, 63);
+			carry = (u32)__builtin_amdgcn_readlane((int)q, 63);
 			const u32 last_lane = (len - 1 - j0) < 64u ? (len - 1 - j0) : 63u;
-			lastq = __shfl(q, (int)last_lane);
+			lastq = (u32)__builtin_amdgcn_readlane((int)q, (int)last_lane);
+		};
+#pragma unroll
+		for (u32 k = 0; k < PS_AHEAD; ++k) if (64u * k < len) chunk(64u * k, c_b[k], c_q[k]);
+		for (u32 j0 = 64u * PS_AHEAD; j0 < len; j0 += 64)
+		{
+			const u32 j = j0 + lane; const bool have = j < len;
+			chunk(j0, (u32)p[have ? so + j : 0u], (u32)p[have ? qo + j : 0u]);
 		}
 		if (len > 0 && lastq == 2 && rle > 0) rle -= 1;     // per-record decrement (Appendix B.13)
 		if (lane == 0)
 		{
 			rp.kept[g] = (u16)kept;
 			rp.trunc[g] = (u16)(th + (len > 0 ? 1u : 0u));
-			a_rle += rle; a_th += th; a_raw += len; a_tag += rp.title_len[g];
+			a_rle += rle; a_th += th; a_raw += len; a_tag += tl;
 			a_min = len < a_min ? len : a_min; a_max = len > a_max ? len : a_max;
 		}
 	}
@@ -474,6 +496,9 @@ __global__ void __launch_bounds__(WG) k_rec_offsets(const BlkDesc* desc, BlkStat
 __global__ void __launch_bounds__(WG) k_prep_write(const u8* in, const BlkDesc* desc, const BlkState* st, RecPools rp,
 												   u8* q_stream, u8* qp_stream, u8* d_stream, DsrcParams prm)
 {
+	__shared__ u8 s_dna[256];
+	dna_index_table(s_dna);
+	__syncthreads();
 	const u32 b = blockIdx.y;
 	const BlkDesc d = desc[b];
 	const u8* p = in + d.in_off;
@@ -517,7 +542,7 @@ __global__ void __launch_bounds__(WG) k_prep_write(const u8* in, const BlkDesc* 
 				// section 10; both forms as a stand-alone kernel: tools/prep_write_repro.hip) -- the emulator build, the function on its own and
 				// k_prep_stats with the same call were all right
 				const u32 cb = in_r ? cb_in : (u32)'A', cq = in_r ? cq_in : prm.quality_offset + 40u;
-				const u32 qq = transform_base<FAST_WRITE>(cb, cq, prm.quality_offset, prm.lossy, &sidx, &keep);
+				const u32 qq = transform_base_s((u32)s_dna[cb & 255u], cq, prm.quality_offset, prm.lossy, &sidx, &keep);
 				if (in_r) q = qq; else { keep = false; sidx = 0; }
 			}
 			const bool k2 = in_r && keep;
