@@ -421,6 +421,9 @@ template <> struct MdMapT<false> { typedef u16 T; static constexpr u32 NONE = 0x
 #ifndef MD_AHEAD
 #define MD_AHEAD 3
 #endif
+#ifndef MD_ROTATE_ALL
+#define MD_ROTATE_ALL 0
+#endif
 //      MD_AHEAD:                     // windows of a bucket requested ahead of the one being coded
 template <int N, int MAPBITS, int ROW_BYTES>
 __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const CtxJob* jobs, const u64* pool, RcPack* rec_pool, u32* bk, const u16* bcnt, RcPack* nowhere)
@@ -635,11 +638,23 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 		MD_T(4, 0)                                                               // the records stored (issue)
 		return coded < nb && dry <= MD_AHEAD;
 	};
-	for (bool go = nb != 0; go;)
-	{
+	if (MD_ROTATE_ALL || MAPBITS != 0)
+		for (bool go = nb != 0; go;)
+		{
 #pragma unroll
-		for (u32 k = 0; k < MD_AHEAD; ++k) if (go) go = step(elq[k], ixq[k]);
-	}
+			for (u32 k = 0; k < MD_AHEAD; ++k) if (go) go = step(elq[k], ixq[k]);
+		}
+	else
+		// (rows owned by their keys, eight-byte rows, four waves to a workgroup: enough waves per SIMD to wait behind, and the loop
+		// in one copy is the faster one -- k_model<4, 0, 4096> 2.03 ms against 2.29 with the slots going round)
+		for (bool go = nb != 0; go;)
+		{
+			u32 e = elq[0], i = ixq[0];
+			go = step(e, i);
+#pragma unroll
+			for (u32 k = 0; k + 1 < MD_AHEAD; ++k) { elq[k] = elq[k + 1]; ixq[k] = ixq[k + 1]; }
+			elq[MD_AHEAD - 1] = e; ixq[MD_AHEAD - 1] = i;
+		}
 	};
 	if (may_rescale) walk(std::true_type()); else walk(std::false_type());
 #ifdef MD_PROFILE
