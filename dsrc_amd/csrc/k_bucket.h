@@ -448,7 +448,10 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 #define MD_XCD_MAP 1
 #endif
 	u32 bx = blockIdx.x;
-	if (MD_XCD_MAP && gridDim.x % 8u == 0) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+	// ... which eighth, goes round with the stream: the same contexts are hot in every stream of a launch (four-level qualities: ten
+	// buckets of 75-170 k symbols at the same ten places of all 128 streams), and with the same eighth on the same XCD for every
+	// stream their ~1300 long walks met on the SIMDs of the two or three XCDs those places fall on (k_model<16>: 14.0 ms per launch)
+	if (MD_XCD_MAP && gridDim.x % 8u == 0) bx = (((bx & 7u) + blockIdx.y) & 7u) * (gridDim.x >> 3) + (bx >> 3);
 	const u32 bucket = bx * MD_WAVES + w;
 	const u32 buckets = 1u << j.bk_hb;
 	if (!j.bk_on || bucket >= buckets || bk[j.jid]) return;
