@@ -248,6 +248,10 @@ class Handle:
         """Hands the batch arena and the table region back to the device (they are allocated again on demand)."""
         self._chk(self.L.dsrcgpu_release_memory(self.h))
 
+    def reserve_memory(self, arena_bytes, table_bytes=0):
+        """Grows the batch arena / the decoder's table region to at least these sizes now (nothing shrinks)."""
+        self._chk(self.L.dsrcgpu_reserve_memory(self.h, C.c_uint64(arena_bytes), C.c_uint64(table_bytes)))
+
     def last_timing(self):
         ms = C.c_float(); rc_ms = C.c_float(); n = C.c_uint32()
         self.L.dsrcgpu_last_timing(self.h, C.byref(ms), C.byref(rc_ms), C.byref(n))

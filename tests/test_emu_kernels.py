@@ -488,6 +488,13 @@ def test_release_memory_between_phases(emu, oracle):
         texts = h.decompress_batch(got[:3])
         h.release_memory()
         assert texts == h.decompress_batch(got[:3]) == [c + b"\n" for c in chunks]
+        # ... and dsrcgpu_reserve_memory asks for both ahead of a call: larger than the call needs, smaller (nothing shrinks), none
+        h.release_memory()
+        h.reserve_memory(32 << 20, 8 << 20)
+        assert h.decompress_batch(got[:3]) == texts
+        h.reserve_memory(1 << 20, 0); h.reserve_memory(0, 0)
+        assert len(h.compress_batch(chunks)) == 3                  # (a batch call after it; its blocks' state has moved on)
+        assert h.decompress_batch(got[:3]) == texts
     finally:
         h.close()
 
