@@ -187,30 +187,60 @@ class Lane:
 
 
 class StepGates:
-    """N > 1 only.  The gather of step s runs on the main thread once every lane has finished step s, while the lanes
-    already compress step s+1 into their other output buffer; a lane may start step s only after the gather of
-    step s-2 (same buffer) is done."""
+    """N > 1 only.  Every scheduler instance has a gather thread of its own (its own RCCL group and its own host-side group for the
+    footer table, so that the instances' exchanges do not have to agree on an order): the gather of instance i's step s runs as soon
+    as i has finished step s, while i already compresses step s+1 into its other output buffer; i may start step s only after the
+    gather of its step s-2 (same buffer) is done."""
 
     def __init__(self, n_lanes):
-        self.cv = threading.Condition(); self.done = {}; self.gathered = set(); self.n_lanes = n_lanes
+        self.cv = threading.Condition(); self.done = set(); self.gathered = set(); self.n_lanes = n_lanes
 
-    def lane_may_start(self, s, first):
+    def lane_may_start(self, idx, s, first):
         with self.cv:
-            while s - 2 >= first and (s - 2) not in self.gathered:
+            while s - 2 >= first and (idx, s - 2) not in self.gathered:
                 self.cv.wait()
 
-    def lane_done(self, s):
+    def lane_done(self, idx, s):
         with self.cv:
-            self.done[s] = self.done.get(s, 0) + 1; self.cv.notify_all()
+            self.done.add((idx, s)); self.cv.notify_all()
 
-    def wait_step(self, s):
+    def wait_lane(self, idx, s):
         with self.cv:
-            while self.done.get(s, 0) < self.n_lanes:
+            while (idx, s) not in self.done:
                 self.cv.wait()
 
-    def step_gathered(self, s):
+    def lane_gathered(self, idx, s):
         with self.cv:
-            self.gathered.add(s); self.cv.notify_all()
+            self.gathered.add((idx, s)); self.cv.notify_all()
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher's environment: start the N ranks ourselves (one process per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* as torch.distributed.run would set them), rank 0 prints the line.  DSRC_BENCH_SAME_GPU=1 (tests, one-GPU
+    boxes): every rank on GPU 0 and the exchanges over gloo through host copies -- RCCL refuses two ranks on one device."""
+    import socket
+    import subprocess
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    same = bool(os.environ.get("DSRC_BENCH_SAME_GPU"))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if same else str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        while procs and rc == 0:
+            for pr in list(procs):
+                try:
+                    code = pr.wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                procs.remove(pr)
+                rc = rc or code
+    finally:
+        for pr in procs:              # a rank failed (or we were interrupted): the others would wait in a collective for ever
+            pr.kill()
+    return rc
 
 
 def measure_decode(lanes, cfg, n_blocks, last_step, pmc, n_inst=int(os.environ.get("DSRC_BENCH_DECODE_INST", "2")), passes=int(os.environ.get("DSRC_BENCH_DECODE_PASSES", "3"))):
@@ -522,17 +552,27 @@ def main():
     # 4 hardware queues by default, which serialises unrelated instances behind each other's 0.25 s range-coder kernel
     # (and behind the host framework's own streams when N > 1); must be set before the runtime initialises.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(2 * max(1, args.pipeline) + 6))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None; torch = None; size_group = None
+    if world != args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus} was started inside a group of WORLD_SIZE={world} ranks: the line would not be what was asked for")
+    dist = None; torch = None
+    host_payload = bool(os.environ.get("DSRC_BENCH_SAME_GPU"))       # (tests) ranks share GPU 0: gloo, payloads through host copies
     if world > 1 or os.environ.get("DSRC_BENCH_FORCE_DIST"):      # FORCE_DIST: exercise the N > 1 code path with one rank
         import torch as torch_
         import torch.distributed as dist_
         torch = torch_
         torch.cuda.set_device(local)
-        dist_.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if host_payload:
+            dist_.init_process_group("gloo")
+        else:
+            dist_.init_process_group("nccl", device_id=torch.device("cuda", local))
         dist = dist_
-        size_group = dist.new_group(backend="gloo")        # the footer tables go over the host (dsrc_amd/dist.py: gather_block_stream)
+        assert dist.get_world_size() == args.gpus, f"{dist.get_world_size()} ranks in the group, --gpus {args.gpus}"
+    group_name = "gloo group, one GPU shared: a test" if host_payload else "RCCL group"
+    xdev = "cpu" if host_payload else "cuda"          # where the tensors of the small exchanges live
 
     from dsrc_amd.config import Config
     cfg = Config.from_levels(args.dna, args.qua)
@@ -552,7 +592,7 @@ def main():
     def hbm_need(sb, n_res):
         chunks = sb * RECS_PER_BLOCK * 1.02 * 384
         per_lane = chunks * 9.0 + (7.5e9 if chunks >= 2.5e9 else 1.9e9) + n_res * chunks + (2 if dist is not None else 1) * chunks / 2
-        return P * per_lane + ((world - 1) * chunks / 2 if dist is not None and rank == 0 else 0)
+        return P * per_lane + (P * (world - 1) * chunks / 2 if dist is not None and rank == 0 and not host_payload else 0)
     try:
         from dsrc_amd._lib import load as _load
         import ctypes as _C
@@ -573,7 +613,7 @@ def main():
         from dsrc_amd._lib import load as load_lib
         from dsrc_amd.dist import exchange_fields_capacity
         t0 = synth_.illumina_title(1 + rank * P * MAX_RESIDENT * (int(sub_blocks * RECS_PER_BLOCK * 1.02) + 1000))
-        seed = exchange_fields_capacity([load_lib().dsrcgpu_title_fields(t0, len(t0), 0)], device=torch.device("cuda", local))
+        seed = exchange_fields_capacity([load_lib().dsrcgpu_title_fields(t0, len(t0), 0)], device=torch.device(xdev, local) if xdev == "cuda" else torch.device("cpu"))
         for ln in lanes:
             ln.h.set_fields_capacity(seed)
 
@@ -583,21 +623,31 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # rank 0 receives every peer's stream of one scheduler instance into buffers allocated once (not inside the timed region);
-    # the gathers of a step run one instance after the other on the main thread, so one set is enough
-    recv_bufs = None
-    if dist is not None and rank == 0 and world > 1:
-        recv_bufs = [None] + [torch.empty(lanes[0].cap_out, dtype=torch.uint8, device="cuda") for _ in range(1, world)]
+    # Every scheduler instance gathers through groups of its own: a device group (RCCL) for the streams, a host group (gloo) for the
+    # footer tables -- the instances' gather threads then need no common order.  Rank 0 receives every peer's stream of an instance
+    # into buffers allocated once (not inside the timed region): one per peer AND instance, the instances' gathers overlap.
+    lane_groups = None; recv_bufs = None
+    if dist is not None:
+        lane_groups = [(None if host_payload else dist.new_group(), dist.new_group(backend="gloo")) for _ in range(P)]
+        if rank == 0 and world > 1:
+            recv_bufs = [[None] + [torch.empty(lanes[0].cap_out, dtype=torch.uint8, device="cpu" if host_payload else "cuda") for _ in range(1, world)] for _ in range(P)]
+
+    def gather_lane(li, step, keep=None):
+        from dsrc_amd.dist import gather_block_stream
+        ln = lanes[li]
+        _, o_sizes, _, _ = ln.results[step]
+        pay = ln.outs[step % len(ln.outs)][1]
+        if host_payload:
+            pay = pay[: sum(o_sizes)].cpu()
+        res = gather_block_stream(o_sizes, pay, group=lane_groups[li][0], recv_bufs=recv_bufs[li] if recv_bufs else None, size_group=lane_groups[li][1])
+        if keep is not None:
+            keep(li, ln, res)
 
     def gather_step(step, keep=None):
         if dist is None:
             return
-        from dsrc_amd.dist import gather_block_stream
-        for li, ln in enumerate(lanes):
-            _, o_sizes, _, _ = ln.results[step]
-            res = gather_block_stream(o_sizes, ln.outs[step % len(ln.outs)][1], recv_bufs=recv_bufs, size_group=size_group)
-            if keep is not None:
-                keep(li, ln, res)
+        for li in range(P):
+            gather_lane(li, step, keep)
 
     # ---- warmup (also sizes the arenas and measures one sub-batch for the stagger) ------------------------
     t_sub = 0.0
@@ -625,25 +675,34 @@ def main():
                 time.sleep(t_sub * idx / P * float(os.environ.get("DSRC_BENCH_STAGGER", "1")))
             for s in range(first, total_steps):
                 if dist is not None:
-                    gates.lane_may_start(s, first)
+                    gates.lane_may_start(idx, s, first)
                 lanes[idx].run(s)
-                gates.lane_done(s)
+                gates.lane_done(idx, s)
         except Exception as e:      # noqa: BLE001
             errors.append(e)
-            for s in range(first, total_steps):      # do not leave the main thread waiting
-                gates.lane_done(s)
+            for s in range(first, total_steps):      # do not leave the gather thread waiting
+                gates.lane_done(idx, s)
+
+    def gatherer(idx):
+        try:
+            torch.cuda.set_device(local)
+            for s in range(first, total_steps):
+                gates.wait_lane(idx, s)
+                if not errors:
+                    gather_lane(idx, s)
+                gates.lane_gathered(idx, s)
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+            for s in range(first, total_steps):
+                gates.lane_gathered(idx, s)
 
     sync_all()
     t_begin = time.perf_counter()
     threads = [threading.Thread(target=worker, args=(i,)) for i in range(P)]
+    if dist is not None:
+        threads += [threading.Thread(target=gatherer, args=(i,)) for i in range(P)]
     for t in threads:
         t.start()
-    if dist is not None:
-        for s in range(first, total_steps):
-            gates.wait_step(s)
-            if not errors:
-                gather_step(s)
-            gates.step_gathered(s)
     for t in threads:
         t.join()
     sync_all()
@@ -734,7 +793,7 @@ def main():
                     for ln in lanes:
                         d_in, starts, szs = ln.shard(last)
                         f.write(ln.h.dev_download(d_in + starts[0], starts[-1] + szs[-1] + 1 - starts[0]))
-        t = torch.tensor([wall, float(in_bytes), float(out_bytes)], device="cuda", dtype=torch.float64)
+        t = torch.tensor([wall, float(in_bytes), float(out_bytes)], device=xdev, dtype=torch.float64)
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
         per_rank = [round(float(x[1]) / float(x[0]) / 1e6, 1) for x in allt]
@@ -763,7 +822,7 @@ def main():
             "config": {"workload": f"Synthetic Illumina 150 bp FASTQ, 100M-read data set shape (BASELINE configs[2]), -d{args.dna} -q{args.qua} -b{args.buf_mb}; "
                                    f"step = {args.blocks} consecutive {args.buf_mb} MiB chunks per GPU, device-resident, {P} scheduler instances per GPU",
                        "blocks_per_step": args.blocks, "pipeline": P,
-                       "parallelism": (f"{world} process(es), one per GPU ({dist.get_world_size()} ranks in the RCCL group): contiguous partId ranges, no data-path collective; per step the block sizes are all-gathered and "
+                       "parallelism": (f"{world} process(es), one per GPU ({dist.get_world_size()} ranks in the {group_name}; a gather thread and a group per scheduler instance): contiguous partId ranges, no data-path collective; per step the block sizes are all-gathered and "
                                        f"every rank's block stream goes to rank 0 by point-to-point send (RCCL), overlapped with the next step") if dist is not None else "1 GPU",
                        **({"per_rank_MB_per_s": per_rank, "gather_verified": gather_verified} if dist is not None else {}),
                        "ratio_out_in": round(out_bytes / in_bytes, 4), "parity_checked_blocks": checked},

@@ -1283,12 +1283,13 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 
 namespace wrap
 {
-// range checks of the reference's setters (src/Configurable.cpp:56-179)
-void Configurable::SetFastqBufferSizeMB(uint64 s) { if (s < 1 || s > 1024) throw DsrcException("Invalid fastq buffer size specified [1-1024]"); params.fastqBufferSizeMB = (uint32)s; }
-void Configurable::SetDnaCompressionLevel(uint32 l) { if (l > 3) throw DsrcException("Invalid DNA compression mode specified [0-3]"); params.dnaCompressionLevel = l; }
-void Configurable::SetQualityCompressionLevel(uint32 l) { if (l > 2) throw DsrcException("Invalid Quality compression mode specified [0-2]"); params.qualityCompressionLevel = l; }
-void Configurable::SetQualityOffset(uint32 o) { if (o != 0 && (o < 33 || o > 64)) throw DsrcException("Invalid Quality offset mode specified [33, 64]"); params.qualityOffset = o; }
-void Configurable::SetThreadsNumber(uint32 t) { if (t == 0 || t > 64) throw DsrcException("Invalid thread number specified [1-64]"); params.threadNum = t; }
+// the reference's setters, their ranges and their texts (src/Configurable.cpp:56-144): the command line has checks of its own
+// (src/main.cpp:276-297: quality offset 33..64 or auto, 1..64 threads) which live in main.cpp here as there
+void Configurable::SetFastqBufferSizeMB(uint64 s) { if (s == 0 || s > 1024) throw DsrcException("Invalid argument: invalid FASTQ buffer size [1-1024]"); params.fastqBufferSizeMB = (uint32)s; }
+void Configurable::SetDnaCompressionLevel(uint32 l) { if (l > 3) throw DsrcException("Invalid argument: invalid DNA compression level [0-3]"); params.dnaCompressionLevel = l; }
+void Configurable::SetQualityCompressionLevel(uint32 l) { if (l > 2) throw DsrcException("Invalid argument: invalid Quality compression level [0-2]"); params.qualityCompressionLevel = l; }
+void Configurable::SetQualityOffset(uint32 o) { if (o != 33 && o != 64) throw DsrcException("Invalid argument: only valid Quality offset are 33 and 64"); params.qualityOffset = o; }
+void Configurable::SetThreadsNumber(uint32 t) { if (t == 0) throw DsrcException("Invalid argument: thread number must be greater than 0"); params.threadNum = t; }
 
 void DsrcModule::Compress(const std::string& in, const std::string& out)
 {

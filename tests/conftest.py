@@ -16,6 +16,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def need_built(path, what):
+    """A built artefact a test stands on.  Missing on a box with a GPU (the driver's round-end run: everything was built before the
+    snapshot travelled) or where /root/reference is present (build() makes all of them there) is a FAILURE -- a broken build must not
+    go green by skipping; only a GPU-less machine without the reference sources may skip the tests that need oracle/_ref."""
+    if os.path.exists(path):
+        return
+    if os.path.exists("/dev/kfd") or os.path.isdir("/root/reference/src"):
+        pytest.fail(f"{what} is missing ({path}): run `python __graft_entry__.py` before the tests")
+    pytest.skip(f"{what} not built (needs /root/reference at build time)")
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from tests._oracle import Oracle
@@ -26,7 +37,8 @@ def oracle():
 def ref():
     from tests._oracle import Ref, have_ref
     if not have_ref():
-        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+        from tests._oracle import REF_SO
+        need_built(REF_SO, "oracle/_ref (the unmodified reference)")
     return Ref()
 
 
@@ -39,8 +51,7 @@ def gpu_hooks():
     build in which the DSRC_GPU_* switches that FORCE a path exist (ballot ranking, the range coder's reference loop, the sort-and-replay
     front end, arena fill ...).  The product library has none of them: it chooses by itself."""
     from dsrc_amd import _lib
-    if not os.path.exists(HOOKS_LIB):
-        pytest.skip("libdsrc_gpu_hooks.so not built")
+    need_built(HOOKS_LIB, "libdsrc_gpu_hooks.so")
     old_env, old_lib = os.environ.get("DSRC_GPU_LIB"), _lib._lib
     os.environ["DSRC_GPU_LIB"] = HOOKS_LIB
     _lib._lib = None

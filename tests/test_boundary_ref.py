@@ -10,6 +10,8 @@ import subprocess
 
 import pytest
 
+from tests.conftest import need_built
+
 from dsrc_amd import synth
 from tests._oracle import REF_BIN
 
@@ -36,16 +38,16 @@ def _check(binary, tmp_path, data, levels, batch, env=None):
             assert back.read_bytes() == data
 
 
-@pytest.mark.skipif(not (os.path.exists(REF_GPU_EMU) and os.path.exists(REF_BIN)), reason="oracle/_ref not built (needs /root/reference)")
 def test_reference_pipeline_with_the_gpu_worker_on_the_emulator(tmp_path):
+    need_built(REF_GPU_EMU, "oracle/_ref/dsrc_ref_gpu_emu"); need_built(REF_BIN, "oracle/_ref/dsrc_ref")
     data = synth.illumina_fastq(250)
     env = dict(os.environ, DSRC_GPU_DEC_SERIAL="1")         # the wave-cooperative decoder is slow on the emulator (tests/test_emu_decode.py)
     _check(REF_GPU_EMU, tmp_path, data, [["-d0", "-q0"], ["-d3", "-q2", "-c"], ["-d2", "-q1", "-l"]], batch=2, env=env)
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not (os.path.exists(REF_GPU) and os.path.exists(REF_BIN)), reason="oracle/_ref not built (needs /root/reference)")
 def test_reference_pipeline_with_the_gpu_worker(tmp_path):
+    need_built(REF_GPU, "oracle/_ref/dsrc_ref_gpu"); need_built(REF_BIN, "oracle/_ref/dsrc_ref")
     from tests.cases import state_dependent_fastq
     _check(REF_GPU, tmp_path, synth.illumina_fastq(60000), [["-d0", "-q0"], ["-d3", "-q2"], ["-d1", "-q1", "-c"], ["-d2", "-q1", "-l"]], batch=7)
     # blocks that depend on the state carried from block to block, one chunk per batch, three batches in flight

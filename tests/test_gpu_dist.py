@@ -52,6 +52,28 @@ def test_bench_dist_path_gathers_the_cli_archive(tmp_path):
     assert line["config"]["gather_verified"] is True and line["steps"] == 2 and "1 ranks in the RCCL group" in line["config"]["parallelism"]
 
 
+@pytest.mark.timeout(900)
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts the two ranks itself.  On the one GPU of a test box both
+    ranks sit on GPU 0 (DSRC_BENCH_SAME_GPU: gloo and host copies -- RCCL refuses two ranks on one device); everything else is the
+    N > 1 path of the driver's run: per-instance gather threads and groups, the state hand-over, the checked gather, one line from rank 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DSRC_BENCH_FORCE_DIST")}
+    env["DSRC_BENCH_SAME_GPU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--pipeline", "2", "--blocks", "8", "--steps", "2", "--warmup", "1",
+                          "--no-cpu", "--decode-blocks", "0", "--check", "1"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=850)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [x for x in out.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints the line"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2
+    assert "2 ranks in the" in line["config"]["parallelism"] and line["config"]["gather_verified"] is True
+    assert len(line["config"]["per_rank_MB_per_s"]) == 2
+    # a group of another size than --gpus is refused, not silently timed
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu"], env=env2, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)

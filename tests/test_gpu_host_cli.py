@@ -7,6 +7,8 @@ import subprocess
 
 import pytest
 
+from tests.conftest import need_built
+
 from dsrc_amd import synth
 from tests._oracle import REF_BIN
 
@@ -34,13 +36,11 @@ def _run(args):
 
 @pytest.mark.parametrize("flags", [["-d3", "-q2"], ["-d0", "-q0"], ["-d2", "-q1", "-l"], ["-d1", "-q1", "-c"]])
 def test_illumina_archive_identical(files, flags):
-    if not os.path.exists(CLI):
-        pytest.skip("dsrc-amd not built")
+    need_built(CLI, "dsrc-amd")
     d, ill, _ = files
     ours = str(d / "ours.dsrc"); theirs = str(d / "ref.dsrc")
     _run([CLI, "c", *flags, "-b1", ill, ours])
-    if not os.path.exists(REF_BIN):
-        pytest.skip("reference CLI not shipped")
+    need_built(REF_BIN, "oracle/_ref/dsrc_ref")
     _run([REF_BIN, "c", *flags, "-b1", "-t1", ill, theirs])
     assert md5(ours) == md5(theirs)
     back = str(d / "back.fastq")
@@ -54,8 +54,7 @@ def test_illumina_archive_identical(files, flags):
 
 
 def test_iontorrent_lossy_archive_identical(files):
-    if not os.path.exists(CLI) or not os.path.exists(REF_BIN):
-        pytest.skip("CLI missing")
+    need_built(CLI, "dsrc-amd"); need_built(REF_BIN, "oracle/_ref/dsrc_ref")
     d, _, ion = files
     ours = str(d / "o.dsrc"); theirs = str(d / "r.dsrc")
     _run([CLI, "c", "-d2", "-q1", "-l", "-b1", ion, ours])
@@ -67,8 +66,7 @@ def test_iontorrent_lossy_archive_identical(files):
 def test_pipelined_instances_write_the_t1_archive(files, flags, which):
     """Several scheduler instances on consecutive small batches (-n2 chunks per batch, -t4 instances): the chain hands
     the block-to-block state along, so the archive is still the one `dsrc c -t1` writes."""
-    if not os.path.exists(CLI) or not os.path.exists(REF_BIN):
-        pytest.skip("CLI missing")
+    need_built(CLI, "dsrc-amd"); need_built(REF_BIN, "oracle/_ref/dsrc_ref")
     d, ill, ion = files
     src = ill if which == "ill" else ion
     ours = str(d / "p.dsrc"); theirs = str(d / "pr.dsrc")
@@ -79,8 +77,7 @@ def test_pipelined_instances_write_the_t1_archive(files, flags, which):
 
 def test_pydsrc_module_names(files):
     """The reference's Python module names (py/Interface.cpp) on top of the GPU path: same archive as `dsrc c -t1`."""
-    if not os.path.exists(CLI) or not os.path.exists(REF_BIN):
-        pytest.skip("CLI missing")
+    need_built(CLI, "dsrc-amd"); need_built(REF_BIN, "oracle/_ref/dsrc_ref")
     from dsrc_amd import pydsrc
     d, ill, _ = files
     m = pydsrc.DsrcModule()
@@ -112,8 +109,7 @@ def test_pydsrc_module_names(files):
 @pytest.mark.parametrize("fields", ["-f1,2", "-f2,4,5", "-f1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16"])
 def test_field_filter_archive_identical(files, fields):
     """`-f`: the title field filter through the whole CLI, against `dsrc c -f... -t1`."""
-    if not os.path.exists(CLI) or not os.path.exists(REF_BIN):
-        pytest.skip("CLI missing")
+    need_built(CLI, "dsrc-amd"); need_built(REF_BIN, "oracle/_ref/dsrc_ref")
     d, ill, _ = files
     ours = str(d / "f.dsrc"); theirs = str(d / "fr.dsrc")
     _run([CLI, "c", "-d2", "-q1", "-c", fields, "-b1", "-n3", "-t3", ill, ours])
@@ -126,8 +122,7 @@ def test_config1_full_size_archive_md5(tmp_path):
     archive the unmodified reference wrote (`dsrc c -t1`; md5 committed in tests/golden/config_golden.json by
     tests/golden/make_config_golden.py), at -d0 -q0 and at -d3 -q2 with and without -c."""
     import json
-    if not os.path.exists(CLI):
-        pytest.skip("dsrc-amd not built")
+    need_built(CLI, "dsrc-amd")
     G = json.load(open(os.path.join(ROOT, "tests", "golden", "config_golden.json")))
     src = tmp_path / "ill1m.fastq"
     h = hashlib.md5()
@@ -148,8 +143,7 @@ def test_decompress_every_golden_archive(oracle, tmp_path):
     import json
     from tests.test_oracle_golden import G, _file_bytes
     from tests.cases import fuzz_solid
-    if not os.path.exists(CLI):
-        pytest.skip("dsrc-amd not built")
+    need_built(CLI, "dsrc-amd")
     src = tmp_path / "in.fastq"; arc = tmp_path / "a.dsrc"; out = tmp_path / "out.fastq"; refout = tmp_path / "ref.fastq"
     n = 0
     for a in G["archives"]:
@@ -180,8 +174,7 @@ def test_decompress_every_golden_archive(oracle, tmp_path):
 def test_verify_pass_with_c(files):
     """-c runs the decode-and-compare pass on the device after every batch (reference: src/DsrcWorker.cpp:53-62); the
     archive is the same with and without it (-x skips it)."""
-    if not os.path.exists(CLI):
-        pytest.skip("dsrc-amd not built")
+    need_built(CLI, "dsrc-amd")
     d, ill, ion = files
     a = str(d / "v1.dsrc"); b = str(d / "v2.dsrc")
     _run([CLI, "c", "-d3", "-q2", "-c", "-b1", "-n4", ill, a])
@@ -194,8 +187,7 @@ def test_device_list_writes_the_t1_archive(tmp_path):
     whose blocks depend on the block-to-block state: still the archive the reference writes with -t1 (golden md5)."""
     import json
     from tests.cases import state_dependent_fastq
-    if not os.path.exists(CLI):
-        pytest.skip("dsrc-amd not built")
+    need_built(CLI, "dsrc-amd")
     G = json.load(open(os.path.join(ROOT, "tests", "golden", "state_golden.json")))
     data = state_dependent_fastq()
     src = tmp_path / "state.fastq"; src.write_bytes(data)

@@ -11,9 +11,24 @@ def test_properties_and_checks():
         assert hasattr(m, name)
     m.DNACompressionLevel = 3; m.QualityCompressionLevel = 2
     assert (m.DNACompressionLevel, m.QualityCompressionLevel) == (3, 2)      # the reference's setter bug is not reproduced
-    for attr, bad in (("DNACompressionLevel", 4), ("QualityCompressionLevel", 3), ("FastqBufferSizeMB", 0), ("ThreadsNumber", 65)):
-        with pytest.raises(RuntimeError):
+    # the setters' ranges and texts are the reference's (src/Configurable.cpp:56-144), not the command line's (src/main.cpp:276-297)
+    for attr, bad, text in (("DNACompressionLevel", 4, "Invalid argument: invalid DNA compression level [0-3]"),
+                            ("QualityCompressionLevel", 3, "Invalid argument: invalid Quality compression level [0-2]"),
+                            ("FastqBufferSizeMB", 0, "Invalid argument: invalid FASTQ buffer size [1-1024]"),
+                            ("FastqBufferSizeMB", 1025, "Invalid argument: invalid FASTQ buffer size [1-1024]"),
+                            ("ThreadsNumber", 0, "Invalid argument: thread number must be greater than 0")):
+        with pytest.raises(RuntimeError) as e:
             setattr(m, attr, bad)
+        assert text in str(e.value)
+    m.ThreadsNumber = 65; m.FastqBufferSizeMB = 1024                         # accepted there, accepted here
+    assert (m.ThreadsNumber, m.FastqBufferSizeMB) == (65, 1024)
+    a = pydsrc.DsrcArchive()
+    for bad in (0, 34, 63, 65):
+        with pytest.raises(RuntimeError) as e:
+            a.QualityOffset = bad
+        assert "Invalid argument: only valid Quality offset are 33 and 64" in str(e.value)
+    a.QualityOffset = 64; a.QualityOffset = 33
+    assert a.QualityOffset == 33
 
 
 def test_record_api_names(tmp_path):

@@ -11,6 +11,8 @@ import subprocess
 
 import pytest
 
+from tests.conftest import need_built
+
 from dsrc_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -61,8 +63,8 @@ def test_running_chunk_size_and_block_cut():
     assert len(e["block_sizes"]) == 4
 
 
-@pytest.mark.skipif(not os.path.exists(REF_RECORDS), reason="oracle/_ref/ref_records not built (needs /root/reference)")
 def test_oracle_against_live_reference(oracle, inputs, tmp_path):
+    need_built(REF_RECORDS, "oracle/_ref/ref_records")
     d, paths = inputs
     # plus repetition, offset 64 data and other buffer sizes than the golden set
     data = synth.illumina_fastq(5000, first=90001)
