@@ -17,6 +17,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <dlfcn.h>
 #include <mutex>
 #ifndef DSRC_REPLAY_WHATIF
@@ -180,6 +181,7 @@ struct dsrcgpu_handle
 	u64 dec_table_budget = 0;        // dsrcgpu_set_table_budget: HBM a decoding pass may take for model tables (0 = automatic)
 	u32* dec_tables = nullptr; u64 dec_tables_cap = 0;     // model tables of the range-decoded levels (bytes), kept between passes
 	std::vector<DecHint> verify_hints;                     // run_batch -> verify_blocks: where the DNA stream of every block it wrote lies
+	u32 rc_redone = 0;               // streams coded a second time by k_rc (carry clamp under k_rcs, device hand-backs) since the handle was created
 	bool rc_caps_worst = false;      // a range-coded stream has outgrown the estimate of its staging once: two bytes per symbol from now on (run_batch)
 };
 
@@ -624,11 +626,12 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	const u32 NJ = (u32)jobs.size();
 	std::vector<RcChain> chains(NJ);
 	{
-		// records of one chain are contiguous: k_replay scatters inside one chain's 8 B x n array (a few chains in
-		// flight stay within the memory-side cache) and k_rc streams it through LDS.  The 64 chains of a k_rc wave
-		// are one pitch apart (a multiple of 4 records: rows stay 16-byte aligned); k_rc's DMA may read RC_OVERREAD
-		// records past the longest chain of its wave.
-		const u32 force_exact = hook_env("DSRC_GPU_FORCE_EXACT_RC") ? 1u : 0u;           // tests only (read per batch)
+		// records of one chain are contiguous: 8 bytes of address space per symbol (k_model's records; k_place leaves k_rc's six-byte
+		// chunks in the first three quarters of every time bin, k_rc.h).  The chains of a k_rc wave are one pitch apart (a multiple
+		// of 4 records: arrays stay 16-byte aligned); the loaders may read RC_OVERREAD records past the longest chain of their wave.
+		// tests only (read per batch): 1 = the reference-loop check for every chunk of 64 symbols, 2 = every stream reports a carry clamp and goes to the redo list,
+		// 3 = a recovery inside k_rcs every few chunks (rcs_recover: the walk of a chunk with the reference's loop, R and L put right)
+		const u32 force_exact = hook_env("DSRC_GPU_RC_REDO") ? 2u : hook_env("DSRC_GPU_RC_RECOVER") ? 3u : hook_env("DSRC_GPU_FORCE_EXACT_RC") ? 1u : 0u;
 		size_t trip_words = 0;
 		std::vector<size_t> cbase(NJ + 1, 0); std::vector<u32> cpitch(NJ + 1, 0);
 		for (u32 g = 0; g < NJ; g += RC_LANES)
@@ -653,7 +656,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			j.trip = trip0 + cbase[i];
 			RcChain& c = chains[i];
 			c.trip = j.trip; c.out_words = j.out_words; c.n = j.n; c.out_byte0 = j.out_byte0; c.out_cap = j.out_cap; c.blk = j.blk; c.is_dna = j.is_dna;
-			c.force_exact = force_exact; c.pitch = cpitch[i]; c.pad0 = 0;
+			c.force_exact = force_exact; c.jid = i; c.bk_on = 0;
 		}
 	}
 	// The ping-pong sort buffers are only alive from k_sort to k_replay, so the job list is cut into slices that
@@ -746,6 +749,10 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			}
 		o_bcnt = A.alloc(cnt_words * 2 + 64);
 	}
+	for (u32 i = 0; i < NJ; ++i) chains[i].bk_on = use_bk ? jobs[i].bk_on : 0u;
+	// redo list of the range coder (k_rc.h): count, then chain ids -- streams in which the carry clamp fired under k_rcs (the device
+	// appends them), streams the bucketed front end handed back on the device (the host appends them after the state read-back)
+	const size_t o_redo = A.alloc(((size_t)NJ + 2) * 4);
 	const size_t o_jobs = A.alloc(sizeof(CtxJob) * std::max(1u, NJ)), o_chains = A.alloc(sizeof(RcChain) * std::max(1u, NJ));
 	if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (phase 3b): batch needs > %zu bytes of HBM scratch", A.top);
 	CtxJob* d_jobs = AP<CtxJob>(h, o_jobs); RcChain* d_chains = AP<RcChain>(h, o_chains);
@@ -839,15 +846,40 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	}
 	hipLaunchKernelGGL(k_dna_none, dim3((B + 63) / 64), dim3(64), 0, s, d_desc, d_state, wpool, B); KCHK();
 	h->rc_launches = 0;
+	std::function<int(const BkGroup&)> launch_fallback;
+	u32* d_bk = use_bk ? AP<u32>(h, o_bk) : nullptr;
+	u32* d_redo = AP<u32>(h, o_redo);
+	const bool rc_one_lane = hook_env("DSRC_GPU_RC_ONE_LANE") != nullptr;      // tests: k_rc (both recurrences in one lane) for every stream
 	if (NJ)
 	{
 		const u32 nq = (u32)qjobs.size(), nd = (u32)djobs.size();
 		const bool sort_atomic = h->sort_atomic;
 		hipLaunchKernelGGL(k_rc_headers, dim3((NJ + 63) / 64), dim3(64), 0, s, d_jobs, NJ, d_state, wpool); KCHK();
-		u32* d_bk = use_bk ? AP<u32>(h, o_bk) : nullptr;
+		HIPCHK(hipMemsetAsync(d_redo, 0, ((size_t)NJ + 2) * 4, s));
 		u16* d_bcnt = use_bk ? AP<u16>(h, o_bcnt) : nullptr;
 		if (use_bk) HIPCHK(hipMemsetAsync(d_bk, 0, bk_zero_words * 4, s));
 		const u32 max_parts = 2048u;         // waves per stream of k_replay (measured: 256 parts 21.4, 512 23.3, 1024 24.3, 2048 24.7, 3200 23.2 GB/s with five instances)
+		// k_sort / k_replay_seams / k_replay over the fallback list of one launch group of the bucketed path
+		launch_fallback = [&, sort_atomic, max_parts](const BkGroup& g) -> int
+		{
+			const u32 cnt = g.hi - g.lo;
+			const u32* fb = d_bk + g.fb;
+			if (sort_atomic) hipLaunchKernelGGL((k_sort<0, true>), dim3(std::min(cnt, 16u)), dim3(SORT_WG), 0, s, d_jobs, lpool, d_d, d_q, d_qp, d_state, fb);
+			else hipLaunchKernelGGL((k_sort<0, false>), dim3(std::min(cnt, 16u)), dim3(SORT_WG), 0, s, d_jobs, lpool, d_d, d_q, d_qp, d_state, fb);
+			u32 mxn = 1; for (u32 i = g.lo; i < g.hi; ++i) mxn = std::max(mxn, jobs[i].n);
+			const u32 parts = std::max(1u, std::min(max_parts, mxn / 1024u));
+			const dim3 rgrid(parts * std::min(cnt, 4u));
+#define BK_REPLAY(NN) { hipLaunchKernelGGL(k_replay_seams<NN>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs, const_cast<u64*>(lpool), parts, cnt, fb); \
+					hipLaunchKernelGGL((k_replay<NN, 0>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs, lpool, AP<RcPack>(h, 0), parts, cnt, fb); }
+			switch (jobs[g.lo].n_alpha)
+			{
+			case 4: BK_REPLAY(4) break; case 8: BK_REPLAY(8) break; case 16: BK_REPLAY(16) break;
+			case 32: BK_REPLAY(32) break; case 64: BK_REPLAY(64) break; default: BK_REPLAY(128) break;
+			}
+#undef BK_REPLAY
+			KCHK();
+			return 0;
+		};
 		for (size_t sl = 0; sl + 1 < slice_lo.size(); ++sl)
 		{
 			const u32 s_lo = slice_lo[sl], s_hi = slice_lo[sl + 1];
@@ -883,23 +915,13 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 				}
 				if (bk_binned && slice_bins) { hipLaunchKernelGGL(k_place, dim3(slice_bins, s_hi - s_lo), dim3(PLACE_WG), 0, s, d_jobs + s_lo, AP<RcPack>(h, 0), d_bk); KCHK(); }
 				for (const BkGroup& g : bk_groups[sl])
-				{	// the group's fallback list (usually empty: the workgroups find a zero count and leave)
-					const u32 cnt = g.hi - g.lo;
-					const u32* fb = d_bk + g.fb;
-					if (sort_atomic) hipLaunchKernelGGL((k_sort<0, true>), dim3(std::min(cnt, 16u)), dim3(SORT_WG), 0, s, d_jobs, lpool, d_d, d_q, d_qp, d_state, fb);
-					else hipLaunchKernelGGL((k_sort<0, false>), dim3(std::min(cnt, 16u)), dim3(SORT_WG), 0, s, d_jobs, lpool, d_d, d_q, d_qp, d_state, fb);
-					u32 mxn = 1; for (u32 i = g.lo; i < g.hi; ++i) mxn = std::max(mxn, jobs[i].n);
-					const u32 parts = std::max(1u, std::min(max_parts, mxn / 1024u));
-					const dim3 rgrid(parts * std::min(cnt, 4u));
-#define BK_REPLAY(NN) { hipLaunchKernelGGL(k_replay_seams<NN>, rgrid, dim3(REPLAY_WG), 0, s, d_jobs, const_cast<u64*>(lpool), parts, cnt, fb); \
-						hipLaunchKernelGGL((k_replay<NN, 0>), rgrid, dim3(REPLAY_WG), 0, s, d_jobs, lpool, AP<RcPack>(h, 0), parts, cnt, fb); }
-					switch (jobs[g.lo].n_alpha)
-					{
-					case 4: BK_REPLAY(4) break; case 8: BK_REPLAY(8) break; case 16: BK_REPLAY(16) break;
-					case 32: BK_REPLAY(32) break; case 64: BK_REPLAY(64) break; default: BK_REPLAY(128) break;
-					}
-#undef BK_REPLAY
-					KCHK();
+				{	// the group's fallback list: here only where the host itself took a stream off the path (too short, too many tiles).  What
+					// the device hands back (k_part / k_model: a bucket too long, too many contexts) is rare and is dealt with after the batch's
+					// state read-back (below) -- rounds 4-5 launched these kernels for every group, and their empty workgroups (144 KB of LDS each)
+					// queued for CUs on the instance's serial stream: 128 launches, 48 ms in the bench profile
+					bool known = false;
+					for (u32 i = g.lo; i < g.hi; ++i) known = known || !jobs[i].bk_on;
+					if (known) { const int rc = launch_fallback(g); if (rc) return rc; }
 				}
 				stage_mark(1);
 				continue;
@@ -969,7 +991,9 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		HIPCHK(hipEventRecord(h->ev[4], s));
 		HIPCHK(hipStreamWaitEvent(h->rc_stream, h->ev[4], 0));
 		HIPCHK(hipEventRecord(h->ev[2], h->rc_stream));
-		hipLaunchKernelGGL(k_rc, dim3((NJ + RC_LANES - 1) / RC_LANES), dim3(64 * RC_WG_WAVES), 0, h->rc_stream, d_chains, NJ, AP<RcPack>(h, 0), wpool, d_state); KCHK();
+		if (rc_one_lane) hipLaunchKernelGGL(k_rc, dim3((NJ + RC_LANES - 1) / RC_LANES), dim3(64 * RC_WG_WAVES), 0, h->rc_stream, d_chains, NJ, (const u32*)nullptr, AP<RcPack>(h, 0), wpool, d_state);
+		else hipLaunchKernelGGL(k_rcs, dim3((NJ + RC_LANES - 1) / RC_LANES), dim3(64 * RCS_WG_WAVES), 0, h->rc_stream, d_chains, NJ, AP<RcPack>(h, 0), wpool, d_state, (const u32*)d_bk, d_redo);
+		KCHK();
 		HIPCHK(hipEventRecord(h->ev[3], h->rc_stream));
 		HIPCHK(hipStreamWaitEvent(s, h->ev[3], 0));
 		h->rc_launches = 1;
@@ -979,11 +1003,42 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 
 	// ---- sizes -> output layout -> assembly -----------------------------------------------------------------------
 	HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
-	std::vector<u32> bk_flags;
-	if (use_bk && getenv("DSRC_GPU_DEBUG")) { bk_flags.resize(NJ); HIPCHK(hipMemcpyAsync(bk_flags.data(), AP<u32>(h, o_bk), NJ * 4, hipMemcpyDeviceToHost, s)); }
+	std::vector<u32> bk_flags, redo;
+	if (NJ)
+	{
+		redo.resize((size_t)NJ + 1); HIPCHK(hipMemcpyAsync(redo.data(), d_redo, ((size_t)NJ + 1) * 4, hipMemcpyDeviceToHost, s));
+		if (use_bk) { bk_flags.resize(NJ); HIPCHK(hipMemcpyAsync(bk_flags.data(), d_bk, (size_t)NJ * 4, hipMemcpyDeviceToHost, s)); }
+	}
 	HIPCHK(hipStreamSynchronize(s));
+	if (NJ && !rc_one_lane)
+	{	// ---- the range coder's redo list: streams whose carry clamp fired under k_rcs (the device listed them) and streams the
+		// device handed back to k_sort / k_replay (their front end runs now): k_rc, both recurrences in one lane, from the start
+		std::vector<u32> list(redo.begin() + 1, redo.begin() + 1 + std::min<u32>(redo[0], NJ));
+		bool handed = false;
+		for (u32 i = 0; i < NJ && use_bk; ++i) if (bk_flags[i] && jobs[i].bk_on) { list.push_back(i); handed = true; }
+		if (!list.empty())
+		{
+			mark("redo"); tr.stage("dsrc batch: range coder, redo list");
+			if (handed)
+				for (size_t sl = 0; sl + 1 < slice_lo.size(); ++sl)
+					for (const BkGroup& g : bk_groups[sl])
+					{
+						bool any = false;
+						for (u32 i = g.lo; i < g.hi; ++i) any = any || (bk_flags[i] && jobs[i].bk_on);
+						if (any) { const int rc = launch_fallback(g); if (rc) return rc; }
+					}
+			std::sort(list.begin(), list.end()); list.erase(std::unique(list.begin(), list.end()), list.end());
+			std::vector<u32> up(list.size() + 1); up[0] = (u32)list.size(); std::copy(list.begin(), list.end(), up.begin() + 1);
+			HIPCHK(hipMemcpyAsync(d_redo, up.data(), up.size() * 4, hipMemcpyHostToDevice, s));
+			hipLaunchKernelGGL(k_rc, dim3(((u32)list.size() + RC_LANES - 1) / RC_LANES), dim3(64 * RC_WG_WAVES), 0, s, d_chains, NJ, (const u32*)d_redo, AP<RcPack>(h, 0), wpool, d_state); KCHK();
+			HIPCHK(hipMemcpyAsync(st.data(), d_state, sizeof(BlkState) * B, hipMemcpyDeviceToHost, s));
+			HIPCHK(hipStreamSynchronize(s));
+			h->rc_redone += (u32)list.size();
+			if (getenv("DSRC_GPU_DEBUG")) fprintf(stderr, "[dsrc_gpu] range coder: %zu of %u streams coded again by k_rc (%u carry clamps, the others handed back by the bucketed front end)\n", list.size(), NJ, std::min<u32>(redo[0], NJ));
+		}
+	}
 	mark("S4"); tr.stage("dsrc batch: assemble");
-	if (!bk_flags.empty())
+	if (!bk_flags.empty() && getenv("DSRC_GPU_DEBUG"))
 	{
 		u32 on = 0, back = 0;
 		for (u32 i = 0; i < NJ; ++i) { on += jobs[i].bk_on; back += bk_flags[i] && jobs[i].bk_on; }
@@ -1924,6 +1979,30 @@ int dsrcgpu_selftest(dsrcgpu_handle* h, uint32_t* mismatches)
 	HIPCHK(hipMemsetAsync(d_bad, 0, 4, h->stream));
 	hipLaunchKernelGGL(k_selftest, dim3(256), dim3(256), 0, h->stream, d_bad); KCHK();
 	hipLaunchKernelGGL(k_selftest_dec, dim3(256), dim3(256), 0, h->stream, d_bad); KCHK();      // the decoder's division (k_dec_rc.h)
+	{	// the two-wave range coder against the reference's loop on states at the carry clamp (k_rc.h); a run in which the reference
+		// never clamped has tested nothing and counts as a mismatch
+		u32* d_hits = nullptr; u32 hits = 0;
+		HIPCHK(hipMalloc((void**)&d_hits, 4));
+		HIPCHK(hipMemsetAsync(d_hits, 0, 4, h->stream));
+#ifdef DSRC_EMU_BUILD
+		hipLaunchKernelGGL(k_selftest_rcs, dim3(4), dim3(256), 0, h->stream, d_bad, d_hits); KCHK();
+#else
+		hipLaunchKernelGGL(k_selftest_rcs, dim3(1024), dim3(256), 0, h->stream, d_bad, d_hits); KCHK();
+#endif
+		u8* d_scr = nullptr;
+#ifdef DSRC_EMU_BUILD
+		const u32 rcv_wgs = 2;
+#else
+		const u32 rcv_wgs = 256;
+#endif
+		HIPCHK(hipMalloc((void**)&d_scr, (size_t)rcv_wgs * 64 * 1024));
+		hipLaunchKernelGGL(k_selftest_rcv, dim3(rcv_wgs), dim3(64), 0, h->stream, d_bad, d_hits, d_scr); KCHK();
+		HIPCHK(hipMemcpyAsync(&hits, d_hits, 4, hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipStreamSynchronize(h->stream));
+		HIPCHK(hipFree(d_hits)); HIPCHK(hipFree(d_scr));
+		if (getenv("DSRC_GPU_DEBUG")) fprintf(stderr, "[dsrc_gpu] selftest: the reference's carry clamp fired in %u of the split coder's test groups\n", hits);
+		if (hits < 16) HIPCHK(hipMemsetAsync(d_bad, 0xFF, 4, h->stream));
+	}
 	{	// the property k_sort's atomic ranking stands on (dsrcgpu_create runs the same test to choose the variant); a violation
 		// counts as a mismatch here so that the test-suite notices a device on which the ballot variant is in use
 		u32* d_ord = nullptr; u32 ord = 0;

@@ -37,6 +37,7 @@
 #define BK_TB 13                       // log2(records per time bin): 48 bits of record + the low bits of t fit the 8-byte slot; k_place holds a bin in LDS
 #endif                                 // (64 KB: with 14 bits and 128 KB a k_place workgroup needs a CU nearly to itself -- 1.5 ms alone, 6.9 ms next to three other instances)
 #define BK_BIN (1u << BK_TB)
+static_assert(BK_TB == RC6_TB, "a time bin is the unit of k_rc's record layout (rc6_chunk_off)");
 #define BK_MAX_BINS 512                // streams of up to 4 M symbols
 #define BK_HASH_MUL 0x9E3779B1u
 
@@ -632,10 +633,19 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 #endif
 		MD_T(3, __builtin_amdgcn_readfirstlane((int)(u32)rec))                  // the symbols on their rows
 		// the record takes the element's place (k_place puts the tile in stream order), or goes where it belongs at once
+		if (binned)
 		{
-			RcPack* to = binned ? recs + ix : recs + ((ix & ~(BK_BIN - 1u)) | (el & (BK_BIN - 1u)));
+			RcPack* to = recs + ix;
 			if (!valid) to = nowhere + lane;
-			*to = binned ? rec | ((u64)(el & (BK_BIN - 1u)) << 48) : rec;
+			*to = rec | ((u64)(el & (BK_BIN - 1u)) << 48);
+		}
+		else
+		{	// (tests: no time bins) the record goes where k_rc reads it at once: rc6_store's two pieces
+			const u32 t = (ix & ~(BK_BIN - 1u)) | (el & (BK_BIN - 1u));
+			u8* chunk = (u8*)recs + rc6_chunk_off(t >> 6);
+			u32* p32 = valid ? (u32*)chunk + (t & 63u) : (u32*)(nowhere + lane);
+			u16* p16 = valid ? (u16*)(chunk + 256) + (t & 63u) : (u16*)(nowhere + lane) + 2;
+			*p32 = (u32)rec; *p16 = (u16)(rec >> 32);
 		}
 		el_slot = el_new; ix_slot = ix_new;
 		MD_T(4, 0)                                                               // the records stored (issue)
@@ -668,7 +678,9 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 }
 
 // ---- k_place: a time bin's records into stream order, in place ------------------------------------------------------------------------
-// Grid: x = time bin, y = stream of the slice.
+// Grid: x = time bin, y = stream of the slice.  In: the bin's 8-byte records in bucket order (k_model), t mod 8192 in their top 16 bits.
+// Out: the bin's 128 chunks of k_rc's six-byte layout (k_rc.h: 64 dwords freq | cum << 16, then 64 u16 totals per chunk) over the
+// first 48 KB of the same 64 KB -- every thread holds its share of the bin before anything is written.
 #ifndef PLACE_WG
 #define PLACE_WG 512
 #endif
@@ -700,7 +712,14 @@ __global__ void __launch_bounds__(PLACE_WG) k_place(const CtxJob* jobs, RcPack* 
 			if (t < HALF) s_rec[t] = v[k] & 0xFFFFFFFFFFFFull;
 		}
 		__syncthreads();                                               // (first pass: every record of the bin is in some thread's registers by now)
-		for (u32 i = threadIdx.x; i < HALF && lo + i < cnt; i += PLACE_WG) r[lo + i] = s_rec[i];
+		for (u32 i = threadIdx.x; i < HALF && lo + i < cnt; i += PLACE_WG)
+		{
+			const u32 t = lo + i;
+			const u64 v6 = s_rec[i];
+			u8* c = (u8*)r + (t >> 6) * RC6_CHUNK_BYTES;
+			((u32*)c)[t & 63u] = (u32)v6;
+			((u16*)(c + 256))[t & 63u] = (u16)(v6 >> 32);
+		}
 		if (p + 1 < PLACE_PASSES) __syncthreads();
 	}
 }

@@ -23,8 +23,30 @@
 
 // what the range coder consumes per symbol (written by k_replay in stream order, one contiguous array per chain)
 struct RcRec { u32 m_lo, mf, cum; };     // what the coder works on (LDS rows): m = ceil(2^48/total): m_lo = m & 0xFFFFFFFF, mf = (m >> 32) << 16 | freq
-typedef u64 RcPack;                      // what k_replay scatters to stream order, 8 aligned bytes: freq | cum << 16 | total << 32 (total <= 2^16).
-                                         // k_rc's loader waves turn it into an RcRec on the way into LDS (the reciprocal is off the coder's chain)
+typedef u64 RcPack;                      // what k_model leaves per symbol, 8 aligned bytes: freq | cum << 16 | total << 32 (total < 2^16) | (t mod 8192) << 48;
+                                         // also the unit the record arrays are carved in (8 bytes of address space per symbol)
+
+// ---- what k_rc reads: six bytes per symbol (round 6) --------------------------------------------------------------------------
+// 64 consecutive records of a stream are one 384-byte CHUNK: 64 dwords freq | cum << 16, then 64 u16 totals -- a loader wave of
+// k_rc takes a chunk with one dword and one ushort load per lane.  128 chunks are a time bin (RC6_TB: 8192 symbols), and a bin starts
+// at a multiple of 64 KB of the stream's array (its 8 bytes of address space per symbol): k_place turns the bin's 64 KB of 8-byte
+// records into its 48 KB of chunks IN PLACE (a workgroup holds its whole bin before it writes), the bin's last 16 KB are dead after
+// it.  k_replay (and k_model without time bins) write the same layout directly.  Against 8-byte records: 2 B per symbol less
+// written by k_place, 2 B less read by k_rc (26 MB per 8 MiB block at -d3 -q2).
+#define RC6_TB 13
+#define RC6_CHUNK_BYTES 384u
+__device__ __forceinline__ u32 rc6_chunk_off(u32 chunk) { return ((chunk >> (RC6_TB - 6)) << (RC6_TB + 3)) + (chunk & ((1u << (RC6_TB - 6)) - 1u)) * RC6_CHUNK_BYTES; }
+__device__ __forceinline__ void rc6_store(RcPack* chain, u32 t, u32 f, u32 cum, u32 tot)
+{
+	u8* p = (u8*)chain + rc6_chunk_off(t >> 6);
+	((u32*)p)[t & 63u] = f | (cum << 16);
+	((u16*)(p + 256))[t & 63u] = (u16)tot;
+}
+__device__ __forceinline__ RcPack rc6_load(const RcPack* chain, u32 t)      // freq | cum << 16 | total << 32
+{
+	const u8* p = (const u8*)chain + rc6_chunk_off(t >> 6);
+	return (u64)((const u32*)p)[t & 63u] | ((u64)((const u16*)(p + 256))[t & 63u] << 32);
+}
 
 struct CtxJob     // one (block, stream)
 {
@@ -799,7 +821,7 @@ __device__ __forceinline__ void replay_part(const CtxJob& j, const u64* pool, Rc
 			const RcPack rr = (u64)f | ((u64)cum << 16) | ((u64)tot << 32);
 			if (PROBE & 8) recs[(u32)el & 0xFFFFFu] = rr;            // scatter inside 8 MB
 			else if (PROBE & 16) recs[(u32)el & 0x3FFFu] = rr;      // scatter inside 128 KB
-			else if (!(PROBE & 3)) recs[(u32)el] = rr;          // (a non-temporal store here: 169 instead of 55 ms per 512 blocks -- the lines do merge in the caches)
+			else if (!(PROBE & 3)) rc6_store(recs, (u32)el, f, cum, tot);   // (a non-temporal store here: 169 instead of 55 ms per 512 blocks -- the lines do merge in the caches)
 			else if (PROBE & 2) recs[idx] = rr;
 			else if (rr == ~0ull) recs[idx] = rr;                  // keeps the computation alive, never true
 		}
@@ -850,21 +872,20 @@ __global__ void __launch_bounds__(REPLAY_WG) k_replay(const CtxJob* jobs, const 
 // ---- range coder: one lane = one stream ---------------------------------------------------------
 // The only serial part of the path.  Per symbol the dependent chain is
 //   range -> floor(range / total) -> * freq -> renormalise          low -> low + r*cum -> renormalise
-// and on the GPU its cost is instruction issue, so the serial kernel (k_rc) does the arithmetic and nothing
-// else:
-//   * floor(range/total) is a multiply by the 48-bit reciprocal k_replay stored (exact, see rc_div);
-//   * a wave owns RC_LANES (32) chains whose records lie in as many arrays.  Per 64 symbols it issues one LDS-DMA
-//     load per chain (global_load_lds_dwordx4 on 48 lanes = 768 contiguous bytes = 64 records of ONE chain,
-//     landing in that chain's LDS row) for the chunk after the current one, so every global access is a full
-//     coalesced row and the coder runs 64-128 symbols (6-12 us) behind its loads; lane c then reads row c,
-//     16 records at a time, with ds_read_b128 into ping-pong registers;
-//   * the bytes a symbol pushes out of the coder are NOT packed serially: the step leaves one 32-bit code per
-//     symbol -- the top three bytes of `low` and how many of them (0..3) leave -- in an LDS row, and the loader
-//     waves, one chunk behind the coder, prefix-sum the byte counts of the row's 64 codes and store the bytes
-//     (rc_emit_chunk; until round 4 the codes went over the record array in HBM and a second kernel read them back);
-//   * RangeEncoder::EncodeFrequency's carry clamp (src/RangeCoder.h:64-74) needs bits 24..39 of `low` to be
-//     all ones; that is accumulated branch-free and checked once per 16 symbols -- if it ever shows, the
-//     group is replayed from a snapshot with the reference's loop, verbatim.
+// and on the GPU its cost is instruction issue of ONE wave: 71 clocks per symbol for both recurrences in one lane (tools/rc_lab.hip),
+// 43 for the range alone.  `low` never feeds back into `range` -- except through the carry clamp of RangeEncoder::EncodeFrequency
+// (src/RangeCoder.h:64-74), which needs bits 24..47 of low to be all ones when a byte leaves (once in 2^24 symbols) and a carry on top of that.  So (round 6) the
+// recurrence is cut in two waves of one workgroup, k_rcs:
+//   * wave R (lane = stream): range alone.  r = floor(range / total) is a multiply by the 64-bit reciprocal the loaders prepared
+//     (rc_div64), range' = r * freq renormalised by clz; it leaves r and the bytes-leaving count per symbol in LDS;
+//   * wave L (lane = stream), one 64-symbol chunk behind: low' = (low + r * cum) << 8 k, the symbol's code (top three bytes of low
+//     and how many of them leave) in place of r -- and the clamp's pre-condition as a running maximum, checked per 16 symbols; when
+//     it shows, the group is walked again with the reference's loop, and a clamp that really fires puts the stream on the REDO
+//     list: k_rc below (both recurrences in one lane, replay of a group on the spot) codes it again from the start, after the
+//     batch's state read-back -- about one stream in 10^4;
+//   * loader waves: records HBM -> registers (RC_DEPTH chunks ahead) -> the R and L rows in LDS one chunk ahead; codes -> bytes
+//     two chunks behind (prefix sum of the byte counts of a row's 64 codes, up to three byte stores per lane).
+// They meet at one barrier per chunk.  Every wave of R and L keeps its SIMD to itself (RC_SPARE_SIMD).
 struct RcChain
 {
 	u64 trip;          // RcPack index of the chain's first record (a multiple of 2: 16-byte aligned)
@@ -872,36 +893,37 @@ struct RcChain
 	u32 n;
 	u32 out_byte0, out_cap;
 	u32 blk, is_dna;
-	u32 force_exact;   // tests: take the reference-loop path for every group (same bytes by construction)
-	u32 pitch;         // records between the arrays of consecutive chains of this chain's wave (RC_LANES chains)
-	u32 pad0;
+	u32 force_exact;   // tests: take the reference-loop path for every group (same bytes by construction); 2: report a clamp for every stream (the redo path)
+	u32 jid;           // the stream's job: bk[jid] != 0 = handed back by the bucketed front end
+	u32 bk_on;         // ... by a kernel of the device (k_part / k_model), i.e. its records are not there yet when k_rcs runs: skipped, coded by the redo launch
 };
 
 #define RC_GROUP 16                    // symbols per register group / clamp check
 #ifndef RC_LANES
-#define RC_LANES 32                    // chains per wave (lanes beyond idle): half a wave keeps the LDS at 52 KB, so a k_rc wave shares a
-#endif                                 // CU with two k_sort workgroups, and it issues half as many DMA requests per symbol
-#define RC_CHUNK 64                    // symbols per chain per LDS chunk (768 B = 48 lanes x 16 B)
+#define RC_LANES 32                    // chains per wave (lanes beyond idle): half a wave keeps the LDS of a workgroup at ~100 KB
+#endif
+#define RC_CHUNK 64                    // symbols per chain per LDS chunk
 #define RC_ROW_U4 49                   // LDS row pitch in 16-byte units: 48 of data + 1 so that a 16-lane ds_read_b128 pass covers all 64 banks
 #ifndef RC_LOADERS
-#define RC_LOADERS 8                   // loader waves per workgroup (each feeds RC_LANES / RC_LOADERS rows; with the bytes written by the loaders four of them
-                                       // are what the coder waits for: k_rc 128.2 ms with four, 118.6 with eight)
+#define RC_LOADERS 8                   // loader waves per workgroup (each feeds RC_LANES / RC_LOADERS rows)
 #endif
-// Waves of a k_rc workgroup.  A workgroup's waves go round the CU's four SIMDs in order: wave 0 (the coder) keeps its SIMD to itself
-// when the waves 4, 8, ... leave at once (RC_SPARE_SIMD) -- the coder is bound by the VALU of its SIMD, every cycle a loader spends
-// there is added to the chain of dependent steps.
+// Waves of a workgroup go round the CU's four SIMDs in order.  A serial wave keeps its SIMD to itself when the waves that would
+// share it leave at once (RC_SPARE_SIMD) -- it is bound by the VALU issue of its SIMD, every cycle a loader spends there is added
+// to the chain of dependent steps.  k_rc: wave 0 codes, waves 4, 8, .. leave; k_rcs: waves 0 (R) and 1 (L), waves 4, 5, 8, 9, .. leave.
 #ifndef RC_SPARE_SIMD
 #define RC_SPARE_SIMD 1
 #endif
 #if RC_SPARE_SIMD
 #define RC_WG_WAVES (1 + RC_LOADERS + (RC_LOADERS + 2) / 3)
+#define RCS_WG_WAVES (2 * RC_LOADERS)               // waves 0 (R), 1 (L), then of every four the two on SIMDs 2 and 3
 #else
 #define RC_WG_WAVES (1 + RC_LOADERS)
+#define RCS_WG_WAVES (2 + RC_LOADERS)
 #endif
 #ifndef RC_DEPTH
 #define RC_DEPTH 8                     // register sets of a loader wave: a chunk is requested RC_DEPTH - 1 chunk periods before it is converted (even)
 #endif
-#define RC_OVERREAD ((RC_DEPTH + 2) * RC_CHUNK)     // records the loaders may touch past the longest chain of a wave (arena slack)
+#define RC_OVERREAD ((RC_DEPTH + 4) * RC_CHUNK)      // (k_rcs: RCS_DEPTH + 2 chunks)     // records the loaders may touch past the longest chain of a wave (arena slack)
 #define RC_XB 64                       // per-lane byte buffer of the exact path (LDS)
 
 typedef u32 __attribute__((vector_size(16))) U4;   // one 16-byte LDS / global access
@@ -912,6 +934,13 @@ __device__ __forceinline__ u32 rc_div(u32 range, u32 m_lo, u32 m_hi)
 {
 	const u64 p = (u64)range * m_hi + __umulhi(range, m_lo);
 	return __builtin_amdgcn_alignbit((u32)(p >> 32), (u32)p, 16);          // (u32)(p >> 16) as one opaque 32-bit value
+}
+// the same quotient with the magic shifted up by 16 (a = bits 63..32, b = bits 31..0 of magic << 16): the top dword of the product,
+// no shift (k_rcs, wave R)
+__device__ __forceinline__ u32 rc_div64(u32 range, u32 a, u32 b)
+{
+	const u64 p = (u64)range * a + __umulhi(range, b);
+	return (u32)(p >> 32);
 }
 
 struct RcState { u64 low; u32 range; };
@@ -952,7 +981,7 @@ __device__ inline void rc_step_exact(RcState& s, const RcRec& e, u8* xb, u32& nb
 	s.low = low; s.range = range;
 }
 
-// one register group: 16 records = 48 dwords = 12 x 16 bytes, as they lie in the chain's array
+// one register group: 16 records = 48 dwords = 12 x 16 bytes, as they lie in the chain's row
 struct RcRegs { U4 q[3 * RC_GROUP / 4]; };
 
 __device__ __forceinline__ RcRec rc_rec(const RcRegs& g, u32 i)
@@ -1009,24 +1038,28 @@ __device__ __forceinline__ RcRec rc_unpack(RcPack v)
 	return e;
 }
 
-// Loader wave `lw` of RC_LOADERS feeds rows lw, lw + RC_LOADERS, ...: lane l fetches record l of the row's 64-record chunk
-// (512 contiguous bytes per row and instruction) that starts at byte `chunk_off` of the chain's array; the arrays of a
-// workgroup's chains are `pitch` bytes apart.  The fetch of chunk k+2 is in flight while chunk k+1 is converted.
+// Loader wave `lw` of RC_LOADERS feeds rows lw, lw + RC_LOADERS, ...: lane l fetches record l of the row's chunk `chunk` -- one
+// dword (freq | cum << 16) and one ushort (total) of the 384-byte chunk (rc6_chunk_off).  Requests run RC_DEPTH chunks ahead.
 #define RC_ROWS_PER_LOADER (RC_LANES / RC_LOADERS)
-__device__ __forceinline__ void rc_fetch(RcPack* r, const u8* base, u32 pitch, u32 chunk_off, u32 lw, u32 n_live)
+struct RcFetch { u32 fc, tot; };
+struct RcRowBases { const u8* p[RC_ROWS_PER_LOADER]; };       // the arrays of a loader's rows (wave-uniform: scalar registers)
+__device__ __forceinline__ void rc_fetch(RcFetch* r, const RcRowBases& rb, u32 chunk, u32 lw, u32 n_live)
 {
-	const u8* sp = base + chunk_off + (u64)lw * pitch + lane_id() * 8u;
+	const u32 off = rc6_chunk_off(chunk);
 #pragma unroll
 	for (u32 k = 0; k < RC_ROWS_PER_LOADER; ++k)
 	{
-		r[k] = lw + k * RC_LOADERS < n_live ? *(const GLOBAL_AS RcPack*)sp : 0ull;   // global, not flat: a flat access orders itself against the LDS traffic       // n_live: constant RC_LANES in full workgroups
-		sp += (u64)RC_LOADERS * pitch;
+		const bool live = lw + k * RC_LOADERS < n_live;                    // n_live: constant RC_LANES in full workgroups
+		const u8* sp = rb.p[k] + off;
+		// global, not flat: a flat access orders itself against the LDS traffic
+		r[k].fc = live ? *(const GLOBAL_AS u32*)(sp + 4u * lane_id()) : 0u;
+		r[k].tot = live ? (u32)*(const GLOBAL_AS u16*)(sp + 256u + 2u * lane_id()) : 0u;
 	}
 }
 
 // ... and turns them into the coder's 12-byte records (reciprocal of the total) in the rows of `buf`;
 // a 3-dword stride over the lanes touches every LDS bank once
-__device__ __forceinline__ void rc_convert(LDS_AS U4* buf, const RcPack* r, u32 lw, u32 n_live)
+__device__ __forceinline__ void rc_convert(LDS_AS U4* buf, const RcFetch* r, u32 lw, u32 n_live)
 {
 #pragma unroll
 	for (u32 k = 0; k < RC_ROWS_PER_LOADER; ++k)
@@ -1034,9 +1067,9 @@ __device__ __forceinline__ void rc_convert(LDS_AS U4* buf, const RcPack* r, u32 
 		const u32 j = lw + k * RC_LOADERS;
 		if (j < n_live)
 		{
-			const RcRec e = rc_unpack(r[k]);
+			const u64 m = recip48(r[k].tot);
 			LDS_AS u32* d = (LDS_AS u32*)(buf + j * RC_ROW_U4) + 3u * lane_id();
-			d[0] = e.m_lo; d[1] = e.mf; d[2] = e.cum;
+			d[0] = (u32)m; d[1] = ((u32)(m >> 32) << 16) | (r[k].fc & 0xFFFFu); d[2] = r[k].fc >> 16;
 		}
 	}
 }
@@ -1084,7 +1117,7 @@ __device__ __forceinline__ void rc_emit_chunk(const LDS_AS u32* codes, RcEmitRow
 	{
 		const u32 total = wave_last(inc[k]);
 		const u32 at = R.pos[k] + inc[k] - kb[k];
-		if (R.pos[k] + total > R.limit[k]) *over |= 1u;
+		if (R.pos[k] + total > R.limit[k]) *over |= 1u << k;
 		else
 		{
 			GLOBAL_AS u8* out = R.out[k];
@@ -1096,15 +1129,55 @@ __device__ __forceinline__ void rc_emit_chunk(const LDS_AS u32* codes, RcEmitRow
 	}
 }
 
-// A workgroup is 1 + RC_LOADERS waves.  Wave 0 codes (one lane = one chain, RC_LANES chains); the others fetch the 8-byte
-// records k_replay left, two chunks ahead, and write the coder's records into the LDS rows one chunk ahead, so that the
-// coder's instruction stream is the arithmetic and nothing else.  They meet at one barrier per 64-symbol chunk: a loader
-// arrives when its rows of the chunk after the current one are written, the coder when it has finished the current one --
-// after the barrier the loaders may overwrite the buffer the coder has just left.
+// what a loader wave takes once from the lanes of its own copy of the chains (scalar registers)
+__device__ __forceinline__ void rc_rows_setup(RcRowBases& rb, RcEmitRows& R, const RcChain& c, u32 n_full, const RcPack* rec_pool, u32* word_pool, u32 lw, u32 n_live)
+{
+#pragma unroll
+	for (u32 k = 0; k < RC_ROWS_PER_LOADER; ++k)
+	{
+		const u32 j = lw + k * RC_LOADERS < n_live ? lw + k * RC_LOADERS : 0u;
+		rb.p[k] = uniform_ptr(rec_pool + __shfl(c.trip, (int)j));
+		R.out[k] = (GLOBAL_AS u8*)uniform_ptr(word_pool + __shfl(c.out_words, (int)j));
+		R.limit[k] = (u32)__builtin_amdgcn_readfirstlane((int)__shfl(c.out_byte0 + c.out_cap, (int)j));
+		R.n_full[k] = (u32)__builtin_amdgcn_readfirstlane((int)__shfl(n_full, (int)j));
+		R.pos[k] = (u32)__builtin_amdgcn_readfirstlane((int)__shfl(c.out_byte0, (int)j));
+	}
+}
+
+// the last n mod 16 symbols and RangeEncoder::End, behind the bytes of the chunks
+__device__ __forceinline__ void rc_finish(RcState s, const RcChain& c, const RcPack* rec_pool, u32* word_pool, BlkState* st, u32 n_full, u32 pos, bool report, u8* xb)
+{
+	const RcPack* p = rec_pool + c.trip;
+	u8* out = (u8*)(word_pool + c.out_words);
+	const u32 limit = c.out_byte0 + c.out_cap;
+	u32* err = &st[c.blk].err;
+	u32 nb = 0;
+	for (u32 t = n_full; t < c.n; ++t) { const RcRec e = rc_unpack(rc6_load(p, t)); rc_step_exact(s, e, xb, nb); }
+	if (nb > RC_XB) { if (report) atomicOr(err, (u32)DSRC_ERR_OUT_OVERFLOW); nb = 0; }
+	if (pos + nb + 8 > limit) { if (report) atomicOr(err, (u32)DSRC_ERR_OUT_OVERFLOW); }
+	else
+	{
+		for (u32 k = 0; k < nb; ++k) out[pos + k] = xb[k];
+		for (u32 k = 0; k < 8; ++k) { out[pos + nb + k] = (u8)(s.low >> 56); s.low <<= 8; }
+	}
+	pos += nb + 8;
+	if (c.is_dna) st[c.blk].dna_bytes = pos; else st[c.blk].qua_bytes = pos;
+}
+
+// ---- k_rc: both recurrences in one lane ------------------------------------------------------------------------------------------
+// Since round 6 the kernel of the REDO list (`list`: count, then chain ids): streams in which the carry clamp fired under k_rcs and
+// streams the bucketed front end handed back on the device (their records come from k_sort / k_replay after the batch's state
+// read-back).  With list = nullptr it codes chains [0, n_chains) -- the path the hooks build can force for a whole batch.
+// A workgroup is 1 + RC_LOADERS waves.  Wave 0 codes (one lane = one chain, RC_LANES chains); the others fetch the records, RC_DEPTH
+// chunks ahead, and write the coder's records into the LDS rows one chunk ahead, so that the coder's instruction stream is the
+// arithmetic and nothing else.  They meet at one barrier per 64-symbol chunk: a loader arrives when its rows of the chunk after the
+// current one are written, the coder when it has finished the current one -- after the barrier the loaders may overwrite the buffer
+// the coder has just left.  The carry clamp's pre-condition (bits 24..39 of low all ones) is accumulated branch-free and checked
+// once per 16 symbols: if it shows, the group is replayed from a snapshot with the reference's loop, verbatim.
 // FULL: every lane below RC_LANES has a chain; the last workgroup of a launch may be partial and then must not request
 // rows it does not have (one launch, two instantiations of the body: a wave only ever fetches the code of its own).
 template <bool FULL>
-__device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains, RcPack* rec_pool, u32* word_pool, BlkState* st, LDS_AS U4* buf_a, LDS_AS U4* buf_b, u8* s_xb,
+__device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains, const u32* list, RcPack* rec_pool, u32* word_pool, BlkState* st, LDS_AS U4* buf_a, LDS_AS U4* buf_b, u8* s_xb,
 												 LDS_AS u32* code_a, LDS_AS u32* code_b, LDS_AS u32* s_pos)
 {
 	__builtin_amdgcn_s_setprio(3);                                             // the serial waves win issue arbitration against co-resident data-parallel waves
@@ -1126,7 +1199,8 @@ __device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains
 	const u32 loader_id = wave_id() - 1u;
 #endif
 	const bool have = lane < RC_LANES && (FULL || id < n_chains);
-	const RcChain c = chains[have ? id : n_chains - 1];                        // idle lanes shadow a real chain's values and code nothing
+	const u32 cid = have ? id : n_chains - 1;                                  // idle lanes shadow a real chain's values and code nothing
+	const RcChain c = chains[list ? list[1 + cid] : cid];
 	const u32 n_live = FULL ? (u32)RC_LANES : n_chains - first_chain;
 	const u32 n = have ? c.n : 0;
 	const u32 n_full = n & ~(u32)(RC_GROUP - 1);
@@ -1135,29 +1209,18 @@ __device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains
 	if (loader)
 	{
 		if (!wave_full) return;
-		// the arrays of a workgroup's chains are c.pitch records apart (wave-uniform; idle lanes shadow the last chain's values)
-		const u8* base = uniform_ptr(rec_pool + __shfl(c.trip, 0));
-		const u32 pitch = (u32)__builtin_amdgcn_readfirstlane((int)(c.pitch * (u32)sizeof(RcPack)));
-		const u32 lw = loader_id, CB = RC_CHUNK * (u32)sizeof(RcPack);
+		const u32 lw = loader_id;
+		RcRowBases rb; RcEmitRows R; u32 over = 0;
+		rc_rows_setup(rb, R, c, n_full, rec_pool, word_pool, lw, n_live);
 		// RC_DEPTH register sets: a chunk is requested RC_DEPTH - 1 chunk periods before it is converted -- with other instances'
 		// traffic on the memory system a load can take many microseconds, and the coder waits for the slowest of a chunk's 32
 		// rows (round 2, four sets of two loaders: k_rc 130 ms alone, 175 ms next to three other instances' front ends)
 		static_assert(RC_DEPTH % 2 == 0 && RC_DEPTH >= 2, "buffer parity must be static");
-		RcPack r[RC_DEPTH][RC_ROWS_PER_LOADER];
+		RcFetch r[RC_DEPTH][RC_ROWS_PER_LOADER];
 #pragma unroll
-		for (u32 d = 0; d < RC_DEPTH; ++d) rc_fetch(r[d], base, pitch, d * CB, lw, n_live);
+		for (u32 d = 0; d < RC_DEPTH; ++d) rc_fetch(r[d], rb, d, lw, n_live);
 		rc_convert(buf_a, r[0], lw, n_live);
 		__syncthreads();                                                       // chunk 0 is there
-		RcEmitRows R; u32 over = 0;
-#pragma unroll
-		for (u32 k = 0; k < RC_ROWS_PER_LOADER; ++k)
-		{
-			const u32 j = lw + k * RC_LOADERS < n_live ? lw + k * RC_LOADERS : 0u;
-			R.out[k] = (GLOBAL_AS u8*)uniform_ptr(word_pool + __shfl(c.out_words, j));
-			R.limit[k] = (u32)__builtin_amdgcn_readfirstlane((int)__shfl(c.out_byte0 + c.out_cap, j));
-			R.n_full[k] = (u32)__builtin_amdgcn_readfirstlane((int)__shfl(n_full, j));
-			R.pos[k] = (u32)__builtin_amdgcn_readfirstlane((int)__shfl(c.out_byte0, j));
-		}
 		// one barrier per chunk the coder works through: it takes them in pairs (buf_a, buf_b)
 		const u32 n_sync = 2u * ((wave_full + 2 * RC_CHUNK - 1) / (2 * RC_CHUNK));
 		for (u32 q = 0; q < n_sync; q += RC_DEPTH)
@@ -1167,7 +1230,7 @@ __device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains
 			{	// the coder is in chunk q + k (buf_a / code_a for even k): its set is free for chunk q + k + RC_DEPTH, the next chunk goes
 				// into the other record buffer, and the codes of the chunk before it (in the other code buffer) become bytes
 				if (q + k >= n_sync) break;
-				rc_fetch(r[k], base, pitch, (q + k + RC_DEPTH) * CB, lw, n_live);
+				rc_fetch(r[k], rb, q + k + RC_DEPTH, lw, n_live);
 				rc_convert((k & 1u) ? buf_a : buf_b, r[(k + 1) % RC_DEPTH], lw, n_live);
 				if (q + k >= 1) rc_emit_chunk((k & 1u) ? code_a : code_b, R, q + k - 1, lw, n_live, &over);
 				__syncthreads();
@@ -1176,14 +1239,11 @@ __device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains
 		rc_emit_chunk(code_b, R, n_sync - 1, lw, n_live, &over);     // n_sync is even: the last chunk's codes are in code_b
 #pragma unroll
 		for (u32 k = 0; k < RC_ROWS_PER_LOADER; ++k)
-			if (lw + k * RC_LOADERS < n_live && lane_id() == 0) s_pos[lw + k * RC_LOADERS] = R.pos[k] | (over ? 0x80000000u : 0u);
+			if (lw + k * RC_LOADERS < n_live && lane_id() == 0) s_pos[lw + k * RC_LOADERS] = R.pos[k] | (((over >> k) & 1u) << 31);
 		__syncthreads();                                                       // the coder takes the positions for the chains' tails
 		return;
 	}
 
-	RcPack* p = rec_pool + c.trip;
-	u8* out = (u8*)(word_pool + c.out_words);
-	const u32 limit = c.out_byte0 + c.out_cap;
 	u8* xb = s_xb + lane * RC_XB;
 	u32* err = &st[c.blk].err;
 	RcState s;
@@ -1210,23 +1270,12 @@ __device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains
 		__syncthreads();                                                       // the loaders have turned the last chunk's codes into bytes
 	}
 	if (!have) return;
-	// the last n mod 16 symbols and RangeEncoder::End, behind the bytes of the chunks
 	u32 pos = c.out_byte0;
 	if (wave_full) { const u32 v = s_pos[lane]; pos = v & 0x7FFFFFFFu; if (v >> 31) atomicOr(err, (u32)DSRC_ERR_OUT_OVERFLOW); }
-	u32 nb = 0;
-	for (u32 t = n_full; t < n; ++t) { const RcRec e = rc_unpack(p[t]); rc_step_exact(s, e, xb, nb); }
-	if (nb > RC_XB) { atomicOr(err, (u32)DSRC_ERR_OUT_OVERFLOW); nb = 0; }
-	if (pos + nb + 8 > limit) atomicOr(err, (u32)DSRC_ERR_OUT_OVERFLOW);
-	else
-	{
-		for (u32 k = 0; k < nb; ++k) out[pos + k] = xb[k];
-		for (u32 k = 0; k < 8; ++k) { out[pos + nb + k] = (u8)(s.low >> 56); s.low <<= 8; }
-	}
-	pos += nb + 8;
-	if (c.is_dna) st[c.blk].dna_bytes = pos; else st[c.blk].qua_bytes = pos;
+	rc_finish(s, c, rec_pool, word_pool, st, n_full, pos, true, xb);
 }
 
-__global__ void __launch_bounds__(64 * RC_WG_WAVES) k_rc(const RcChain* chains, u32 n_chains, RcPack* rec_pool, u32* word_pool, BlkState* st)
+__global__ void __launch_bounds__(64 * RC_WG_WAVES) k_rc(const RcChain* chains, u32 n_chains, const u32* list, RcPack* rec_pool, u32* word_pool, BlkState* st)
 {
 	__shared__ U4 s_a[RC_LANES * RC_ROW_U4];
 	__shared__ U4 s_b[RC_LANES * RC_ROW_U4];
@@ -1234,8 +1283,521 @@ __global__ void __launch_bounds__(64 * RC_WG_WAVES) k_rc(const RcChain* chains, 
 	__shared__ U4 s_cb[RC_LANES * RC_CODE_PITCH / 4];
 	__shared__ u32 s_pos[RC_LANES];
 	__shared__ u8 s_xb[64 * RC_XB];
-	if (blockIdx.x * RC_LANES + RC_LANES <= n_chains) rc_workgroup<true>(chains, n_chains, rec_pool, word_pool, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb, (LDS_AS u32*)s_ca, (LDS_AS u32*)s_cb, (LDS_AS u32*)s_pos);
-	else rc_workgroup<false>(chains, n_chains, rec_pool, word_pool, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb, (LDS_AS u32*)s_ca, (LDS_AS u32*)s_cb, (LDS_AS u32*)s_pos);
+	if (list) n_chains = list[0];
+	if (blockIdx.x * RC_LANES >= n_chains) return;
+	if (blockIdx.x * RC_LANES + RC_LANES <= n_chains) rc_workgroup<true>(chains, n_chains, list, rec_pool, word_pool, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb, (LDS_AS u32*)s_ca, (LDS_AS u32*)s_cb, (LDS_AS u32*)s_pos);
+	else rc_workgroup<false>(chains, n_chains, list, rec_pool, word_pool, st, (LDS_AS U4*)s_a, (LDS_AS U4*)s_b, s_xb, (LDS_AS u32*)s_ca, (LDS_AS u32*)s_cb, (LDS_AS u32*)s_pos);
+}
+
+// ---- k_rcs: the two recurrences on two waves ---------------------------------------------------------------------------------------
+// LDS of a workgroup: R rows (a, b, freq: 12 B per symbol) x 2, L rows (freq | cum << 16) x 3, R's words x 2, code rows x 2 -- the
+// chunk of period p is converted in period p - 1, coded by R in p, by L in p + 1 and turned into bytes in p + 2.
+#define RCS_RROW_U4 (RC_LANES * RC_ROW_U4)
+#define RCS_LROW_U4 (RC_LANES * RC_CODE_PITCH / 4)
+#define RCS_KROW_U4 ((RC_LANES + 1) * RC_CODE_PITCH / 4)      // + a row for the idle lanes of R and L to write to
+#ifndef RCS_PROBE
+#define RCS_PROBE 0                    // experiments only (wrong output): 1 no byte emission, 2 wave L idle, 4 wave R idle, 8 no conversion
+#endif
+#define RCS_DEPTH 6                    // register sets of a loader wave: a chunk is requested RCS_DEPTH - 1 chunk periods before it is converted
+
+// wave R, one symbol: r | (bytes leaving) << 30.  r < 2^30: a row's total is at least the alphabet size (>= 4).
+__device__ __forceinline__ u32 rcs_step_r(u32& range_, u32 a, u32 b, u32 freq)
+{
+	const u32 r = rc_div64(range_, a, b);
+	const u32 range = r * freq;
+	__builtin_assume(range != 0);
+	const u32 k8 = (u32)__builtin_clz(range) & 0x18u;
+	range_ = range << k8;
+	return r | (k8 << 27);
+}
+
+// wave L, one symbol: the code rc_step_fast gives.  The clamp (src/RangeCoder.h:67-71) tests the top byte of low against that of
+// low + range with range < 2^24, for the first byte that leaves on low itself (a carry through bits 24..55), for the second on
+// low << 8 (bits 16..47 of low): either needs bits 24..47 of low to be all ones.  `flag`: running maximum of bits 16..47 -- its top
+// 24 bits are the maximum of bits 24..47 (one alignbit per symbol, no mask); once in 2^24 symbols.
+__device__ __forceinline__ u32 rcs_step_l(u64& low_, u32 rk, u32 fc, u32& flag)
+{
+	const u32 r = rk & 0x3FFFFFFFu, k8 = (rk >> 27) & 0x18u;
+	const u64 low = low_ + (u64)r * (fc >> 16);
+	const u32 z = __builtin_amdgcn_alignbit((u32)(low >> 32), (u32)low, 16);     // bits 16..47
+	flag = z > flag ? z : flag;
+	low_ = low << k8;
+	return ((u32)(low >> 32) & 0xFFFFFF00u) | k8;
+}
+
+// wave L, a chunk in which the pre-condition showed: the reference's loop on low over the chain's `count` symbols of the chunk (r and
+// the byte counts are R's); true if the clamp fires (R's range is then not the reference's from that symbol on: the stream goes to
+// the redo list).  Not inlined: rare, and the serial wave's loop stays short.
+__device__ __attribute__((noinline)) bool rcs_chunk_clamps(u64 low, const LDS_AS u32* rk, const LDS_AS u32* fc, u32 count)
+{
+#pragma unroll 1
+	for (u32 i = 0; i < count; ++i)
+	{
+		const u32 r = rk[i] & 0x3FFFFFFFu, fci = fc[i];
+		low += (u64)r * (fci >> 16);
+		u32 range = r * (fci & 0xFFFFu);
+#pragma unroll 1
+		for (u32 guard = 0; range <= 0x00FFFFFFu && guard < 8; ++guard)
+		{
+			if ((low ^ (low + range)) & 0xFF00000000000000ull) return true;
+			low <<= 8; range <<= 8;
+		}
+	}
+	return false;
+}
+
+// Wave L, a chunk q in which the clamp fires (about once in four 450-block batches): R's range is not the reference's from that symbol
+// on -- and R is already a chunk further.  The lane walks chunk q again from the state at its start with RangeEncoder::EncodeFrequency
+// verbatim (records straight from the stream's array in HBM: nothing of it is left in LDS), deals the bytes out three per code slot
+// (the emitter only concatenates them), then codes chunk q + 1 the way R does from the range that is right: its words go to a row of
+// their own (`fixrow`: L reads them in place of R's in the next period), the range after them to R, which takes it at the start of
+// chunk q + 2.  res: [0,1] low after chunk q, [2] range after chunk q, [3] range after chunk q + 1, [4] 0 = done, 1 = the bytes do
+// not fit the chunk's slots (the stream goes to the redo list instead).  Not inlined: rare, and the serial wave's loop stays short.
+#define RCS_RXB 200
+__device__ __attribute__((noinline)) void rcs_recover(const RcPack* chain, u32 q, u64 low, u32 range, u32 n_full, LDS_AS u32* crow, LDS_AS u32* fixrow, u8* xb, LDS_AS u32* res)
+{
+	const u32 t0 = q * RC_CHUNK;
+	const u32 cnt = n_full - t0 < RC_CHUNK ? n_full - t0 : RC_CHUNK;
+	u32 nb = 0;
+#pragma unroll 1
+	for (u32 i = 0; i < cnt; ++i)
+	{
+		const RcRec e = rc_unpack(rc6_load(chain, t0 + i));
+		const u32 r = rc_div(range, e.m_lo, e.mf >> 16);
+		low += (u64)r * e.cum;
+		range = r * (e.mf & 0xFFFFu);
+#pragma unroll 1
+		for (u32 guard = 0; range <= 0x00FFFFFFu && guard < 8; ++guard)
+		{
+			if ((low ^ (low + range)) & 0xFF00000000000000ull) { const u32 rr = (u32)low; range = (rr | 0x00FFFFFFu) - rr; }
+			if (nb < RCS_RXB) xb[nb] = (u8)(low >> 56);
+			++nb;
+			low <<= 8; range <<= 8;
+		}
+	}
+	res[0] = (u32)low; res[1] = (u32)(low >> 32); res[2] = range;
+	if (nb > 3 * cnt || nb > RCS_RXB) { res[4] = 1; return; }
+#pragma unroll 1
+	for (u32 i = 0; i < RC_CHUNK; ++i)
+	{
+		const u32 have = nb > 3 * i ? nb - 3 * i : 0u, take = have < 3 ? have : 3u;
+		u32 code = take << 3;
+		if (take >= 1) code |= (u32)xb[3 * i] << 24;
+		if (take >= 2) code |= (u32)xb[3 * i + 1] << 16;
+		if (take >= 3) code |= (u32)xb[3 * i + 2] << 8;
+		crow[i] = code;
+	}
+	const u32 t1 = t0 + RC_CHUNK;
+	const u32 cnt1 = n_full > t1 ? (n_full - t1 < RC_CHUNK ? n_full - t1 : RC_CHUNK) : 0u;
+#pragma unroll 1
+	for (u32 i = 0; i < RC_CHUNK; ++i)
+	{
+		u32 w = 0;
+		if (i < cnt1)
+		{
+			const RcPack v = rc6_load(chain, t1 + i);
+			const u64 m = recip48((u32)(v >> 32));
+			w = rcs_step_r(range, (u32)(m >> 16), (u32)m << 16, (u32)v & 0xFFFFu);
+		}
+		fixrow[i] = w;
+	}
+	res[3] = range; res[4] = 0;
+}
+
+struct RcsLds { LDS_AS U4* r; LDS_AS U4* l; LDS_AS U4* k; LDS_AS U4* c; u8* xb; LDS_AS u32* pos; LDS_AS u32* range; LDS_AS u32* rstart; LDS_AS u32* fix; LDS_AS u32* fixrow; LDS_AS u32* res; u8* rxb; LDS_AS u32* owner; };
+
+template <bool FULL>
+__device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chains, RcPack* rec_pool, u32* word_pool, BlkState* st, const u32* bk, u32* redo, const RcsLds S)
+{
+	LDS_AS U4* const s_r = S.r; LDS_AS U4* const s_l = S.l; LDS_AS U4* const s_k = S.k; LDS_AS U4* const s_c = S.c;
+	u8* const s_xb = S.xb; LDS_AS u32* const s_pos = S.pos; LDS_AS u32* const s_range = S.range;
+	__builtin_amdgcn_s_setprio(3);
+	const u32 first_chain = blockIdx.x * RC_LANES;
+	const u32 lane = lane_id(), id = first_chain + lane, w = wave_id();
+	const bool loader = w >= 2;
+#if RC_SPARE_SIMD
+#if !defined(DSRC_EMU_BUILD) && defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "RC_SPARE_SIMD relies on the gfx9 barrier counting only live waves: build other targets with -DRC_SPARE_SIMD=0"
+#endif
+	if (loader && (w & 3u) < 2u) return;                                       // the waves that would share R's and L's SIMDs leave before the first barrier
+	const u32 loader_id = (w >> 2) * 2u + (w & 1u);
+#else
+	const u32 loader_id = w - 2u;
+#endif
+	const bool have0 = lane < RC_LANES && (FULL || id < n_chains);
+	const RcChain c = chains[have0 ? id : n_chains - 1];                       // idle lanes shadow a real chain's values and code nothing
+	// a stream the device handed back to k_sort / k_replay has no records yet: the redo launch codes it
+	const bool have = have0 && !(c.bk_on && bk && bk[c.jid]);
+	const u32 n_live = FULL ? (u32)RC_LANES : n_chains - first_chain;
+	const u32 n = have ? c.n : 0;
+	const u32 n_full = n & ~(u32)(RC_GROUP - 1);
+	const u32 wave_full = (u32)__builtin_amdgcn_readfirstlane((int)wave_max(n_full));      // same value in every wave
+	const u32 n_chunks = (wave_full + RC_CHUNK - 1) / RC_CHUNK;
+
+	if (loader)
+	{
+		if (!wave_full) return;
+		const u32 lw = loader_id;
+		RcRowBases rb; RcEmitRows R; u32 over = 0;
+		rc_rows_setup(rb, R, c, n_full, rec_pool, word_pool, lw, n_live);
+		RcFetch r[RCS_DEPTH][RC_ROWS_PER_LOADER];
+#pragma unroll
+		for (u32 d = 0; d < RCS_DEPTH; ++d) rc_fetch(r[d], rb, d, lw, n_live);
+		// a chunk's R rows are in buffer (chunk & 1), its L rows in buffer (chunk % 3)
+		auto convert = [&](const RcFetch* f, u32 r2, u32 l3)
+		{
+			LDS_AS U4* rbuf = s_r + r2 * RCS_RROW_U4;
+			LDS_AS u32* lbuf = (LDS_AS u32*)(s_l + l3 * RCS_LROW_U4);
+#pragma unroll
+			for (u32 k = 0; k < RC_ROWS_PER_LOADER; ++k)
+			{
+				const u32 j = lw + k * RC_LOADERS;
+				if (j < n_live)
+				{
+					const u64 m = recip48(f[k].tot);                          // < 2^47: m << 16 fits
+					LDS_AS u32* d = (LDS_AS u32*)(rbuf + j * RC_ROW_U4) + 3u * lane_id();
+					d[0] = (u32)(m >> 16); d[1] = (u32)m << 16; d[2] = f[k].fc & 0xFFFFu;
+					lbuf[j * RC_CODE_PITCH + lane_id()] = f[k].fc;
+				}
+			}
+		};
+		convert(r[0], 0, 0);
+		__syncthreads();                                                       // chunk 0 is there
+		// periods 0 .. n_chunks + 1: R is in chunk p, L in p - 1, the bytes of p - 2 are written, p + 1 is converted.  Unrolled over
+		// the register sets: every set and buffer is known statically (a rolled loop that picks the sets with a switch makes the
+		// compiler wait for every request in flight, vmcnt(0), once per period: 144 instead of 100 ms)
+		static_assert(RCS_DEPTH % 6 == 0, "buffer indices must be static in the unrolled loop");
+		const u32 n_per = n_chunks + 2u;
+		for (u32 q = 0; q < n_per; q += RCS_DEPTH)
+		{
+#pragma unroll
+			for (u32 k = 0; k < RCS_DEPTH; ++k)
+			{
+				const u32 p = q + k;                                           // p mod 2 = k mod 2, p mod 3 = k mod 3
+				if (p >= n_per) break;
+				rc_fetch(r[k], rb, p + RCS_DEPTH, lw, n_live);
+				if (!(RCS_PROBE & 8)) convert(r[(k + 1) % RCS_DEPTH], (k + 1) & 1u, (k + 1) % 3u);
+				if (p >= 2u && !(RCS_PROBE & 1)) rc_emit_chunk((const LDS_AS u32*)(s_c + (k & 1u) * RCS_KROW_U4), R, p - 2u, lw, n_live, &over);      // (p - 2) mod 2
+				__syncthreads();
+			}
+		}
+#pragma unroll
+		for (u32 k = 0; k < RC_ROWS_PER_LOADER; ++k)
+			if (lw + k * RC_LOADERS < n_live && lane_id() == 0) s_pos[lw + k * RC_LOADERS] = R.pos[k] | (((over >> k) & 1u) << 31);
+		__syncthreads();                                                       // L takes the positions for the chains' tails
+		return;
+	}
+
+	// R and L have NO lane-dependent control flow in their loops (a guard per group of 16 made the compiler sink the LDS reads under it
+	// and cost wave L 25 of 76 clocks per symbol): every lane codes every chunk of the wave's longest chain -- past its own chain's
+	// end on whatever lies there -- and keeps the state it had at the end of its own last full group (a select per group).  Idle lanes
+	// (RC_LANES .. 63) read the last row and write to a spare one.
+	const u32 rowi = lane < RC_LANES ? lane : RC_LANES - 1;
+	const u32 rowo = lane < RC_LANES ? lane : RC_LANES;
+	if (w == 0)
+	{	// ---- wave R
+		if (!wave_full) return;
+		u32 range = 0xFFFFFFFFu, range_end = 0xFFFFFFFFu;
+		__syncthreads();
+		for (u32 p = 0; p < n_chunks + 2u; ++p)
+		{
+			if (p < n_chunks && !(RCS_PROBE & 4))
+			{
+				{	// L's correction for this chunk, if any (a clamp two chunks back: rcs_recover); the range this chunk starts from, for L
+					const u32 fp = S.fix[2 * lane], fr = S.fix[2 * lane + 1];
+					range = fp == p ? fr : range;
+					S.rstart[(p & 1u) * 64u + lane] = range;
+				}
+				const LDS_AS U4* row = s_r + (p & 1u) * RCS_RROW_U4 + rowi * RC_ROW_U4;
+				LDS_AS U4* out = s_k + (p & 1u) * RCS_KROW_U4 + rowo * (RC_CODE_PITCH / 4);
+				// eight symbols (six 16-byte reads) at a time, the next eight on their way: two sets of 24 registers
+				constexpr u32 H = RC_GROUP / 2, HQ = 3 * H / 4, NH = RC_CHUNK / H;
+				U4 ha[HQ], hb[HQ];
+#pragma unroll
+				for (u32 i = 0; i < HQ; ++i) ha[i] = row[i];
+#pragma unroll
+				for (u32 hh = 0; hh < NH; ++hh)
+				{
+					U4* cur = (hh & 1u) ? hb : ha; U4* nxt = (hh & 1u) ? ha : hb;
+					if (hh + 1 < NH)
+					{
+#pragma unroll
+						for (u32 i = 0; i < HQ; ++i) nxt[i] = row[(hh + 1) * HQ + i];
+					}
+					const u32* d = (const u32*)cur;
+					u32 v[H];
+#pragma unroll
+					for (u32 i = 0; i < H; ++i) v[i] = rcs_step_r(range, d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+#pragma unroll
+					for (u32 i = 0; i < H / 4; ++i) { const U4 x = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]}; out[hh * (H / 4) + i] = x; }
+					if (hh & 1u) range_end = p * RC_CHUNK + (hh / 2 + 1) * RC_GROUP == n_full ? range : range_end;      // the chain's last full group ends here
+				}
+			}
+			__syncthreads();
+		}
+		s_range[lane] = range_end;
+		__syncthreads();
+		return;
+	}
+
+	// ---- wave L
+	u8* xb = s_xb + lane * RC_XB;
+	RcState s;
+	s.low = 0; s.range = 0xFFFFFFFFu;
+	bool dead = false;
+	if (wave_full)
+	{
+		u64 low = 0, low_end = 0;
+		u32 range_fix_end = 0;                                                 // the range at the chain's last full group, if a recovery passed over it
+		bool fix_mine = false; u32 fix_start = 0;                              // this lane's words of the chunk come from the fix row; the range that chunk starts from
+		__syncthreads();
+		u32 i3 = 2;                                                            // (p - 1) mod 3
+		for (u32 p = 0; p < n_chunks + 2u; ++p)
+		{
+			if (p >= 1u && p <= n_chunks && !(RCS_PROBE & 2))
+			{
+				const u32 q = p - 1u;
+				const LDS_AS U4* fcrow = s_l + i3 * RCS_LROW_U4 + rowi * (RC_CODE_PITCH / 4);
+				const LDS_AS U4* krow = fix_mine ? (const LDS_AS U4*)S.fixrow : s_k + (q & 1u) * RCS_KROW_U4 + rowi * (RC_CODE_PITCH / 4);
+				LDS_AS U4* crow = s_c + (q & 1u) * RCS_KROW_U4 + rowo * (RC_CODE_PITCH / 4);
+				// a group's words are requested while the group before it is coded (two sets of registers)
+				constexpr u32 GQ = RC_GROUP / 4, NG = RC_CHUNK / RC_GROUP;
+				U4 ka[GQ], fa[GQ], kb[GQ], fb[GQ];
+#pragma unroll
+				for (u32 i = 0; i < GQ; ++i) { ka[i] = krow[i]; fa[i] = fcrow[i]; }
+				const u64 snap = low;
+				u32 flag = c.force_exact ? 0xFFFFFF00u : 0u;
+#pragma unroll
+				for (u32 g = 0; g < NG; ++g)
+				{
+					U4* kq = (g & 1u) ? kb : ka; U4* fq = (g & 1u) ? fb : fa;
+					U4* kn = (g & 1u) ? ka : kb; U4* fn = (g & 1u) ? fa : fb;
+					if (g + 1 < NG)
+					{
+#pragma unroll
+						for (u32 i = 0; i < GQ; ++i) { kn[i] = krow[(g + 1) * GQ + i]; fn[i] = fcrow[(g + 1) * GQ + i]; }
+					}
+					const u32* rk = (const u32*)kq; const u32* fc = (const u32*)fq;
+					u32 v[RC_GROUP];
+#pragma unroll
+					for (u32 i = 0; i < RC_GROUP; ++i) v[i] = rcs_step_l(low, rk[i], fc[i], flag);
+#pragma unroll
+					for (u32 i = 0; i < GQ; ++i) { const U4 x = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]}; crow[g * GQ + i] = x; }
+					low_end = q * RC_CHUNK + (g + 1) * RC_GROUP == n_full ? low : low_end;
+				}
+				// the clamp's pre-condition somewhere in the chunk, in some lane's own symbols (once in 2^24 symbols; beyond a chain's end
+				// the words are whatever lay there): a branch of the whole wave, once per chunk -- R's words and the L row are still there
+				const bool look = !(RCS_PROBE & 16) && (flag >> 8) == 0xFFFFFFu && !dead && q * RC_CHUNK < n_full;
+				const bool had_fix = fix_mine;
+				bool recovered = false;
+				if (__ballot(look))
+				{
+					const u32 count = n_full - q * RC_CHUNK < RC_CHUNK ? n_full - q * RC_CHUNK : RC_CHUNK;
+					// tests: 2 = every stream reports a clamp in its first chunk and goes to the redo list, 3 = a recovery every few chunks (the walk with
+					// the reference's loop gives the bytes the fast path gave: nothing changes but the road)
+					const bool forced = c.force_exact == 2u || (c.force_exact == 3u && (q + lane) % 5u == 2u);
+					if (look && (forced || rcs_chunk_clamps(snap, (const LDS_AS u32*)krow, (const LDS_AS u32*)fcrow, count)))
+					{
+						// one recovery at a time per workgroup (the fix row): a second lane in the same two periods, and anything rcs_recover
+						// cannot express, goes to the redo list -- k_rc codes the stream again (what this launch still writes for it is overwritten)
+						bool mine = had_fix;
+						if (!mine && c.force_exact != 2u) mine = atomicCAS((u32*)S.owner, 0u, lane + 1u) == 0u;
+						if (mine)
+						{
+							const u32 r0 = had_fix ? fix_start : S.rstart[(q & 1u) * 64u + lane];
+							rcs_recover(rec_pool + c.trip, q, snap, r0, n_full, (LDS_AS u32*)crow, S.fixrow, S.rxb, S.res);
+							if (S.res[4] == 0u)
+							{
+								low = (u64)S.res[0] | ((u64)S.res[1] << 32);
+								const u32 rq = S.res[2], rq1 = S.res[3], end_q = (q + 1u) * RC_CHUNK;
+								if (n_full <= end_q) { low_end = low; range_fix_end = rq; }
+								else if (n_full <= end_q + RC_CHUNK) range_fix_end = rq1;
+								fix_mine = true; fix_start = rq; recovered = true;
+								S.fix[2 * lane] = q + 2u; S.fix[2 * lane + 1] = rq1;       // R takes it at the start of chunk q + 2
+							}
+							else { mine = false; if (!had_fix) *S.owner = 0u; }
+						}
+						if (!mine)
+						{
+							dead = true;
+							if (!(RCS_PROBE & 64)) { const u32 at = atomicAdd(&redo[0], 1u); redo[1 + at] = id; }
+						}
+					}
+				}
+				// the fix row has been read; unless a recovery has just filled it again for the next chunk, it is free
+				if (had_fix && !recovered) { fix_mine = false; *S.owner = 0u; }
+			}
+			i3 = i3 == 2u ? 0u : i3 + 1u;
+			__syncthreads();
+		}
+		__syncthreads();                                                       // the loaders have turned the last chunk's codes into bytes
+		s.low = low_end; s.range = range_fix_end ? range_fix_end : s_range[lane];
+	}
+	if (!have || dead) return;
+	u32 pos = c.out_byte0;
+	if (wave_full) { const u32 v = s_pos[lane]; pos = v & 0x7FFFFFFFu; if (v >> 31) atomicOr(&st[c.blk].err, (u32)DSRC_ERR_OUT_OVERFLOW); }
+	rc_finish(s, c, rec_pool, word_pool, st, n_full, pos, true, xb);
+}
+
+__global__ void __launch_bounds__(64 * RCS_WG_WAVES) k_rcs(const RcChain* chains, u32 n_chains, RcPack* rec_pool, u32* word_pool, BlkState* st, const u32* bk, u32* redo)
+{
+	__shared__ U4 s_r[2 * RCS_RROW_U4];
+	__shared__ U4 s_l[3 * RCS_LROW_U4];
+	__shared__ U4 s_k[2 * RCS_KROW_U4];
+	__shared__ U4 s_c[2 * RCS_KROW_U4];
+	__shared__ u32 s_pos[RC_LANES];
+	__shared__ u32 s_range[64];
+	__shared__ u8 s_xb[64 * RC_XB];
+	__shared__ u32 s_rstart[2 * 64];
+	__shared__ u32 s_fix[2 * 64];
+	__shared__ u32 s_fixrow[RC_CODE_PITCH];
+	__shared__ u32 s_res[8];
+	__shared__ u8 s_rxb[RCS_RXB + 8];
+	__shared__ u32 s_owner;
+	if (threadIdx.x < 128) s_fix[threadIdx.x] = 0xFFFFFFFFu;                  // no chunk has this number
+	if (threadIdx.x == 0) s_owner = 0;
+	RcsLds S;
+	S.r = (LDS_AS U4*)s_r; S.l = (LDS_AS U4*)s_l; S.k = (LDS_AS U4*)s_k; S.c = (LDS_AS U4*)s_c; S.xb = s_xb; S.pos = (LDS_AS u32*)s_pos; S.range = (LDS_AS u32*)s_range;
+	S.rstart = (LDS_AS u32*)s_rstart; S.fix = (LDS_AS u32*)s_fix; S.fixrow = (LDS_AS u32*)s_fixrow; S.res = (LDS_AS u32*)s_res; S.rxb = s_rxb; S.owner = (LDS_AS u32*)&s_owner;
+	if (blockIdx.x * RC_LANES + RC_LANES <= n_chains) rcs_workgroup<true>(chains, n_chains, rec_pool, word_pool, st, bk, redo, S);
+	else rcs_workgroup<false>(chains, n_chains, rec_pool, word_pool, st, bk, redo, S);
+}
+
+// ---- device self-test of the split coder (dsrcgpu_selftest) --------------------------------------------------------------------------
+// Groups of 16 symbols coded three ways from the same state: RangeEncoder::EncodeFrequency verbatim (division by the hardware, the
+// clamp where it fires), wave R's steps + wave L's steps, and L's check of a group (rcs_group_clamps).  The states are made to
+// sit where the clamp lives -- bits 24..55 (or 16..47) of low all ones, a range that does or does not carry -- which no FASTQ file of
+// a test-suite ever reaches.  Counted as mismatches: a clamp the pre-condition flag did not announce, a check that disagrees with the
+// reference, bytes or state that differ in a group without a clamp.  *hits counts the groups in which the reference clamped.
+__global__ void __launch_bounds__(256) k_selftest_rcs(u32* bad, u32* hits)
+{
+	const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+	__shared__ u32 s_rk[256][RC_GROUP + 1], s_fc[256][RC_GROUP + 1];
+	u64 x = 0x9E3779B97F4A7C15ull * (tid + 1);
+	auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (u32)(x >> 21); };
+	u32 wrong = 0, clamps = 0;
+	for (u32 round = 0; round < 8; ++round)
+	{
+		// state: a normalised range, low near the clamp in one of three ways
+		u32 range0 = (rnd() | 0x01000000u);
+		u64 low0 = ((u64)rnd() << 32) | rnd();
+		const u32 kind = rnd() % 4u;
+		if (kind == 0) low0 |= 0x00FFFFFFFF000000ull;                     // first byte: a carry through bits 24..55
+		else if (kind == 1) low0 |= 0x0000FFFFFFFF0000ull;                // second byte: bits 16..47
+		else if (kind == 2) low0 |= 0x0000FFFFFF000000ull;                // the pre-condition alone
+		u32 tot[RC_GROUP], frq[RC_GROUP], cum[RC_GROUP];
+		for (u32 i = 0; i < RC_GROUP; ++i)
+		{
+			const u32 shape = rnd() % 4u;
+			tot[i] = shape == 0 ? 4u + rnd() % 60u : shape == 1 ? 65000u + rnd() % 500u : 4u + rnd() % 65000u;
+			frq[i] = shape == 3 ? 1u : 1u + rnd() % tot[i];
+			cum[i] = (i < 2 && kind < 3 && (rnd() & 1u)) ? 0u : rnd() % (tot[i] - frq[i] + 1u);       // cum = 0 keeps low where it was put
+		}
+		// the reference
+		u64 low = low0; u32 range = range0; bool clamped = false; u8 ref[3 * RC_GROUP]; u32 nref = 0;
+		for (u32 i = 0; i < RC_GROUP; ++i)
+		{
+			range /= tot[i]; low += (u64)(range * cum[i]); range *= frq[i];
+			while (range <= 0x00FFFFFFu)
+			{
+				if ((low ^ (low + range)) & 0xFF00000000000000ull) { const u32 r = (u32)low; range = (r | 0x00FFFFFFu) - r; clamped = true; }
+				if (nref < 3 * RC_GROUP) ref[nref] = (u8)(low >> 56);
+				++nref; low <<= 8; range <<= 8;
+			}
+		}
+		// R, then L
+		u32 rr = range0, flag = 0; u64 ll = low0; u8 got[3 * RC_GROUP]; u32 ngot = 0;
+		for (u32 i = 0; i < RC_GROUP; ++i)
+		{
+			const u64 m = recip48(tot[i]);
+			const u32 rk = rcs_step_r(rr, (u32)(m >> 16), (u32)m << 16, frq[i]);
+			const u32 fc = frq[i] | (cum[i] << 16);
+			s_rk[threadIdx.x][i] = rk; s_fc[threadIdx.x][i] = fc;
+			const u32 code = rcs_step_l(ll, rk, fc, flag);
+			for (u32 k = 0; k < ((code >> 3) & 3u); ++k) if (ngot < 3 * RC_GROUP) got[ngot++] = (u8)(code >> (24 - 8 * k));
+		}
+		const bool announced = (flag >> 8) == 0xFFFFFFu;
+		const bool check = rcs_chunk_clamps(low0, (const LDS_AS u32*)s_rk[threadIdx.x], (const LDS_AS u32*)s_fc[threadIdx.x], RC_GROUP);
+		if (clamped) { ++clamps; if (!announced || !check) wrong = 1; }
+		else
+		{
+			if (check) wrong = 1;
+			if (ngot != nref || ll != low || rr != range) wrong = 1;
+			for (u32 k = 0; k < ngot && k < nref; ++k) if (got[k] != ref[k]) wrong = 1;
+		}
+	}
+	if (wrong) atomicAdd(bad, 1u);
+	if (clamps) atomicAdd(hits, clamps);
+}
+
+// ... and rcs_recover (what wave L does when the clamp fires) against the reference's loop on chunks made the same way: the bytes it
+// deals out over the chunk's code slots, the state after the chunk, and the words and the range it hands on for the next chunk.
+// scratch: 1 KB per thread (two chunks of records in k_rc's layout).
+__global__ void __launch_bounds__(64) k_selftest_rcv(u32* bad, u32* hits, u8* scratch)
+{
+	const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+	__shared__ u32 s_crow[64][RC_CHUNK + 1], s_fixrow[64][RC_CHUNK + 1], s_res[64][8];
+	__shared__ u8 s_rxb[64][RCS_RXB + 8];
+	RcPack* chain = (RcPack*)(scratch + (size_t)tid * 1024u);
+	u64 x = 0xD1B54A32D192ED03ull * (tid + 1);
+	auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (u32)(x >> 21); };
+	u32 wrong = 0, clamps = 0;
+	for (u32 round = 0; round < 4; ++round)
+	{
+		const u32 range0 = rnd() | 0x01000000u;
+		u64 low0 = ((u64)rnd() << 32) | rnd();
+		const u32 kind = rnd() % 3u;
+		if (kind == 0) low0 |= 0x00FFFFFFFF000000ull; else if (kind == 1) low0 |= 0x0000FFFFFFFF0000ull;
+		const u32 n_full = round == 3 ? 48u + 16u * (rnd() % 5u) : 2 * RC_CHUNK;      // a chain that ends inside the two chunks, too
+		for (u32 i = 0; i < 2 * RC_CHUNK; ++i)
+		{
+			const u32 shape = rnd() % 4u;
+			const u32 tot = shape == 0 ? 4u + rnd() % 60u : shape == 1 ? 65000u + rnd() % 500u : 4u + rnd() % 65000u;
+			const u32 frq = shape == 3 ? 1u : 1u + rnd() % tot;
+			const u32 cum = (i < 3 && (rnd() & 1u)) ? 0u : rnd() % (tot - frq + 1u);
+			rc6_store(chain, i, frq, cum, tot);
+		}
+		// the reference over the first chunk's symbols of the chain
+		const u32 cnt = n_full < RC_CHUNK ? n_full : RC_CHUNK;
+		u64 low = low0; u32 range = range0; bool clamped = false; u8 ref[RCS_RXB]; u32 nref = 0;
+		for (u32 i = 0; i < cnt; ++i)
+		{
+			const RcPack v = rc6_load(chain, i);
+			range /= (u32)(v >> 32); low += (u64)(range * (((u32)v >> 16) & 0xFFFFu)); range *= (u32)v & 0xFFFFu;
+			while (range <= 0x00FFFFFFu)
+			{
+				if ((low ^ (low + range)) & 0xFF00000000000000ull) { const u32 r = (u32)low; range = (r | 0x00FFFFFFu) - r; clamped = true; }
+				if (nref < RCS_RXB) ref[nref] = (u8)(low >> 56);
+				++nref; low <<= 8; range <<= 8;
+			}
+		}
+		rcs_recover(chain, 0, low0, range0, n_full, (LDS_AS u32*)s_crow[threadIdx.x], (LDS_AS u32*)s_fixrow[threadIdx.x], s_rxb[threadIdx.x], (LDS_AS u32*)s_res[threadIdx.x]);
+		const u32* res = s_res[threadIdx.x];
+		if (clamped) ++clamps;
+		if (res[4] == 0)
+		{
+			if ((((u64)res[1] << 32) | res[0]) != low || res[2] != range) wrong = 1;
+			u32 ngot = 0;
+			for (u32 i = 0; i < RC_CHUNK; ++i)
+			{
+				const u32 code = s_crow[threadIdx.x][i];
+				for (u32 k = 0; k < ((code >> 3) & 3u); ++k) { if (ngot >= nref || ref[ngot] != (u8)(code >> (24 - 8 * k))) wrong = 1; ++ngot; }
+				if (i >= cnt && ((code >> 3) & 3u)) wrong = 1;                       // no bytes in the slots behind the chain's end
+			}
+			if (ngot != nref) wrong = 1;
+			u32 rr = range;
+			for (u32 i = 0; i < RC_CHUNK; ++i)
+			{
+				u32 want = 0;
+				if (RC_CHUNK + i < n_full) { const RcPack v = rc6_load(chain, RC_CHUNK + i); const u64 m = recip48((u32)(v >> 32)); want = rcs_step_r(rr, (u32)(m >> 16), (u32)m << 16, (u32)v & 0xFFFFu); }
+				if (s_fixrow[threadIdx.x][i] != want) wrong = 1;
+			}
+			if (res[3] != rr) wrong = 1;
+		}
+		else if (nref <= 3 * cnt && nref <= RCS_RXB) wrong = 1;                       // refused although the bytes fit
+	}
+	if (wrong) atomicAdd(bad, 1u);
+	if (clamps) atomicAdd(hits, clamps);
 }
 
 // ---- stream prologues ---------------------------------------------------------------------------

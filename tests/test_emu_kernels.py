@@ -259,6 +259,22 @@ def test_range_coder_reference_loop_path(emu, oracle, monkeypatch):
         assert run(emu, cfg, data) == oracle.compress_block(cfg, data)
 
 
+@pytest.mark.parametrize("hook", ["DSRC_GPU_RC_REDO", "DSRC_GPU_RC_RECOVER", "DSRC_GPU_RC_ONE_LANE"])
+def test_range_coder_redo_list_and_one_lane_kernel(emu, oracle, monkeypatch, hook):
+    """k_rcs (two waves: range, low) + the redo list coded by k_rc, and k_rc for the whole batch: same blocks (tests/test_gpu_parity.py)."""
+    monkeypatch.setenv(hook, "1")
+    data = synth.illumina_fastq(300)[:-1]
+    for d, q, lossy in [(3, 2, False), (2, 1, True)]:
+        cfg = Config.from_levels(d, q, lossy)
+        assert run(emu, cfg, data) == oracle.compress_block(cfg, data)
+    cfg = Config.from_levels(1, 1)
+    chunks = [synth.illumina_fastq(120, first=1 + 200 * k)[:-1] for k in range(5)] + [synth.illumina_fastq(3)[:-1]]
+    h = emu.Handle(cfg.dna_order, cfg.quality_order)
+    got = h.compress_batch(chunks)
+    h.close()
+    assert [g[0] for g in got] == [oracle.compress_block(cfg, c)[0] for c in chunks]
+
+
 def test_sort_ballot_variant(emu, oracle, monkeypatch):
     """k_sort has two ranking variants (LDS atomics where the device applies them in lane order, else ballots): same blocks."""
     monkeypatch.setenv("DSRC_GPU_SORT_BALLOT", "1")

@@ -125,6 +125,28 @@ def test_range_coder_reference_loop_path(gpu_hooks, oracle, monkeypatch):
         _check(gpu_hooks, oracle, Config.from_levels(d, q, lossy), chunks)
 
 
+@pytest.mark.parametrize("hook", ["DSRC_GPU_RC_REDO", "DSRC_GPU_RC_RECOVER", "DSRC_GPU_RC_ONE_LANE"])
+def test_range_coder_redo_list_and_one_lane_kernel(gpu_hooks, oracle, monkeypatch, hook):
+    """Round 6: k_rcs codes a stream on two waves (range, low); a stream in which the carry clamp fires is put on a redo list and coded
+    again by k_rc (both recurrences in one lane) after the batch's state read-back -- but first the lane tries to put things right inside
+    the kernel (rcs_recover: the chunk walked again with the reference's loop, the next chunk's words and the range handed to wave R).
+    DSRC_GPU_RC_REDO makes every stream report a clamp and go to the list (whatever k_rcs wrote for it is overwritten),
+    DSRC_GPU_RC_RECOVER forces a recovery every few chunks of every stream (lanes that meet in one period: the list),
+    DSRC_GPU_RC_ONE_LANE sends the whole batch through k_rc: same blocks."""
+    monkeypatch.setenv(hook, "1")
+    chunks = [synth.illumina_fastq(20000, first=1 + 20000 * k)[:-1] for k in range(3)] + [synth.illumina_fastq(9000, first=777777)[:-1], synth.illumina_fastq(40)[:-1]]
+    for d, q, lossy in [(3, 2, False), (2, 1, True), (1, 1, False)]:
+        _check(gpu_hooks, oracle, Config.from_levels(d, q, lossy), chunks)
+
+
+def test_split_range_coder_selftest(gpu):
+    """dsrcgpu_selftest: the two-wave coder against the reference's loop on states at the carry clamp (k_selftest_rcs), the exact
+    divisions, the LDS ordering the front end stands on."""
+    h = gpu.Handle()
+    assert h.selftest() == 0
+    h.close()
+
+
 def test_concurrent_scheduler_instances(gpu, oracle):
     """Several handles driven from several host threads at once (what bench.py does) give the same blocks as one
     handle alone: no state is shared between instances."""

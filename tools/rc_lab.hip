@@ -72,6 +72,39 @@ __device__ __forceinline__ u32 step_v5(double& range_, Rec e)
 	return (u32)r | (k8 << 27);
 }
 
+// V6: wave L's step as shipped: a = r | k8 << 27, b = freq | cum << 16
+__device__ __forceinline__ u32 step_v6(u64& low_, Rec e, u32& flag)
+{
+	const u32 r = e.a & 0x3FFFFFFFu, k8 = (e.a >> 27) & 0x18u;
+	const u64 low = low_ + (u64)r * (e.b >> 16);
+	const u32 z = __builtin_amdgcn_alignbit((u32)(low >> 32), (u32)low, 16);
+	flag = z > flag ? z : flag;
+	low_ = low << k8;
+	return ((u32)(low >> 32) & 0xFFFFFF00u) | k8;
+}
+// V7: the same with clean inputs: a = r, b = cum, c = k8
+__device__ __forceinline__ u32 step_v7(u64& low_, Rec e, u32& flag)
+{
+	const u64 low = low_ + (u64)e.a * e.b;
+	const u32 z = __builtin_amdgcn_alignbit((u32)(low >> 32), (u32)low, 16);
+	flag = z > flag ? z : flag;
+	low_ = low << e.c;
+	return ((u32)(low >> 32) & 0xFFFFFF00u) | e.c;
+}
+// V8: V7 without 64-bit instructions: 32-bit product, add with carry, the shift from alignbit + a select (c = k8)
+__device__ __forceinline__ u32 step_v8(u32& hi_, u32& lo_, Rec e, u32& flag)
+{
+	const u32 p = e.a * e.b;
+	const u32 lo = lo_ + p;
+	const u32 hi = hi_ + (lo < p ? 1u : 0u);
+	const u32 z = __builtin_amdgcn_alignbit(hi, lo, 16);
+	flag = z > flag ? z : flag;
+	const u32 sh = __builtin_amdgcn_alignbit(hi, lo, 32u - e.c);       // c = 0: shift 32 = 0 mod 32 gives lo
+	hi_ = e.c ? sh : hi;
+	lo_ = lo << e.c;
+	return (hi & 0xFFFFFF00u) | e.c;
+}
+
 template <int V> __global__ void __launch_bounds__(64) k_lab(const Rec* recs, u32 n_chunks, u64* out)
 {
 	__shared__ U4 rows[64 * ROW_U4];
@@ -105,9 +138,12 @@ template <int V> __global__ void __launch_bounds__(64) k_lab(const Rec* recs, u3
 				else if (V == 1) c[i] = step_v1(range, e);
 				else if (V == 2) c[i] = step_v2(range, e);
 				else if (V == 4) c[i] = step_v4(range, e);
+				else if (V == 6) c[i] = step_v6(low, e, flag);
+				else if (V == 7) c[i] = step_v7(low, e, flag);
+				else if (V == 8) { u32 hi = (u32)(low >> 32), lo = (u32)low; c[i] = step_v8(hi, lo, e, flag); low = ((u64)hi << 32) | lo; }
 				else c[i] = step_v5(ranged, e);
 			}
-			if (V == 0 && (flag >> 16) == 0xFFFFu) { acc ^= 1; flag = 0; }
+			if ((V == 0 || V >= 6) && (flag >> 16) == 0xFFFFu) { acc ^= 1; flag = 0; }
 #pragma unroll
 			for (u32 i = 0; i < 4; ++i) { const U4 v = {c[4 * i], c[4 * i + 1], c[4 * i + 2], c[4 * i + 3]}; codes[lane * 17 + g * 4 + i] = v; }
 		}
@@ -117,6 +153,40 @@ template <int V> __global__ void __launch_bounds__(64) k_lab(const Rec* recs, u3
 	for (u32 i = 0; i < 64; ++i) acc ^= cw[i];
 	out[lane] = low ^ range ^ acc ^ (u64)ranged;
 	if (lane == 0) { out[64] = t1 - t0; out[65] = w1 - w0; }
+}
+
+
+// ---- single instructions: a chain of dependent ones, and four independent chains (issue rate) ------------------------------------
+#define OPS_LIST(X) X(0, "v_mad_u64_u32") X(1, "v_lshlrev_b64") X(2, "v_mul_lo_u32") X(3, "v_mul_hi_u32") X(4, "v_add_u32") X(5, "v_alignbit_b32") X(6, "v_lshlrev_b32") X(7, "v_mad_u32_u24") X(8, "v_lshl_add_u64") X(9, "v_perm_b32")
+template <int OP> __device__ __forceinline__ void one_op(u64& a, u32 b, u32 c)
+{
+	if (OP == 0) a = (u64)(u32)a * b + a;
+	else if (OP == 1) a = (a << (c & 8u)) | 1u;
+	else if (OP == 2) a = (u32)a * b;
+	else if (OP == 3) a = __umulhi((u32)a, b) | 0x10000u;
+	else if (OP == 4) a = (u32)a + b;
+	else if (OP == 5) a = __builtin_amdgcn_alignbit((u32)a, b, c);
+	else if (OP == 6) a = ((u32)a << (c & 1u)) | 1u;
+	else if (OP == 7) a = __umul24((u32)a, b) + c;
+	else if (OP == 8) a = (a << 1) + (((u64)c << 32) | b);
+	else a = __builtin_amdgcn_perm((u32)a, b, c);
+}
+template <int OP, int CHAINS> __global__ void __launch_bounds__(64) k_micro(u64* out, u32 n, u32 b, u32 c)
+{
+	u64 a[CHAINS];
+	for (int k = 0; k < CHAINS; ++k) a[k] = threadIdx.x * 977u + k + 3u;
+	const u64 t0 = clock64();
+	for (u32 i = 0; i < n; ++i)
+	{
+#pragma unroll
+		for (int u = 0; u < 16; ++u)
+#pragma unroll
+			for (int k = 0; k < CHAINS; ++k) { one_op<OP>(a[k], b, c); asm volatile("" : "+v"(a[k])); }
+	}
+	const u64 t1 = clock64();
+	u64 x = 0; for (int k = 0; k < CHAINS; ++k) x ^= a[k];
+	out[threadIdx.x] = x;
+	if (threadIdx.x == 0) out[64] = t1 - t0;
 }
 
 // V3: the same range chain on the scalar unit: one chain per wave (every lane holds the same values; the compiler keeps
@@ -169,6 +239,13 @@ int main()
 		float ff = (float)freq; u32 fb; memcpy(&fb, &ff, 4);
 		r5[i] = {(u32)(b >> 32), (u32)b, fb};
 	}
+	// wave L's inputs: r and k8 as wave R would leave them
+	std::vector<Rec> r6(64 * 64), r7(64 * 64);
+	for (u32 i = 0; i < 64 * 64; ++i)
+	{
+		const u32 r = rnd() & 0x3FFFFFFFu, k8 = (rnd() % 3u) * 8u, cum = rnd() & 0xFFFFu, freq = 1 + (rnd() & 0xFFFu);
+		r6[i] = {r | (k8 << 27), freq | (cum << 16), 0}; r7[i] = {r, cum, k8};
+	}
 	Rec* d; u64* out;
 	CHECK(hipMalloc(&d, 4096 * 64 * sizeof(Rec))); CHECK(hipMalloc(&out, 8192 * 8));
 	std::vector<u64> h(8192);
@@ -188,6 +265,12 @@ int main()
 	RUN(2, r2, "V2 range alone, quotient through f64")
 	RUN(4, r1, "V4 V1 + r*freq from 24-bit multiplies")
 	RUN(5, r5, "V5 range kept in f64 (frexp / ldexp)")
+	RUN(6, r6, "V6 wave L's step (packed r | k8, freq | cum)")
+	RUN(7, r7, "V7 wave L's step, clean r, cum, k8")
+	RUN(8, r7, "V8 wave L's step, 32-bit instructions only")
+#define MICRO(OP, NAME) { for (int ch = 1; ch <= 4; ch += 3) { if (ch == 1) hipLaunchKernelGGL((k_micro<OP, 1>), dim3(1), dim3(64), 0, 0, out, 4096u, 0x9E3779B1u, 8u); else hipLaunchKernelGGL((k_micro<OP, 4>), dim3(1), dim3(64), 0, 0, out, 4096u, 0x9E3779B1u, 8u); \
+		CHECK(hipDeviceSynchronize()); CHECK(hipMemcpy(h.data(), out, 8192 * 8, hipMemcpyDeviceToHost)); printf("%-20s %d chain(s): %6.2f clk per instruction\n", NAME, ch, (double)h[64] / (4096.0 * 16 * ch)); } }
+	OPS_LIST(MICRO)
 	// scalar: 1, 2, 4, 8 waves per workgroup on one CU, then 4 waves on each of 256 workgroups
 	{
 		std::vector<Rec> big(4096 * 64);
