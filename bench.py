@@ -135,9 +135,10 @@ def cpu_baseline(write_sample, d: int, q: int):
 class Lane:
     """One scheduler instance: own handle (HIP stream + arena) and its sub-batches."""
 
-    def __init__(self, cfg, device, sub_blocks, n_sub, rank, lane_id, n_lanes, alloc_out, n_out=1, binned=False):
+    def __init__(self, cfg, device, sub_blocks, n_sub, rank, lane_id, n_lanes, alloc_out, n_out=1, binned=False, lanes=(1, 0)):
         from dsrc_amd._lib import Handle
         self.h = Handle(cfg.dna_order, cfg.quality_order, quality_offset=33, device=device)
+        self.h.set_lanes(*lanes)          # scheduler lanes inside the handle (1 = the call runs on the handle's own lane)
         self.sub = []
         recs = int(sub_blocks * RECS_PER_BLOCK * 1.02) + 1000
         cap_in = recs * 384
@@ -534,6 +535,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--blocks", type=int, default=int(os.environ.get("DSRC_BENCH_BLOCKS", "1800")), help="8 MiB chunks per step per GPU")
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DSRC_BENCH_PIPELINE", "4")), help="scheduler instances per GPU (round 4: four batches of 450 blocks: 39-40 GB/s; five of 300: 35-37)")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("DSRC_BENCH_LANES", "1")), help="scheduler lanes INSIDE every handle (dsrcgpu_set_lanes; 0 = the library's default, 1 = none)")
+    ap.add_argument("--sub-blocks", type=int, default=int(os.environ.get("DSRC_BENCH_SUB_BLOCKS", "0")), help="chunks per sub-batch of a handle's lanes (0 = the library's default, about 1 GiB)")
     ap.add_argument("--buf-mb", type=int, default=8, help="chunk size (the reference's -b; 8 = BASELINE's configurations; -m1 / -m2 of the reference's command line are 64 / 256)")
     ap.add_argument("--dna", type=int, default=3)
     ap.add_argument("--qua", type=int, default=2)
@@ -551,7 +554,7 @@ def main():
     # Every scheduler instance drives two HIP streams (front end + range coder).  The HIP runtime multiplexes streams onto
     # 4 hardware queues by default, which serialises unrelated instances behind each other's 0.25 s range-coder kernel
     # (and behind the host framework's own streams when N > 1); must be set before the runtime initialises.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(2 * max(1, args.pipeline) + 6))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(2 * max(1, args.pipeline) * (1 if args.lanes == 1 else (args.lanes or 4)) + 6))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -591,7 +594,12 @@ def main():
     # buffer per peer.  Too much: fewer resident shards first, then smaller sub-batches (a step stays `--blocks` chunks: more of them).
     def hbm_need(sb, n_res):
         chunks = sb * RECS_PER_BLOCK * 1.02 * 384
-        per_lane = chunks * 9.0 + (7.5e9 if chunks >= 2.5e9 else 1.9e9) + n_res * chunks + (2 if dist is not None else 1) * chunks / 2
+        if args.lanes == 1:
+            arena = chunks * 9.0 + (7.5e9 if chunks >= 2.5e9 else 1.9e9)
+        else:                       # lanes inside the handle: an arena per lane, sized for a sub-batch (about 1 GiB of chunks unless told otherwise)
+            sub = min(chunks, (args.sub_blocks * BUF * 1.0) if args.sub_blocks else 1.9e9)
+            arena = (args.lanes or 4) * (sub * 9.0 + 1.9e9)
+        per_lane = arena + n_res * chunks + (2 if dist is not None else 1) * chunks / 2
         return P * per_lane + (P * (world - 1) * chunks / 2 if dist is not None and rank == 0 and not host_payload else 0)
     try:
         from dsrc_amd._lib import load as _load
@@ -605,7 +613,7 @@ def main():
             args.blocks = sub_blocks * P
     except OSError:
         pass
-    lanes = [Lane(cfg, local, sub_blocks, total_steps, rank, i, P, alloc_out, n_out=2 if dist is not None else 1) for i in range(P)]
+    lanes = [Lane(cfg, local, sub_blocks, total_steps, rank, i, P, alloc_out, n_out=2 if dist is not None else 1, lanes=(args.lanes, args.sub_blocks)) for i in range(P)]
 
     if dist is not None:
         # block-to-block state across ranks (dsrc_amd/dist.py): rank r starts as if ranks 0..r-1 had compressed their chunks

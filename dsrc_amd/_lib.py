@@ -23,7 +23,7 @@ EXPORTS = [
     "dsrcgpu_decompress_block", "dsrcgpu_decompress_batch", "dsrcgpu_decompress_batch_device",
     "dsrcgpu_title_fields", "dsrcgpu_fields_capacity_after", "dsrcgpu_set_fields_capacity", "dsrcgpu_get_fields_capacity",
     "dsrcgpu_chain_seed", "dsrcgpu_last_stage_timing", "dsrcgpu_try_collect", "dsrcgpu_prepare", "dsrcgpu_set_table_budget", "dsrcgpu_device_memory", "dsrcgpu_release_memory",
-    "dsrcgpu_synth_fastq", "dsrcgpu_reserve_memory",
+    "dsrcgpu_synth_fastq", "dsrcgpu_reserve_memory", "dsrcgpu_set_lanes",
 ]
 
 
@@ -147,6 +147,10 @@ class Handle:
     def set_chain(self, chain, seq: int):
         """The next batch call on this handle is batch number `seq` of `chain` (None detaches)."""
         self._chk(self.L.dsrcgpu_set_chain(self.h, chain.c if chain is not None else None, C.c_uint64(seq)))
+
+    def set_lanes(self, lanes: int = 0, sub_batch_chunks: int = 0):
+        """Scheduler lanes inside the handle (include/dsrc_gpu.h): 0 = the defaults, lanes = 1: batches stay on the handle's own lane."""
+        self._chk(self.L.dsrcgpu_set_lanes(self.h, C.c_uint32(lanes), C.c_uint32(sub_batch_chunks)))
 
     def set_fields_capacity(self, cap: int):
         """Seed the block-to-block state of a handle that starts in the middle of an archive (see fields_capacity_fold)."""

@@ -181,6 +181,12 @@ struct dsrcgpu_handle
 	u64 dec_table_budget = 0;        // dsrcgpu_set_table_budget: HBM a decoding pass may take for model tables (0 = automatic)
 	u32* dec_tables = nullptr; u64 dec_tables_cap = 0;     // model tables of the range-decoded levels (bytes), kept between passes
 	std::vector<DecHint> verify_hints;                     // run_batch -> verify_blocks: where the DNA stream of every block it wrote lies
+	// Scheduler lanes inside the handle (round 6): a batch call is cut into sub-batches that run on `lanes` child handles (own arena,
+	// own streams, one host thread each per call), the block-to-block state going from sub-batch to sub-batch through `sub_chain`:
+	// the range coder of one sub-batch overlaps the front ends of the others without the caller holding several handles
+	std::vector<dsrcgpu_handle*> subs; dsrcgpu_chain* sub_chain = nullptr;
+	u32 lanes_want = 0, sub_chunks_want = 0;      // dsrcgpu_set_lanes: 0 = the defaults
+	bool is_sub = false;
 	u32 rc_redone = 0;               // streams coded a second time by k_rc (carry clamp under k_rcs, device hand-backs) since the handle was created
 	bool rc_caps_worst = false;      // a range-coded stream has outgrown the estimate of its staging once: two bytes per symbol from now on (run_batch)
 };
@@ -638,7 +644,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		{
 			const u32 hi = std::min(NJ, g + RC_LANES);
 			u32 mx = 0; for (u32 i = g; i < hi; ++i) mx = std::max(mx, jobs[i].n);
-			const u32 pitch = (mx + 3) / 4 * 4 + 4;
+			const u32 pitch = (mx + 3) / 4 * 4 + 48;          // (+ 48: a last chunk of k_rc's layout is 384 bytes however few records it holds)
 			if ((u64)pitch * sizeof(RcPack) >= (1ull << 32))      // k_rc: 32-bit byte offsets inside one stream's array
 				return fail(h, DSRCGPU_E_ARG, "chunk too large for the range-coder stage (a stream of %u symbols exceeds 4 GiB of records); use a smaller buffer size", mx);
 			for (u32 i = g; i < hi; ++i) { cbase[i] = trip_words + (size_t)(i - g) * pitch; cpitch[i] = pitch; }
@@ -992,7 +998,10 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		HIPCHK(hipStreamWaitEvent(h->rc_stream, h->ev[4], 0));
 		HIPCHK(hipEventRecord(h->ev[2], h->rc_stream));
 		if (rc_one_lane) hipLaunchKernelGGL(k_rc, dim3((NJ + RC_LANES - 1) / RC_LANES), dim3(64 * RC_WG_WAVES), 0, h->rc_stream, d_chains, NJ, (const u32*)nullptr, AP<RcPack>(h, 0), wpool, d_state);
-		else hipLaunchKernelGGL(k_rcs, dim3((NJ + RC_LANES - 1) / RC_LANES), dim3(64 * RCS_WG_WAVES), 0, h->rc_stream, d_chains, NJ, AP<RcPack>(h, 0), wpool, d_state, (const u32*)d_bk, d_redo);
+		// 32 streams per workgroup where the launch is large (fewer CUs under the serial waves: 61.3 against 59.1 GB/s with four instances
+		// of 900 streams), 16 where it is small and its time is what the caller waits for (76 against 101 ms per launch)
+		else if (NJ > (u32)hook_int("DSRC_GPU_RC_WIDE_FROM", 512)) hipLaunchKernelGGL(k_rcs<32>, dim3((NJ + 31) / 32), dim3(64 * RCS_WG_WAVES), 0, h->rc_stream, d_chains, NJ, AP<RcPack>(h, 0), wpool, d_state, (const u32*)d_bk, d_redo);
+		else hipLaunchKernelGGL(k_rcs<16>, dim3((NJ + 15) / 16), dim3(64 * RCS_WG_WAVES), 0, h->rc_stream, d_chains, NJ, AP<RcPack>(h, 0), wpool, d_state, (const u32*)d_bk, d_redo);
 		KCHK();
 		HIPCHK(hipEventRecord(h->ev[3], h->rc_stream));
 		HIPCHK(hipStreamWaitEvent(s, h->ev[3], 0));
@@ -1567,6 +1576,16 @@ int user_batch_begin(dsrcgpu_handle* h, std::vector<u32>& layout)
 	return DSRCGPU_OK;
 }
 
+struct LanesIO
+{
+	const u8* d_in; const uint8_t* const* host_in;            // one of the two
+	const u64* offs; const u64* sizes; u32 n;
+	u8* d_out; u8* host_out; u64 cap;                        // one of the two
+	u64* out_offs; u64* out_sizes; u64* raw; u64* comp;
+	const std::vector<u32>* layout;
+};
+u32 lanes_sub_chunks(const dsrcgpu_handle* h, u32 n, const u64* sizes, u32* lanes_out);
+int run_lanes(dsrcgpu_handle* h, const LanesIO& io, u32 sub, u32 lanes);
 int compress_batch_host(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* fastq, const uint64_t* sizes,
 						uint8_t* blocks, uint64_t blocks_cap, uint64_t* block_offs, uint64_t* block_sizes,
 						uint64_t* raw_sizes, uint64_t* comp_sizes, const std::vector<u32>& layout);
@@ -1652,6 +1671,9 @@ void dsrcgpu_destroy(dsrcgpu_handle* h)
 		h->q_thread.join();
 		if (h->q_thread2.joinable()) h->q_thread2.join();
 	}
+	for (dsrcgpu_handle* c : h->subs) dsrcgpu_destroy(c);
+	h->subs.clear();
+	if (h->sub_chain) { dsrcgpu_chain_destroy(h->sub_chain); h->sub_chain = nullptr; }
 	if (h->twin) { dsrcgpu_destroy(h->twin); h->twin = nullptr; }
 	if (h->q_chain) { dsrcgpu_chain_destroy(h->q_chain); h->q_chain = nullptr; }
 	for (QBatch& b : h->qb) { if (b.in) hipHostFree(b.in); if (b.out) hipHostFree(b.out); }
@@ -1683,6 +1705,11 @@ int dsrcgpu_compress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_f
 	std::vector<u32> layout;
 	{ const int rc = user_batch_begin(h, layout); if (rc) return rc; }
 	HIPCHK(hipSetDevice(h->device));
+	{
+		u32 lanes = 0;
+		if (const u32 sub = lanes_sub_chunks(h, n, sizes, &lanes))
+			return run_lanes(h, LanesIO{(const u8*)d_fastq, nullptr, offs, sizes, n, (u8*)d_blocks, nullptr, blocks_cap, block_offs, block_sizes, raw_sizes, comp_sizes, &layout}, sub, lanes);
+	}
 	return with_arena_retry(h, estimate_arena(h, n, sizes), [&]() {
 		BatchIO io{(const u8*)d_fastq, offs, sizes, n, (u8*)d_blocks, blocks_cap, nullptr, 0, block_offs, block_sizes, raw_sizes, comp_sizes, &layout};
 		const int rc = run_batch(h, io);
@@ -1714,6 +1741,11 @@ int compress_batch_host(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* fas
 						uint64_t* raw_sizes, uint64_t* comp_sizes, const std::vector<u32>& layout)
 {
 	HIPCHK(hipSetDevice(h->device));
+	{
+		u32 lanes = 0;
+		if (const u32 sub = lanes_sub_chunks(h, n, sizes, &lanes))
+			return run_lanes(h, LanesIO{nullptr, fastq, nullptr, sizes, n, nullptr, blocks, blocks_cap, block_offs, block_sizes, raw_sizes, comp_sizes, &layout}, sub, lanes);
+	}
 	std::vector<u64> offs(n);
 	size_t in_bytes = 0;
 	for (u32 i = 0; i < n; ++i) { offs[i] = in_bytes; in_bytes += al((size_t)sizes[i] + 16, 256); }
@@ -1728,9 +1760,141 @@ int compress_batch_host(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* fas
 		return verify_blocks(h, n, block_offs, block_sizes);
 	});
 }
+
+// ---- scheduler lanes inside one handle ----------------------------------------------------------------------------------------------
+// The reference needs ONE DsrcCompressorMT for a file; until round 5 the GPU path needed four handles (and their HBM) to hide the
+// serial range coder.  Here a batch call of n chunks is cut into K = ceil(n / sub_chunks) consecutive sub-batches; `lanes` threads take them
+// in order, each on a child handle of its own (arena sized for a sub-batch); TagStats::fields' capacity goes from sub-batch k to k + 1
+// through a chain, so the blocks are those of one handle fed in order.  A sub-batch assembles its blocks in its own arena; when every
+// earlier sub-batch has put its blocks down it copies them behind theirs (device to device, or down to the host).
+#define DSRC_LANES_DEFAULT 4
+#define DSRC_SUB_BYTES_DEFAULT ((size_t)1792 << 20)
+
+// how a batch would be cut: 0 = not at all (run_batch on the handle itself)
+u32 lanes_sub_chunks(const dsrcgpu_handle* h, u32 n, const u64* sizes, u32* lanes_out)
+{
+	if (h->is_sub || h->chain || h->arena_fixed || tl_queue_lane || h->lanes_want == 1 || n < 2) return 0;
+	size_t tot = 0; for (u32 i = 0; i < n; ++i) tot += (size_t)sizes[i];
+	u32 sub = h->sub_chunks_want;
+	if (!sub) sub = (u32)std::max<size_t>(1, DSRC_SUB_BYTES_DEFAULT / std::max<size_t>(1, tot / n));
+	const u32 K = (n + sub - 1) / sub;
+	if (K < 2) return 0;
+	sub = (n + K - 1) / K;                                    // equal sub-batches
+	*lanes_out = std::min(h->lanes_want ? h->lanes_want : (u32)DSRC_LANES_DEFAULT, (n + sub - 1) / sub);
+	return sub;
+}
+
+int run_lanes(dsrcgpu_handle* h, const LanesIO& io, u32 sub, u32 lanes)
+{
+	const u32 n = io.n;
+	// the sub-batches (equal ones: with the first of every lane of growing size, so that the lanes' front ends and range coders do not
+	// all run at once, 4 x 225 blocks went from 43.5 to 39.1 GB/s)
+	std::vector<u32> cut(1, 0);
+	while (cut.back() < n) cut.push_back(std::min(n, cut.back() + sub));
+	const u32 K = (u32)cut.size() - 1;
+	while (h->subs.size() < lanes)
+	{
+		dsrcgpu_handle* c = nullptr;
+		const int rc = dsrcgpu_create(&h->set, &h->ds, h->device, 0, &c);
+		if (rc) { const std::string why = c ? dsrcgpu_last_error(c) : "out of memory"; if (c) dsrcgpu_destroy(c); return fail(h, rc, "scheduler lane: %s", why.c_str()); }
+		c->is_sub = true; c->dec_table_budget = h->dec_table_budget;
+		h->subs.push_back(c);
+	}
+	if (!h->sub_chain && dsrcgpu_chain_create(&h->sub_chain) != DSRCGPU_OK) return fail(h, DSRCGPU_E_NOMEM, "out of memory");
+	{ std::lock_guard<std::mutex> g(h->sub_chain->m); h->sub_chain->next_seq = 0; h->sub_chain->fields_cap = h->fields_cap; h->sub_chain->failed = false; }
+	struct Shared
+	{
+		std::mutex m; std::condition_variable cv;
+		u32 next = 0, next_commit = 0; u64 base = 0;
+		int rc = DSRCGPU_OK; std::string err;
+	} sh;
+	const auto t0 = std::chrono::steady_clock::now();
+	std::vector<float> rc_ms(lanes, 0.f); std::vector<u32> rc_n(lanes, 0);
+	auto work = [&](u32 li)
+	{
+		dsrcgpu_handle* c = h->subs[li];
+		(void)hipSetDevice(h->device);
+		for (;;)
+		{
+			u32 k;
+			{ std::lock_guard<std::mutex> g(sh.m); if (sh.rc || sh.next >= K) return; k = sh.next++; }
+			const u32 lo = cut[k], hi = cut[k + 1], nk = hi - lo;
+			std::vector<u32> lay;
+			if (io.layout && !io.layout->empty()) lay.assign(io.layout->begin() + lo, io.layout->begin() + hi);
+			(void)dsrcgpu_set_chain(c, h->sub_chain, k);
+			std::vector<u64> offs_k(nk);
+			size_t in_bytes = 0;
+			if (io.host_in) for (u32 i = 0; i < nk; ++i) { offs_k[i] = in_bytes; in_bytes += al((size_t)io.sizes[lo + i] + 16, 256); }
+			int rc = with_arena_retry(c, estimate_arena(c, nk, io.sizes + lo) + in_bytes, [&]() -> int {
+				const u8* d_in = io.d_in; const u64* offs = io.offs + lo;
+				if (io.host_in)
+				{
+					const size_t o_in = c->arena.alloc(in_bytes + 256);
+					if (c->arena.failed) return fail(c, DSRCGPU_E_NOMEM, "arena exhausted (input)");
+					u8* p = c->arena.base + o_in;
+					for (u32 i = 0; i < nk; ++i) if (hipMemcpyAsync(p + offs_k[i], io.host_in[lo + i], io.sizes[lo + i], hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail(c, DSRCGPU_E_HIP, "copy of a chunk to the device failed");
+					d_in = p; offs = offs_k.data();
+				}
+				BatchIO b{d_in, offs, io.sizes + lo, nk, nullptr, 0, nullptr, ~0ull, io.out_offs + lo, io.out_sizes + lo, io.raw + 4 * (size_t)lo, io.comp + 4 * (size_t)lo, &lay};
+				const int r = run_batch(c, b);
+				if (r != DSRCGPU_OK || !c->set.verify_after_compress || !c->set.calculate_crc32) return r;
+				return verify_blocks(c, nk, io.out_offs + lo, io.out_sizes + lo);
+			});
+			u64 total = 0;
+			if (!rc) { total = io.out_offs[hi - 1] + io.out_sizes[hi - 1]; rc_ms[li] += c->rc_ms; ++rc_n[li]; }
+			// the sub-batch's blocks go behind those of the sub-batches before it
+			std::unique_lock<std::mutex> g(sh.m);
+			sh.cv.wait(g, [&] { return sh.rc || sh.next_commit == k; });
+			if (!rc && !sh.rc)
+			{
+				if (sh.base + total > io.cap) rc = fail(c, DSRCGPU_E_CAPACITY, "output needs more than %llu bytes, caller gave %llu", (unsigned long long)(sh.base + total), (unsigned long long)io.cap);
+				else
+				{
+					const u64 base = sh.base;
+					g.unlock();
+					hipError_t e = io.d_out ? hipMemcpyAsync(io.d_out + base, c->last_d_out, total, hipMemcpyDeviceToDevice, c->stream)
+											: hipMemcpyAsync(io.host_out + base, c->last_d_out, total, hipMemcpyDeviceToHost, c->stream);
+					if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+					if (e != hipSuccess) rc = fail(c, DSRCGPU_E_HIP, "copy of a sub-batch's blocks failed: %s", hipGetErrorString(e));
+					for (u32 i = lo; i < hi; ++i) io.out_offs[i] += base;
+					g.lock();
+					sh.base = base + total;
+				}
+			}
+			if (rc && !sh.rc) { sh.rc = rc; std::lock_guard<std::mutex> ge(c->err_m); sh.err = c->err; }
+			if (sh.rc)
+			{	// nobody must wait for a sub-batch that will not come
+				std::lock_guard<std::mutex> gc(h->sub_chain->m); h->sub_chain->failed = true; h->sub_chain->cv.notify_all();
+			}
+			sh.next_commit = k + 1;
+			sh.cv.notify_all();
+			if (sh.rc) return;
+		}
+	};
+	std::vector<std::thread> th;
+	for (u32 li = 1; li < lanes; ++li) th.emplace_back(work, li);
+	work(0);
+	for (std::thread& t : th) t.join();
+	if (sh.rc) return fail(h, sh.rc, "%s", sh.err.c_str());
+	{ std::lock_guard<std::mutex> g(h->sub_chain->m); h->fields_cap = h->sub_chain->fields_cap; }
+	h->batch_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	float s_ms = 0.f; u32 s_n = 0; for (u32 li = 0; li < lanes; ++li) { s_ms += rc_ms[li]; s_n += rc_n[li]; }
+	h->rc_ms = s_n ? s_ms / s_n : 0.f; h->rc_launches = K;
+	h->sort_ms = h->replay_ms = 0.f;
+	h->last_d_out = io.d_out;
+	return DSRCGPU_OK;
+}
 } // namespace
 
 extern "C" {
+
+int dsrcgpu_set_lanes(dsrcgpu_handle* h, uint32_t lanes, uint32_t sub_batch_chunks)
+{
+	if (!h) return DSRCGPU_E_ARG;
+	if (lanes > 16) return fail(h, DSRCGPU_E_ARG, "at most 16 scheduler lanes per handle");
+	h->lanes_want = lanes; h->sub_chunks_want = sub_batch_chunks;
+	return DSRCGPU_OK;
+}
 
 int dsrcgpu_decompress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_blocks, const uint64_t* offs, const uint64_t* sizes,
 									const uint64_t* text_caps, void* d_text, uint64_t text_cap, uint64_t* text_offs, uint64_t* text_sizes, uint32_t* crc_ok)
@@ -2143,6 +2307,7 @@ int dsrcgpu_release_memory(dsrcgpu_handle* h)
 	if (h->arena.base) { HIPCHK(hipFree(h->arena.base)); h->arena.base = nullptr; h->arena.cap = 0; h->arena.top = 0; }
 	if (h->dec_tables) { HIPCHK(hipFree(h->dec_tables)); h->dec_tables = nullptr; h->dec_tables_cap = 0; }
 	h->last_d_out = nullptr;
+	for (dsrcgpu_handle* c : h->subs) { const int rc = dsrcgpu_release_memory(c); if (rc) return rc; }
 	return h->twin ? dsrcgpu_release_memory(h->twin) : DSRCGPU_OK;
 }
 

@@ -1042,12 +1042,12 @@ __device__ __forceinline__ RcRec rc_unpack(RcPack v)
 // dword (freq | cum << 16) and one ushort (total) of the 384-byte chunk (rc6_chunk_off).  Requests run RC_DEPTH chunks ahead.
 #define RC_ROWS_PER_LOADER (RC_LANES / RC_LOADERS)
 struct RcFetch { u32 fc, tot; };
-struct RcRowBases { const u8* p[RC_ROWS_PER_LOADER]; };       // the arrays of a loader's rows (wave-uniform: scalar registers)
-__device__ __forceinline__ void rc_fetch(RcFetch* r, const RcRowBases& rb, u32 chunk, u32 lw, u32 n_live)
+template <int ROWS> struct RcRowBases { const u8* p[ROWS]; };       // the arrays of a loader's rows (wave-uniform: scalar registers)
+template <int ROWS> __device__ __forceinline__ void rc_fetch(RcFetch* r, const RcRowBases<ROWS>& rb, u32 chunk, u32 lw, u32 n_live)
 {
 	const u32 off = rc6_chunk_off(chunk);
 #pragma unroll
-	for (u32 k = 0; k < RC_ROWS_PER_LOADER; ++k)
+	for (u32 k = 0; k < (u32)ROWS; ++k)
 	{
 		const bool live = lw + k * RC_LOADERS < n_live;                    // n_live: constant RC_LANES in full workgroups
 		const u8* sp = rb.p[k] + off;
@@ -1093,27 +1093,27 @@ __device__ __forceinline__ void rc_chunk(RcState& s, LDS_AS u32* c, RcRegs& r0, 
 #define RC_CODE_PITCH 68
 // What a loader wave knows about its rows (wave-uniform values, taken once from the lanes of its own copy of the chains:
 // scalar registers -- nothing the byte stores need comes from memory, a load here would wait behind the record fetches in flight).
-struct RcEmitRows { GLOBAL_AS u8* out[RC_LANES / RC_LOADERS]; u32 limit[RC_LANES / RC_LOADERS], n_full[RC_LANES / RC_LOADERS], pos[RC_LANES / RC_LOADERS]; };
+template <int ROWS> struct RcEmitRows { GLOBAL_AS u8* out[ROWS]; u32 limit[ROWS], n_full[ROWS], pos[ROWS]; };
 
 // Loader wave `lw`, rows lw, lw + RC_LOADERS, ...: the 64 codes of chunk `chunk` of each row -> bytes at the row's running position
 // (lane l takes code l: scan of the byte counts, up to three byte stores).
-__device__ __forceinline__ void rc_emit_chunk(const LDS_AS u32* codes, RcEmitRows& R, u32 chunk, u32 lw, u32 n_live, u32* over)
+template <int ROWS> __device__ __forceinline__ void rc_emit_chunk(const LDS_AS u32* codes, RcEmitRows<ROWS>& R, u32 chunk, u32 lw, u32 n_live, u32* over)
 {
 	const u32 lane = lane_id();
 	const u32 t = chunk * RC_CHUNK + lane;
-	u32 v[RC_LANES / RC_LOADERS], kb[RC_LANES / RC_LOADERS], inc[RC_LANES / RC_LOADERS];
+	u32 v[ROWS], kb[ROWS], inc[ROWS];
 	// the rows' scans are independent chains of DPP steps: kept apart from the stores so that they interleave
 #pragma unroll
-	for (u32 k = 0; k < RC_LANES / RC_LOADERS; ++k)
+	for (u32 k = 0; k < (u32)ROWS; ++k)
 	{
 		const u32 j = lw + k * RC_LOADERS;
 		v[k] = codes[(j < n_live ? j : 0u) * RC_CODE_PITCH + lane];
 		kb[k] = j < n_live && t < R.n_full[k] ? (v[k] >> 3) & 3u : 0u;      // the code's low byte is 8 * bytes
 	}
 #pragma unroll
-	for (u32 k = 0; k < RC_LANES / RC_LOADERS; ++k) inc[k] = wave_incl_scan_dpp(kb[k]);
+	for (u32 k = 0; k < (u32)ROWS; ++k) inc[k] = wave_incl_scan_dpp(kb[k]);
 #pragma unroll
-	for (u32 k = 0; k < RC_LANES / RC_LOADERS; ++k)
+	for (u32 k = 0; k < (u32)ROWS; ++k)
 	{
 		const u32 total = wave_last(inc[k]);
 		const u32 at = R.pos[k] + inc[k] - kb[k];
@@ -1130,10 +1130,10 @@ __device__ __forceinline__ void rc_emit_chunk(const LDS_AS u32* codes, RcEmitRow
 }
 
 // what a loader wave takes once from the lanes of its own copy of the chains (scalar registers)
-__device__ __forceinline__ void rc_rows_setup(RcRowBases& rb, RcEmitRows& R, const RcChain& c, u32 n_full, const RcPack* rec_pool, u32* word_pool, u32 lw, u32 n_live)
+template <int ROWS> __device__ __forceinline__ void rc_rows_setup(RcRowBases<ROWS>& rb, RcEmitRows<ROWS>& R, const RcChain& c, u32 n_full, const RcPack* rec_pool, u32* word_pool, u32 lw, u32 n_live)
 {
 #pragma unroll
-	for (u32 k = 0; k < RC_ROWS_PER_LOADER; ++k)
+	for (u32 k = 0; k < (u32)ROWS; ++k)
 	{
 		const u32 j = lw + k * RC_LOADERS < n_live ? lw + k * RC_LOADERS : 0u;
 		rb.p[k] = uniform_ptr(rec_pool + __shfl(c.trip, (int)j));
@@ -1210,7 +1210,7 @@ __device__ __forceinline__ void rc_workgroup(const RcChain* chains, u32 n_chains
 	{
 		if (!wave_full) return;
 		const u32 lw = loader_id;
-		RcRowBases rb; RcEmitRows R; u32 over = 0;
+		RcRowBases<RC_ROWS_PER_LOADER> rb; RcEmitRows<RC_ROWS_PER_LOADER> R; u32 over = 0;
 		rc_rows_setup(rb, R, c, n_full, rec_pool, word_pool, lw, n_live);
 		// RC_DEPTH register sets: a chunk is requested RC_DEPTH - 1 chunk periods before it is converted -- with other instances'
 		// traffic on the memory system a load can take many microseconds, and the coder waits for the slowest of a chunk's 32
@@ -1292,9 +1292,9 @@ __global__ void __launch_bounds__(64 * RC_WG_WAVES) k_rc(const RcChain* chains, 
 // ---- k_rcs: the two recurrences on two waves ---------------------------------------------------------------------------------------
 // LDS of a workgroup: R rows (a, b, freq: 12 B per symbol) x 2, L rows (freq | cum << 16) x 3, R's words x 2, code rows x 2 -- the
 // chunk of period p is converted in period p - 1, coded by R in p, by L in p + 1 and turned into bytes in p + 2.
-#define RCS_RROW_U4 (RC_LANES * RC_ROW_U4)
-#define RCS_LROW_U4 (RC_LANES * RC_CODE_PITCH / 4)
-#define RCS_KROW_U4 ((RC_LANES + 1) * RC_CODE_PITCH / 4)      // + a row for the idle lanes of R and L to write to
+#define RCS_RROW_U4 (LANES * RC_ROW_U4)
+#define RCS_LROW_U4 (LANES * RC_CODE_PITCH / 4)
+#define RCS_KROW_U4 ((LANES + 1) * RC_CODE_PITCH / 4)      // + a row for the idle lanes of R and L to write to
 #ifndef RCS_PROBE
 #define RCS_PROBE 0                    // experiments only (wrong output): 1 no byte emission, 2 wave L idle, 4 wave R idle, 8 no conversion
 #endif
@@ -1406,13 +1406,15 @@ __device__ __attribute__((noinline)) void rcs_recover(const RcPack* chain, u32 q
 
 struct RcsLds { LDS_AS U4* r; LDS_AS U4* l; LDS_AS U4* k; LDS_AS U4* c; u8* xb; LDS_AS u32* pos; LDS_AS u32* range; LDS_AS u32* rstart; LDS_AS u32* fix; LDS_AS u32* fixrow; LDS_AS u32* res; u8* rxb; LDS_AS u32* owner; };
 
-template <bool FULL>
+template <bool FULL, int LANES>
 __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chains, RcPack* rec_pool, u32* word_pool, BlkState* st, const u32* bk, u32* redo, const RcsLds S)
 {
 	LDS_AS U4* const s_r = S.r; LDS_AS U4* const s_l = S.l; LDS_AS U4* const s_k = S.k; LDS_AS U4* const s_c = S.c;
 	u8* const s_xb = S.xb; LDS_AS u32* const s_pos = S.pos; LDS_AS u32* const s_range = S.range;
 	__builtin_amdgcn_s_setprio(3);
-	const u32 first_chain = blockIdx.x * RC_LANES;
+	constexpr int ROWS = LANES / RC_LOADERS;
+	static_assert(ROWS * RC_LOADERS == LANES, "every loader wave feeds the same number of rows");
+	const u32 first_chain = blockIdx.x * LANES;
 	const u32 lane = lane_id(), id = first_chain + lane, w = wave_id();
 	const bool loader = w >= 2;
 #if RC_SPARE_SIMD
@@ -1424,11 +1426,11 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 #else
 	const u32 loader_id = w - 2u;
 #endif
-	const bool have0 = lane < RC_LANES && (FULL || id < n_chains);
+	const bool have0 = lane < (u32)LANES && (FULL || id < n_chains);
 	const RcChain c = chains[have0 ? id : n_chains - 1];                       // idle lanes shadow a real chain's values and code nothing
 	// a stream the device handed back to k_sort / k_replay has no records yet: the redo launch codes it
 	const bool have = have0 && !(c.bk_on && bk && bk[c.jid]);
-	const u32 n_live = FULL ? (u32)RC_LANES : n_chains - first_chain;
+	const u32 n_live = FULL ? (u32)LANES : n_chains - first_chain;
 	const u32 n = have ? c.n : 0;
 	const u32 n_full = n & ~(u32)(RC_GROUP - 1);
 	const u32 wave_full = (u32)__builtin_amdgcn_readfirstlane((int)wave_max(n_full));      // same value in every wave
@@ -1438,9 +1440,9 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 	{
 		if (!wave_full) return;
 		const u32 lw = loader_id;
-		RcRowBases rb; RcEmitRows R; u32 over = 0;
+		RcRowBases<ROWS> rb; RcEmitRows<ROWS> R; u32 over = 0;
 		rc_rows_setup(rb, R, c, n_full, rec_pool, word_pool, lw, n_live);
-		RcFetch r[RCS_DEPTH][RC_ROWS_PER_LOADER];
+		RcFetch r[RCS_DEPTH][ROWS];
 #pragma unroll
 		for (u32 d = 0; d < RCS_DEPTH; ++d) rc_fetch(r[d], rb, d, lw, n_live);
 		// a chunk's R rows are in buffer (chunk & 1), its L rows in buffer (chunk % 3)
@@ -1449,7 +1451,7 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 			LDS_AS U4* rbuf = s_r + r2 * RCS_RROW_U4;
 			LDS_AS u32* lbuf = (LDS_AS u32*)(s_l + l3 * RCS_LROW_U4);
 #pragma unroll
-			for (u32 k = 0; k < RC_ROWS_PER_LOADER; ++k)
+			for (u32 k = 0; k < (u32)ROWS; ++k)
 			{
 				const u32 j = lw + k * RC_LOADERS;
 				if (j < n_live)
@@ -1482,7 +1484,7 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 			}
 		}
 #pragma unroll
-		for (u32 k = 0; k < RC_ROWS_PER_LOADER; ++k)
+		for (u32 k = 0; k < (u32)ROWS; ++k)
 			if (lw + k * RC_LOADERS < n_live && lane_id() == 0) s_pos[lw + k * RC_LOADERS] = R.pos[k] | (((over >> k) & 1u) << 31);
 		__syncthreads();                                                       // L takes the positions for the chains' tails
 		return;
@@ -1492,8 +1494,8 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 	// and cost wave L 25 of 76 clocks per symbol): every lane codes every chunk of the wave's longest chain -- past its own chain's
 	// end on whatever lies there -- and keeps the state it had at the end of its own last full group (a select per group).  Idle lanes
 	// (RC_LANES .. 63) read the last row and write to a spare one.
-	const u32 rowi = lane < RC_LANES ? lane : RC_LANES - 1;
-	const u32 rowo = lane < RC_LANES ? lane : RC_LANES;
+	const u32 rowi = lane < (u32)LANES ? lane : (u32)LANES - 1u;
+	const u32 rowo = lane < (u32)LANES ? lane : (u32)LANES;
 	if (w == 0)
 	{	// ---- wave R
 		if (!wave_full) return;
@@ -1639,13 +1641,13 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 	rc_finish(s, c, rec_pool, word_pool, st, n_full, pos, true, xb);
 }
 
-__global__ void __launch_bounds__(64 * RCS_WG_WAVES) k_rcs(const RcChain* chains, u32 n_chains, RcPack* rec_pool, u32* word_pool, BlkState* st, const u32* bk, u32* redo)
+template <int LANES> __global__ void __launch_bounds__(64 * RCS_WG_WAVES) k_rcs(const RcChain* chains, u32 n_chains, RcPack* rec_pool, u32* word_pool, BlkState* st, const u32* bk, u32* redo)
 {
 	__shared__ U4 s_r[2 * RCS_RROW_U4];
 	__shared__ U4 s_l[3 * RCS_LROW_U4];
 	__shared__ U4 s_k[2 * RCS_KROW_U4];
 	__shared__ U4 s_c[2 * RCS_KROW_U4];
-	__shared__ u32 s_pos[RC_LANES];
+	__shared__ u32 s_pos[LANES];
 	__shared__ u32 s_range[64];
 	__shared__ u8 s_xb[64 * RC_XB];
 	__shared__ u32 s_rstart[2 * 64];
@@ -1659,8 +1661,8 @@ __global__ void __launch_bounds__(64 * RCS_WG_WAVES) k_rcs(const RcChain* chains
 	RcsLds S;
 	S.r = (LDS_AS U4*)s_r; S.l = (LDS_AS U4*)s_l; S.k = (LDS_AS U4*)s_k; S.c = (LDS_AS U4*)s_c; S.xb = s_xb; S.pos = (LDS_AS u32*)s_pos; S.range = (LDS_AS u32*)s_range;
 	S.rstart = (LDS_AS u32*)s_rstart; S.fix = (LDS_AS u32*)s_fix; S.fixrow = (LDS_AS u32*)s_fixrow; S.res = (LDS_AS u32*)s_res; S.rxb = s_rxb; S.owner = (LDS_AS u32*)&s_owner;
-	if (blockIdx.x * RC_LANES + RC_LANES <= n_chains) rcs_workgroup<true>(chains, n_chains, rec_pool, word_pool, st, bk, redo, S);
-	else rcs_workgroup<false>(chains, n_chains, rec_pool, word_pool, st, bk, redo, S);
+	if (blockIdx.x * LANES + LANES <= n_chains) rcs_workgroup<true, LANES>(chains, n_chains, rec_pool, word_pool, st, bk, redo, S);
+	else rcs_workgroup<false, LANES>(chains, n_chains, rec_pool, word_pool, st, bk, redo, S);
 }
 
 // ---- device self-test of the split coder (dsrcgpu_selftest) --------------------------------------------------------------------------

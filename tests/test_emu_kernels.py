@@ -135,6 +135,63 @@ def test_chain_hands_state_between_handles(emu, oracle):
     assert alone != want[2]
 
 
+def test_short_streams_end_inside_a_chunk(emu, oracle):
+    """72 symbols per stream: the second 384-byte chunk of k_rc's record layout holds eight records and must still have its room
+    (fuzz seed 420 of tests/test_gpu_parity.py::test_field_filter found the arrays of two streams overlapping)."""
+    from tests.cases import fuzz_fastq
+    data, _ = fuzz_fastq(420, None)
+    for d, q, lossy in [(3, 2, False), (1, 1, False), (2, 2, True)]:
+        cfg = Config.from_levels(d, q, lossy)
+        assert run(emu, cfg, data) == oracle.compress_block(cfg, data)
+
+
+def _state_chunks():
+    import random
+    rng = random.Random(11)
+
+    def fq(nf, n, first):
+        recs = []
+        for i in range(n):
+            title = f"@r.{first + i}" + "".join(f":{(7 * i + k) % 90 + 10}" for k in range(nf - 2))
+            seq = "".join(rng.choice("ACGT") for _ in range(40))
+            qua = "".join(chr(33 + rng.randint(20, 40)) for _ in range(40))
+            recs.append(f"{title}\n{seq}\n+\n{qua}")
+        return "\n".join(recs).encode()
+    # field counts that make the carried capacity grow across sub-batches
+    return [fq(5, 30, 1), fq(9, 30, 100), fq(9, 30, 200), fq(17, 30, 300), fq(5, 25, 400), fq(33, 20, 500), fq(9, 30, 600)]
+
+
+@pytest.mark.parametrize("lanes,sub", [(3, 1), (2, 2), (5, 3)])
+def test_scheduler_lanes_inside_a_handle(emu, oracle, lanes, sub):
+    """dsrcgpu_set_lanes: a batch call cut into sub-batches that run on lanes inside the handle gives the blocks -- and leaves the
+    state -- of the same call on one lane (the reference's -t1 history), for host-resident and device-resident chunks."""
+    chunks = _state_chunks()
+    for d, q, lossy, crc in [(0, 0, False, False), (1, 1, False, True)]:
+        cfg = Config.from_levels(d, q, lossy, crc)
+        want = oracle.compress_blocks_state(cfg, chunks + chunks[:2])
+        h = emu.Handle(cfg.dna_order, cfg.quality_order, cfg.lossy, cfg.crc, cfg.quality_offset, verify=crc)
+        h.set_lanes(lanes, sub)
+        got = h.compress_batch(chunks)
+        assert [g[0] for g in got] == [w[0] for w in want[:len(chunks)]]
+        assert [g[1:] for g in got] == [w[1:] for w in want[:len(chunks)]]
+        # the state left behind is the one the next call starts from (here on the device-resident form)
+        blob = b"\n".join(chunks[:2])
+        offs = [0, len(chunks[0]) + 1]; sizes = [len(chunks[0]), len(chunks[1])]
+        d_in = h.dev_alloc(len(blob) + 64); h.dev_upload(d_in, blob)
+        cap = 1 << 20; d_out = h.dev_alloc(cap)
+        o_offs, o_sizes, _, _ = h.compress_batch_device(d_in, offs, sizes, d_out, cap)
+        out = h.dev_download(d_out, o_offs[-1] + o_sizes[-1])
+        assert [out[o_offs[i]: o_offs[i] + o_sizes[i]] for i in range(2)] == [w[0] for w in want[len(chunks):]]
+        # an output buffer that is too small: DSRCGPU_E_CAPACITY, and the state is where it was
+        before = h.get_fields_capacity()
+        with pytest.raises(emu.DsrcGpuError) as e:
+            h.compress_batch_device(d_in, offs, sizes, d_out, o_sizes[0] + 5)
+        assert e.value.code == -4
+        assert h.get_fields_capacity() == before
+        h.dev_free(d_in); h.dev_free(d_out)
+        h.close()
+
+
 def test_queue_form_is_asynchronous_and_ordered(emu, oracle):
     """submit / flush / collect / release: several batches flushed before anything is collected (the ring holds three), blocks
     come back in submission order with the state carried across batches, try_collect never blocks, and a ring slot is
@@ -273,6 +330,22 @@ def test_range_coder_redo_list_and_one_lane_kernel(emu, oracle, monkeypatch, hoo
     got = h.compress_batch(chunks)
     h.close()
     assert [g[0] for g in got] == [oracle.compress_block(cfg, c)[0] for c in chunks]
+
+
+def test_range_coder_wide_workgroups(emu, oracle, monkeypatch):
+    """k_rcs<32> (launches of more than 512 streams on the GPU) on the emulator's small batches: DSRC_GPU_RC_WIDE_FROM=0; with the forced
+    recoveries as well."""
+    monkeypatch.setenv("DSRC_GPU_RC_WIDE_FROM", "0")
+    cfg = Config.from_levels(3, 2)
+    chunks = [synth.illumina_fastq(150, first=1 + 200 * k)[:-1] for k in range(3)] + [synth.illumina_fastq(3)[:-1]]
+    want = [oracle.compress_block(cfg, c)[0] for c in chunks]
+    for hook in (None, "DSRC_GPU_RC_RECOVER"):
+        if hook:
+            monkeypatch.setenv(hook, "1")
+        h = emu.Handle(cfg.dna_order, cfg.quality_order)
+        got = h.compress_batch(chunks)
+        h.close()
+        assert [g[0] for g in got] == want
 
 
 def test_sort_ballot_variant(emu, oracle, monkeypatch):
