@@ -222,8 +222,8 @@ int ensure_arena(dsrcgpu_handle* h, size_t need)
 		// (profiles/r05_alloc_probe.txt: 0 ms or seconds, depending on the device's recent past).  Four instances asking at once
 		// all came back together after 3.3 s (4 x 24 GB, profiles/r05_e2e_first.txt); asking in turn lets the first one start its
 		// batch while the others' arenas are still being cleaned.
-		static std::mutex alloc_turn;
-		std::lock_guard<std::mutex> g(alloc_turn);
+		static std::mutex alloc_turn[64];                 // per device: the wipe is the device's, and several GPUs of a node do not wait for each other
+		std::lock_guard<std::mutex> g(alloc_turn[h->device & 63]);
 		const auto t0 = std::chrono::steady_clock::now();
 		e = hipMalloc((void**)&h->arena.base, want);
 		if (getenv("DSRC_GPU_DEBUG")) fprintf(stderr, "[dsrc_gpu] %p arena of %.1f GB: hipMalloc took %.0f ms\n", (void*)h, want / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -249,7 +249,8 @@ size_t estimate_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
 	const size_t sort_slice = std::min(tot * 14, slice_budget(tot) + mx * 16);       // see slice_lo in run_batch
 	// measured at -d3 -q2 (round 5: streams carved from the statistics, one byte and a sixteenth of staging per range-coded symbol):
 	// 8.6 x the input + the slice; a batch that needs more -- other data, worst-case staging -- says so and is run again
-	return tot * (h->rc_caps_worst ? 21 : 18) / 2 + (rc ? sort_slice : 0) + (size_t)n * (1u << 20) + (16u << 20);
+	const size_t copy = (h->set.tag_preserve_flags || h->ds.color_space || !h->rec_pending.empty()) ? tot + (1u << 20) : 0;      // (the device form's private copy of the text)
+	return tot * (h->rc_caps_worst ? 21 : 18) / 2 + (rc ? sort_slice : 0) + (size_t)n * (1u << 20) + (16u << 20) + copy;
 }
 size_t estimate_decode_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes, bool own_text);
 
@@ -260,6 +261,7 @@ struct BatchIO
 	u8* host_out; u64 host_cap;
 	u64* out_offs; u64* out_sizes; u64* raw; u64* comp;
 	const std::vector<u32>* layout = nullptr;     // dsrcgpu_set_record_layout of this batch (empty / null: chunks cut from a file)
+	bool in_is_callers = false;                   // d_in is the caller's device memory (dsrcgpu_compress_batch_device), not a copy in the arena
 };
 
 template <typename T> T* AP(dsrcgpu_handle* h, size_t off) { return (T*)(h->arena.base + off); }
@@ -310,8 +312,18 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		in_total += io.sizes[b];
 	}
 	const u8* d_in = io.d_in;
-
 	HIPCHK(hipEventRecord(h->ev[0], s));
+	if (io.in_is_callers && (prm.tag_flags || prm.color_space || prm.record_layout))
+	{	// k_tag_filter, k_cs_decode and k_tag_poke rewrite the chunk text in place, as BlockCompressor::Store does with its buffer -- but
+		// a batch that is run again (a larger arena, worst-case staging) must find the text as it came, and a caller's device buffer is
+		// not ours to destroy: those modes work on a copy (round 5 filtered / decoded the already-rewritten text on the second pass)
+		u64 lo = ~0ull, hi = 0;
+		for (u32 b = 0; b < B; ++b) { lo = std::min<u64>(lo, io.offs[b]); hi = std::max<u64>(hi, io.offs[b] + io.sizes[b]); }
+		const size_t o_copy = A.alloc(hi - lo + 64);
+		if (A.failed) return fail(h, DSRCGPU_E_NOMEM, "arena exhausted (copy of the input)");
+		HIPCHK(hipMemcpyAsync(AP<u8>(h, o_copy), io.d_in + lo, hi - lo, hipMemcpyDeviceToDevice, s));
+		d_in = AP<u8>(h, o_copy) - lo;
+	}
 	TraceRange tr; tr.stage("dsrc batch: line index");
 
 	// ---- phase 1: line counts ------------------------------------------------------------------
@@ -565,7 +577,9 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	// estimator, whose code length stays within (N - 1) / 2 * log2(n) bits of n * log2(N) per context: <= 7.1 bits per symbol for the
 	// alphabets here.  So: a byte and a sixteenth per symbol; k_rc never writes past a stream's limit, it reports
 	// DSRC_ERR_OUT_OVERFLOW, and the batch is then run again with the two bytes per symbol that cannot be exceeded (sticky per handle).
-	auto rc_bytes_bound = [&](u32 n) -> size_t { return h->rc_caps_worst ? (size_t)n * 2 : (size_t)n + n / 16; };
+	// (test hook DSRC_GPU_HOOK_RC_BOUND_SHIFT: the estimate divided by 2^k, so that the overflow and the second pass really happen)
+	const u32 bound_shift = (u32)hook_int("DSRC_GPU_HOOK_RC_BOUND_SHIFT", 0);
+	auto rc_bytes_bound = [&](u32 n) -> size_t { return h->rc_caps_worst ? (size_t)n * 2 : ((size_t)n + n / 16) >> bound_shift; };
 	for (u32 b = 0; b < B; ++b)
 	{
 		const BlkState& S = st[b]; BlkDesc& D = desc[b];
@@ -1134,8 +1148,10 @@ template <typename F> int with_arena_retry_(dsrcgpu_handle* h, size_t initial, F
 		// a batch that did not complete (capacity, checksum, input, memory) leaves the block-to-block state where it was: the
 		// caller may run the same batch again (grow-and-retry) and must get the blocks a fresh pass would have written
 		if (rc != DSRCGPU_OK && tl_queue_lane != 2) h->fields_cap = saved_cap;
-		if (rc != DSRCGPU_E_NOMEM || h->arena_fixed || !h->arena.failed) return rc;
+		// (a fixed arena is tried again as well -- the worst-case staging of the range coder may still fit it; ensure_arena says so if not)
+		if (rc != DSRCGPU_E_NOMEM || !h->arena.failed) return rc;
 		need = std::max(h->arena.top + h->arena.top / 8, need + need / 4);      // A.top is a lower bound of what the failed pass needed
+		if (h->arena_fixed && h->arena.top <= h->arena_fixed) need = std::min<size_t>(need, (size_t)h->arena_fixed);      // all of it, once more
 	}
 	return fail(h, DSRCGPU_E_NOMEM, "batch does not fit in HBM scratch after 8 attempts");
 }
@@ -1566,9 +1582,9 @@ int check_settings(dsrcgpu_handle* h, const dsrcgpu_settings* s, const dsrcgpu_d
 int user_batch_begin(dsrcgpu_handle* h, std::vector<u32>& layout)
 {
 	std::lock_guard<std::mutex> g(h->q_m);
+	if (h->q_started && h->q_pending) return fail(h, DSRCGPU_E_STATE, "batches of the queue form are still in flight on this handle");
 	if (h->q_chain)
 	{
-		if (h->q_pending) return fail(h, DSRCGPU_E_STATE, "batches of the queue form are still in flight on this handle");
 		h->chain = nullptr;          // the queue is drained: no lane touches the handle until the next flush
 		h->q_user_batch = true;
 	}
@@ -1711,7 +1727,7 @@ int dsrcgpu_compress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_f
 			return run_lanes(h, LanesIO{(const u8*)d_fastq, nullptr, offs, sizes, n, (u8*)d_blocks, nullptr, blocks_cap, block_offs, block_sizes, raw_sizes, comp_sizes, &layout}, sub, lanes);
 	}
 	return with_arena_retry(h, estimate_arena(h, n, sizes), [&]() {
-		BatchIO io{(const u8*)d_fastq, offs, sizes, n, (u8*)d_blocks, blocks_cap, nullptr, 0, block_offs, block_sizes, raw_sizes, comp_sizes, &layout};
+		BatchIO io{(const u8*)d_fastq, offs, sizes, n, (u8*)d_blocks, blocks_cap, nullptr, 0, block_offs, block_sizes, raw_sizes, comp_sizes, &layout, true};
 		const int rc = run_batch(h, io);
 		if (rc != DSRCGPU_OK || !h->set.verify_after_compress || !h->set.calculate_crc32) return rc;
 		return verify_blocks(h, n, block_offs, block_sizes);
@@ -1835,7 +1851,7 @@ int run_lanes(dsrcgpu_handle* h, const LanesIO& io, u32 sub, u32 lanes)
 					for (u32 i = 0; i < nk; ++i) if (hipMemcpyAsync(p + offs_k[i], io.host_in[lo + i], io.sizes[lo + i], hipMemcpyHostToDevice, c->stream) != hipSuccess) return fail(c, DSRCGPU_E_HIP, "copy of a chunk to the device failed");
 					d_in = p; offs = offs_k.data();
 				}
-				BatchIO b{d_in, offs, io.sizes + lo, nk, nullptr, 0, nullptr, ~0ull, io.out_offs + lo, io.out_sizes + lo, io.raw + 4 * (size_t)lo, io.comp + 4 * (size_t)lo, &lay};
+				BatchIO b{d_in, offs, io.sizes + lo, nk, nullptr, 0, nullptr, ~0ull, io.out_offs + lo, io.out_sizes + lo, io.raw + 4 * (size_t)lo, io.comp + 4 * (size_t)lo, &lay, io.host_in == nullptr};
 				const int r = run_batch(c, b);
 				if (r != DSRCGPU_OK || !c->set.verify_after_compress || !c->set.calculate_crc32) return r;
 				return verify_blocks(c, nk, io.out_offs + lo, io.out_sizes + lo);
@@ -2222,12 +2238,9 @@ int dsrcgpu_set_fields_capacity(dsrcgpu_handle* h, uint32_t cap)
 {
 	if (!h) return DSRCGPU_E_ARG;
 	std::lock_guard<std::mutex> g(h->q_m);
-	if (h->q_chain)
-	{	// two lanes: between flushes with the queue drained the lanes go on from this value; with batches in flight there is no
-		// point in the archive it could belong to
-		if (h->q_pending) return fail(h, DSRCGPU_E_STATE, "batches of the queue form are still in flight on this handle");
-		h->q_user_batch = true;
-	}
+	// with batches in flight (one lane or two) there is no point in the archive the value could belong to, and a lane is writing the field
+	if (h->q_started && h->q_pending) return fail(h, DSRCGPU_E_STATE, "batches of the queue form are still in flight on this handle");
+	if (h->q_chain) h->q_user_batch = true;        // two lanes: between flushes with the queue drained the lanes go on from this value
 	h->fields_cap = cap;
 	return DSRCGPU_OK;
 }

@@ -871,8 +871,21 @@ bool DsrcDecompressorGPU::Process(const InputParameters& args)
 		const uint32 wanted = perDev * (uint32)devs.size();
 		std::vector<std::pair<uint64, uint64> > batches;
 		{
-			// as few rounds of `wanted` concurrent passes as passes of <= 4800 blocks (14 GiB of archive) allow, all of one size
-			const uint64 rounds = std::max<uint64>(1, (nBlocks + (uint64)wanted * 4800 - 1) / ((uint64)wanted * 4800));
+			// as few rounds of `wanted` concurrent passes as passes of <= 4800 blocks (14 GiB of archive) allow, all of one size ...
+			// ... and as the device's memory allows.  What a pass keeps in HBM per block: the block itself, its text (the chunk it was cut
+			// from: 4 - 7 x the block on FASTQ data, taken as 8 x), the decoder's arena (3 x the block + 1 MiB) and, with an order model,
+			// its share of the table region (16 MiB).  `perDev` passes run side by side on a device and together stay below 85 % of what
+			// is free now; the table region is capped by the library as well (dsrcgpu_set_table_budget below).
+			uint64 memBlocks = 4800;
+			{
+				uint64_t freeB = 0, totalB = 0;
+				uint64 archive = 0; for (uint64 i = 0; i < nBlocks; ++i) archive += rd.BlockSizes()[i];
+				const uint64 avg = nBlocks ? archive / nBlocks + 1 : 1;
+				const uint64 perBlock = avg * (1 + 8 + 3) + (1ull << 20) + (tables ? (16ull << 20) : 0);
+				if (dsrcgpu_device_memory(devs[0], &freeB, &totalB) == DSRCGPU_OK && freeB)
+					memBlocks = std::max<uint64>(16, std::min<uint64>(4800, freeB / 100 * 85 / perDev / perBlock));
+			}
+			const uint64 rounds = std::max<uint64>(1, (nBlocks + (uint64)wanted * memBlocks - 1) / ((uint64)wanted * memBlocks));
 			const uint64 maxBlocks = args.batchBlocks ? args.batchBlocks : std::max<uint64>(1, (nBlocks + wanted * rounds - 1) / (wanted * rounds));
 			const uint64 budget = 14336ull << 20;
 			uint64 lo = 0, bytes = 0;

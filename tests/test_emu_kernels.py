@@ -348,6 +348,34 @@ def test_range_coder_wide_workgroups(emu, oracle, monkeypatch):
         assert [g[0] for g in got] == want
 
 
+def test_staging_overflow_second_pass(emu, oracle, monkeypatch):
+    """A range-coded stream that outgrows the estimate of its staging (1 1/16 bytes per symbol) is detected by the coder, never written
+    past, and the batch is run again with the two bytes per symbol that cannot be exceeded.  DSRC_GPU_HOOK_RC_BOUND_SHIFT makes the
+    estimate far too small, so that this really happens: with a field filter on the device-resident form (the kernels rewrite the
+    text: the second pass must find it as it came, and so must the caller), and with a fixed arena."""
+    import dataclasses
+    monkeypatch.setenv("DSRC_GPU_HOOK_RC_BOUND_SHIFT", "3")
+    chunks = [synth.illumina_fastq(200, first=1 + 300 * k)[:-1] for k in range(3)]
+    for flags, fixed in ((0b1010, 0), (0, 64 << 20), (0b10, 96 << 20)):
+        cfg = dataclasses.replace(Config.from_levels(2, 1), tag_flags=flags)
+        want = [oracle.compress_block(cfg, c)[0] for c in chunks]
+        h = emu.Handle(cfg.dna_order, cfg.quality_order, tag_flags=flags, arena_bytes=fixed)
+        blob = b"\n".join(chunks)
+        offs = []; at = 0
+        for c in chunks:
+            offs.append(at); at += len(c) + 1
+        d_in = h.dev_alloc(len(blob) + 64); h.dev_upload(d_in, blob)
+        cap = 1 << 20; d_out = h.dev_alloc(cap)
+        o_offs, o_sizes, _, _ = h.compress_batch_device(d_in, offs, [len(c) for c in chunks], d_out, cap)
+        out = h.dev_download(d_out, o_offs[-1] + o_sizes[-1])
+        assert [out[o_offs[i]: o_offs[i] + o_sizes[i]] for i in range(3)] == want, (flags, fixed)
+        assert h.dev_download(d_in, len(blob)) == blob                      # the caller's text is as it was
+        # the handle has learnt: the next batch takes one pass (same blocks)
+        o_offs, o_sizes, _, _ = h.compress_batch_device(d_in, offs[:1], [len(chunks[0])], d_out, cap)
+        assert h.dev_download(d_out, o_sizes[0]) == oracle.compress_block(cfg, chunks[0])[0]
+        h.dev_free(d_in); h.dev_free(d_out); h.close()
+
+
 def test_sort_ballot_variant(emu, oracle, monkeypatch):
     """k_sort has two ranking variants (LDS atomics where the device applies them in lane order, else ballots): same blocks."""
     monkeypatch.setenv("DSRC_GPU_SORT_BALLOT", "1")

@@ -139,6 +139,30 @@ def test_range_coder_redo_list_and_one_lane_kernel(gpu_hooks, oracle, monkeypatc
         _check(gpu_hooks, oracle, Config.from_levels(d, q, lossy), chunks)
 
 
+def test_staging_overflow_second_pass(gpu_hooks, oracle, monkeypatch):
+    """tests/test_emu_kernels.py::test_staging_overflow_second_pass on the GPU: the range coder's staging estimate made too small, the
+    batch run again with worst-case staging -- device-resident form with a field filter (the caller's text stays as it was) and with a
+    fixed arena."""
+    import dataclasses
+    monkeypatch.setenv("DSRC_GPU_HOOK_RC_BOUND_SHIFT", "3")
+    chunks = [synth.illumina_fastq(9000, first=1 + 9000 * k)[:-1] for k in range(3)]
+    for flags, fixed in ((0b1010, 0), (0, 1 << 30), (0b10, 1 << 30)):
+        cfg = dataclasses.replace(Config.from_levels(3, 2), tag_flags=flags)
+        want = [oracle.compress_block(cfg, c)[0] for c in chunks]
+        h = gpu_hooks.Handle(cfg.dna_order, cfg.quality_order, tag_flags=flags, arena_bytes=fixed)
+        blob = b"\n".join(chunks)
+        offs = []; at = 0
+        for c in chunks:
+            offs.append(at); at += len(c) + 1
+        d_in = h.dev_alloc(len(blob) + 64); h.dev_upload(d_in, blob)
+        cap = 16 << 20; d_out = h.dev_alloc(cap)
+        o_offs, o_sizes, _, _ = h.compress_batch_device(d_in, offs, [len(c) for c in chunks], d_out, cap)
+        out = h.dev_download(d_out, o_offs[-1] + o_sizes[-1])
+        assert [out[o_offs[i]: o_offs[i] + o_sizes[i]] for i in range(3)] == want, (flags, fixed)
+        assert h.dev_download(d_in, len(blob)) == blob
+        h.dev_free(d_in); h.dev_free(d_out); h.close()
+
+
 def test_split_range_coder_selftest(gpu):
     """dsrcgpu_selftest: the two-wave coder against the reference's loop on states at the carry clamp (k_selftest_rcs), the exact
     divisions, the LDS ordering the front end stands on."""
