@@ -250,7 +250,8 @@ size_t estimate_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes)
 	// measured at -d3 -q2 (round 5: streams carved from the statistics, one byte and a sixteenth of staging per range-coded symbol):
 	// 8.6 x the input + the slice; a batch that needs more -- other data, worst-case staging -- says so and is run again
 	const size_t copy = (h->set.tag_preserve_flags || h->ds.color_space || !h->rec_pending.empty()) ? tot + (1u << 20) : 0;      // (the device form's private copy of the text)
-	return tot * (h->rc_caps_worst ? 21 : 18) / 2 + (rc ? sort_slice : 0) + (size_t)n * (1u << 20) + (16u << 20) + copy;
+	// (round 6: 6-byte records, 7.1 x the input measured)
+	return tot * (h->rc_caps_worst ? 18 : 15) / 2 + (rc ? sort_slice : 0) + (size_t)n * (1u << 20) + (16u << 20) + copy;
 }
 size_t estimate_decode_arena(const dsrcgpu_handle* h, u32 n, const u64* sizes, bool own_text);
 
@@ -646,9 +647,8 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	const u32 NJ = (u32)jobs.size();
 	std::vector<RcChain> chains(NJ);
 	{
-		// records of one chain are contiguous: 8 bytes of address space per symbol (k_model's records; k_place leaves k_rc's six-byte
-		// chunks in the first three quarters of every time bin, k_rc.h).  The chains of a k_rc wave are one pitch apart (a multiple
-		// of 4 records: arrays stay 16-byte aligned); the loaders may read RC_OVERREAD records past the longest chain of their wave.
+		// a chain's records: its chunks of 64 six-byte records back to back (k_rc.h) -- the one per-symbol array that stays until the
+		// range coder has run.  The loaders may read RC_OVERREAD records' worth past the last chain's array.
 		// tests only (read per batch): 1 = the reference-loop check for every chunk of 64 symbols, 2 = every stream reports a carry clamp and goes to the redo list,
 		// 3 = a recovery inside k_rcs every few chunks (rcs_recover: the walk of a chunk with the reference's loop, R and L put right)
 		const u32 force_exact = hook_env("DSRC_GPU_RC_REDO") ? 2u : hook_env("DSRC_GPU_RC_RECOVER") ? 3u : hook_env("DSRC_GPU_FORCE_EXACT_RC") ? 1u : 0u;
@@ -658,12 +658,13 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		{
 			const u32 hi = std::min(NJ, g + RC_LANES);
 			u32 mx = 0; for (u32 i = g; i < hi; ++i) mx = std::max(mx, jobs[i].n);
-			const u32 pitch = (mx + 3) / 4 * 4 + 48;          // (+ 48: a last chunk of k_rc's layout is 384 bytes however few records it holds)
+			// a stream's array: its chunks of 64 records, 384 bytes each (k_rc.h), in 8-byte units
+			const u32 pitch = (mx + 63) / 64 * 48 + 4;
 			if ((u64)pitch * sizeof(RcPack) >= (1ull << 32))      // k_rc: 32-bit byte offsets inside one stream's array
 				return fail(h, DSRCGPU_E_ARG, "chunk too large for the range-coder stage (a stream of %u symbols exceeds 4 GiB of records); use a smaller buffer size", mx);
 			for (u32 i = g; i < hi; ++i) { cbase[i] = trip_words + (size_t)(i - g) * pitch; cpitch[i] = pitch; }
 			trip_words += (size_t)pitch * (hi - g);
-			if (hi == NJ) trip_words += pitch + RC_OVERREAD;               // over-read slack behind the last array
+			if (hi == NJ) trip_words += RC_OVERREAD;                       // over-read slack behind the last array (the loaders request chunks ahead)
 		}
 		const size_t o_trip = A.alloc(trip_words * sizeof(RcPack) + 256);
 		const size_t trip0 = (o_trip + 15) / 16 * 2;                 // in records, 16-byte aligned
@@ -933,7 +934,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 #undef BK_FINISH
 					KCHK();
 				}
-				if (bk_binned && slice_bins) { hipLaunchKernelGGL(k_place, dim3(slice_bins, s_hi - s_lo), dim3(PLACE_WG), 0, s, d_jobs + s_lo, AP<RcPack>(h, 0), d_bk); KCHK(); }
+				if (bk_binned && slice_bins) { hipLaunchKernelGGL(k_place, dim3(slice_bins, s_hi - s_lo), dim3(PLACE_WG), 0, s, d_jobs + s_lo, lpool, AP<RcPack>(h, 0), d_bk); KCHK(); }
 				for (const BkGroup& g : bk_groups[sl])
 				{	// the group's fallback list: here only where the host itself took a stream off the path (too short, too many tiles).  What
 					// the device hands back (k_part / k_model: a bucket too long, too many contexts) is rare and is dealt with after the batch's
@@ -1014,7 +1015,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		if (rc_one_lane) hipLaunchKernelGGL(k_rc, dim3((NJ + RC_LANES - 1) / RC_LANES), dim3(64 * RC_WG_WAVES), 0, h->rc_stream, d_chains, NJ, (const u32*)nullptr, AP<RcPack>(h, 0), wpool, d_state);
 		// 32 streams per workgroup where the launch is large (fewer CUs under the serial waves: 61.3 against 59.1 GB/s with four instances
 		// of 900 streams), 16 where it is small and its time is what the caller waits for (76 against 101 ms per launch)
-		else if (NJ > (u32)hook_int("DSRC_GPU_RC_WIDE_FROM", 512)) hipLaunchKernelGGL(k_rcs<32>, dim3((NJ + 31) / 32), dim3(64 * RCS_WG_WAVES), 0, h->rc_stream, d_chains, NJ, AP<RcPack>(h, 0), wpool, d_state, (const u32*)d_bk, d_redo);
+		else if (NJ > (u32)hook_int("DSRC_GPU_RC_WIDE_FROM", 640)) hipLaunchKernelGGL(k_rcs<32>, dim3((NJ + 31) / 32), dim3(64 * RCS_WG_WAVES), 0, h->rc_stream, d_chains, NJ, AP<RcPack>(h, 0), wpool, d_state, (const u32*)d_bk, d_redo);
 		else hipLaunchKernelGGL(k_rcs<16>, dim3((NJ + 15) / 16), dim3(64 * RCS_WG_WAVES), 0, h->rc_stream, d_chains, NJ, AP<RcPack>(h, 0), wpool, d_state, (const u32*)d_bk, d_redo);
 		KCHK();
 		HIPCHK(hipEventRecord(h->ev[3], h->rc_stream));

@@ -457,7 +457,9 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 	const u32 buckets = 1u << j.bk_hb;
 	if (!j.bk_on || bucket >= buckets || bk[j.jid]) return;
 	const u32* src = (const u32*)(pool + j.elems);
-	RcPack* recs = rec_pool + j.trip;
+	// the 8-byte records of the bucketed path go to the stream's second element buffer (only k_sort uses that one), k_place reads them
+	// there; without time bins (tests) the record goes into the stream's array of chunks at once
+	RcPack* recs = j.bk_binned ? (RcPack*)pool + j.elems_b : rec_pool + j.trip;
 	const u32 keys = 1u << j.bk_lb;
 	const bool binned = j.bk_binned != 0;
 	map_t* map = s_map[w]; u32* rows = (u32*)s_rows[w]; u16* off = s_off[w]; u16* num = s_num[w]; u8* head = s_head[w];
@@ -677,17 +679,17 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 #endif
 }
 
-// ---- k_place: a time bin's records into stream order, in place ------------------------------------------------------------------------
-// Grid: x = time bin, y = stream of the slice.  In: the bin's 8-byte records in bucket order (k_model), t mod 8192 in their top 16 bits.
-// Out: the bin's 128 chunks of k_rc's six-byte layout (k_rc.h: 64 dwords freq | cum << 16, then 64 u16 totals per chunk) over the
-// first 48 KB of the same 64 KB -- every thread holds its share of the bin before anything is written.
+// ---- k_place: a time bin's records into stream order ------------------------------------------------------------------------
+// Grid: x = time bin, y = stream of the slice.  In: the bin's 8-byte records in bucket order (k_model; in the stream's second element
+// buffer of the slice), t mod 8192 in their top 16 bits.  Out: the bin's 128 chunks of k_rc's six-byte layout (k_rc.h: 64 dwords
+// freq | cum << 16, then 64 u16 totals per chunk) in the stream's array of chunks.
 #ifndef PLACE_WG
 #define PLACE_WG 512
 #endif
 #ifndef PLACE_PASSES
 #define PLACE_PASSES 2                 // the bin's records wait in registers (16 per thread) and go through LDS half a bin at a time: 32 KB, so that a
 #endif                                 // workgroup finds room on a CU next to a k_rc workgroup and other instances' kernels (64 KB: 1.4 ms alone, 2.5 - 3 ms in the bench)
-__global__ void __launch_bounds__(PLACE_WG) k_place(const CtxJob* jobs, RcPack* rec_pool, const u32* bk)
+__global__ void __launch_bounds__(PLACE_WG) k_place(const CtxJob* jobs, const u64* pool, RcPack* rec_pool, const u32* bk)
 {
 	constexpr u32 PER = BK_BIN / PLACE_WG, HALF = BK_BIN / PLACE_PASSES;
 	__shared__ u64 s_rec[HALF];
@@ -697,7 +699,8 @@ __global__ void __launch_bounds__(PLACE_WG) k_place(const CtxJob* jobs, RcPack* 
 	const u32 t0 = bin << BK_TB;
 	if (t0 >= j.n) return;
 	const u32 cnt = j.n - t0 < BK_BIN ? j.n - t0 : BK_BIN;
-	RcPack* r = rec_pool + j.trip + t0;
+	const RcPack* r = (const RcPack*)pool + j.elems_b + t0;
+	u8* out = (u8*)(rec_pool + j.trip) + (size_t)(t0 >> 6) * RC6_CHUNK_BYTES;      // the bin's 128 chunks
 	u64 v[PER];
 #pragma unroll
 	for (u32 k = 0; k < PER; ++k) v[k] = threadIdx.x + k * PLACE_WG < cnt ? r[threadIdx.x + k * PLACE_WG] : ~0ull;      // no record: a time no pass takes
@@ -716,7 +719,7 @@ __global__ void __launch_bounds__(PLACE_WG) k_place(const CtxJob* jobs, RcPack* 
 		{
 			const u32 t = lo + i;
 			const u64 v6 = s_rec[i];
-			u8* c = (u8*)r + (t >> 6) * RC6_CHUNK_BYTES;
+			u8* c = out + (t >> 6) * RC6_CHUNK_BYTES;
 			((u32*)c)[t & 63u] = (u32)v6;
 			((u16*)(c + 256))[t & 63u] = (u16)(v6 >> 32);
 		}

@@ -28,14 +28,13 @@ typedef u64 RcPack;                      // what k_model leaves per symbol, 8 al
 
 // ---- what k_rc reads: six bytes per symbol (round 6) --------------------------------------------------------------------------
 // 64 consecutive records of a stream are one 384-byte CHUNK: 64 dwords freq | cum << 16, then 64 u16 totals -- a loader wave of
-// k_rc takes a chunk with one dword and one ushort load per lane.  128 chunks are a time bin (RC6_TB: 8192 symbols), and a bin starts
-// at a multiple of 64 KB of the stream's array (its 8 bytes of address space per symbol): k_place turns the bin's 64 KB of 8-byte
-// records into its 48 KB of chunks IN PLACE (a workgroup holds its whole bin before it writes), the bin's last 16 KB are dead after
-// it.  k_replay (and k_model without time bins) write the same layout directly.  Against 8-byte records: 2 B per symbol less
-// written by k_place, 2 B less read by k_rc (26 MB per 8 MiB block at -d3 -q2).
+// k_rc takes a chunk with one dword and one ushort load per lane.  A stream's chunks lie back to back in its array (the ONLY thing of a
+// stream that stays in HBM until the range coder has run: 40 MB per 8 MiB block at -d3 -q2, 53 MB with the 8-byte records of rounds
+// 1-5).  k_model's 8-byte records (48 bits + t mod 8192) live in the element slice, one launch group at a time; k_place puts a time
+// bin of them into stream order and writes its 128 chunks.  k_replay (and k_model without time bins) write chunks directly.
 #define RC6_TB 13
 #define RC6_CHUNK_BYTES 384u
-__device__ __forceinline__ u32 rc6_chunk_off(u32 chunk) { return ((chunk >> (RC6_TB - 6)) << (RC6_TB + 3)) + (chunk & ((1u << (RC6_TB - 6)) - 1u)) * RC6_CHUNK_BYTES; }
+__device__ __forceinline__ u32 rc6_chunk_off(u32 chunk) { return chunk * RC6_CHUNK_BYTES; }
 __device__ __forceinline__ void rc6_store(RcPack* chain, u32 t, u32 f, u32 cum, u32 tot)
 {
 	u8* p = (u8*)chain + rc6_chunk_off(t >> 6);
