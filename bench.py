@@ -314,7 +314,7 @@ def measure_decode(lanes, cfg, n_blocks, last_step, pmc, n_inst=int(os.environ.g
                          "note": "algorithmic bytes = block bytes in + text bytes out of a pass; a decoded stream is a chain of dependent model-row accesses, one 64-byte row fetched and written back per symbol (traffic: rocprofv3 FETCH_SIZE + WRITE_SIZE of every decoding kernel per block, profiles/r05_pmc_final.json), and the kernels are bound by latency x blocks in flight and instruction issue, not by bandwidth (DESIGN section 7)"}}
 
 
-def measure_queue_form(cfg, device, chunks, n_handles, batches=4, per_batch=192):
+def measure_queue_form(cfg, device, chunks, n_handles, batches=4, per_batch=192, pinned=False):
     """The form INTEGRATION.md section 1 binds in place of DsrcCompressor::Process: host-resident chunks go in through
     dsrcgpu_submit / flush, blocks come back through dsrcgpu_collect / release (reference: src/DsrcWorker.cpp:30-73).  PCIe and the
     copy into the page-locked ring are inside the figure.  One submitting and one collecting thread per handle, as the header allows."""
@@ -323,6 +323,13 @@ def measure_queue_form(cfg, device, chunks, n_handles, batches=4, per_batch=192)
     hs = [Handle(cfg.dna_order, cfg.quality_order, quality_offset=33, device=device) for _ in range(n_handles)]
     L = hs[0].L
     errs = []
+    pin = None; pin_at = []
+    if pinned:          # the chunks in page-locked memory of the caller's (what a host pipeline's reader threads fill): dsrcgpu_submit_pinned
+        from dsrc_amd._lib import host_alloc
+        pin = host_alloc(sum(len(c) + 256 for c in chunks))
+        at = 0
+        for c in chunks:
+            C.memmove(pin + at, c, len(c)); pin_at.append(at); at += (len(c) + 255) & ~255
 
     def submitter(h, nb):
         try:
@@ -331,7 +338,10 @@ def measure_queue_form(cfg, device, chunks, n_handles, batches=4, per_batch=192)
                 for _ in range(per_batch):
                     c = chunks[k % len(chunks)]; k += 1
                     while True:
-                        rc = L.dsrcgpu_submit(h.h, C.c_int64(k), c, C.c_uint64(len(c)))
+                        if pinned:
+                            rc = L.dsrcgpu_submit_pinned(h.h, C.c_int64(k), C.c_void_p(pin + pin_at[(k - 1) % len(chunks)]), C.c_uint64(len(c)))
+                        else:
+                            rc = L.dsrcgpu_submit(h.h, C.c_int64(k), c, C.c_uint64(len(c)))
                         if rc != -8:
                             break
                         time.sleep(0.0005)          # ring full: the collector is behind
@@ -367,11 +377,14 @@ def measure_queue_form(cfg, device, chunks, n_handles, batches=4, per_batch=192)
             t.join()
         return time.perf_counter() - t0
     try:
-        run(3)                                   # sizes the page-locked ring (three batches) and the arena
+        run(6)                                   # sizes the page-locked ring (the lanes + 2 batches) and the lanes' arenas
         dt = run(batches)
     finally:
         for h in hs:
             h.close()
+        if pin:
+            from dsrc_amd._lib import host_free
+            host_free(pin)
     if errs:
         raise errs[0]
     nbytes = sum(len(chunks[k % len(chunks)]) for k in range(batches * per_batch)) * n_handles
@@ -904,6 +917,9 @@ def main():
                     for nh in (1, 2):
                         mbs, nbytes, dt = measure_queue_form(cfg, ln.h.device, chunks, nh)
                         q[f"handles_{nh}"] = {"value": mbs, "unit": "MB/s", "bytes": nbytes, "s": round(dt, 2)}
+                    mbs, nbytes, dt = measure_queue_form(cfg, ln.h.device, chunks, 1, batches=8, pinned=True)
+                    q["handles_1_pinned"] = {"value": mbs, "unit": "MB/s", "bytes": nbytes, "s": round(dt, 2),
+                                             "what": "the same with dsrcgpu_submit_pinned: the chunks lie in page-locked memory of the caller's and are not copied into the ring"}
                     q["what"] = "dsrcgpu_submit / flush / collect / release with host-resident 8 MiB chunks, 192 chunks per flush, one submitting and one collecting thread per handle; host copy into the page-locked ring, PCIe both ways and the compression inside; a handle runs consecutive batches on two scheduler lanes of its own (round 4)"
                     line["queue_form"] = q
                     del chunks

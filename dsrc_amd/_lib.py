@@ -23,7 +23,7 @@ EXPORTS = [
     "dsrcgpu_decompress_block", "dsrcgpu_decompress_batch", "dsrcgpu_decompress_batch_device",
     "dsrcgpu_title_fields", "dsrcgpu_fields_capacity_after", "dsrcgpu_set_fields_capacity", "dsrcgpu_get_fields_capacity",
     "dsrcgpu_chain_seed", "dsrcgpu_last_stage_timing", "dsrcgpu_try_collect", "dsrcgpu_prepare", "dsrcgpu_set_table_budget", "dsrcgpu_device_memory", "dsrcgpu_release_memory",
-    "dsrcgpu_synth_fastq", "dsrcgpu_reserve_memory", "dsrcgpu_set_lanes",
+    "dsrcgpu_synth_fastq", "dsrcgpu_reserve_memory", "dsrcgpu_set_lanes", "dsrcgpu_submit_pinned",
 ]
 
 
@@ -87,6 +87,19 @@ def fields_capacity_fold(chunks, tag_flags: int = 0, cap: int = 0) -> int:
             e += 1
         cap = L.dsrcgpu_fields_capacity_after(cap, L.dsrcgpu_title_fields(bytes(c[:e]), e, tag_flags))
     return cap
+
+
+def host_alloc(nbytes: int) -> int:
+    """Page-locked host memory (dsrcgpu_host_alloc); free with host_free."""
+    p = C.c_void_p()
+    rc = load().dsrcgpu_host_alloc(C.c_uint64(nbytes), C.byref(p))
+    if rc:
+        raise DsrcGpuError(rc, "dsrcgpu_host_alloc failed")
+    return p.value
+
+
+def host_free(ptr: int):
+    load().dsrcgpu_host_free(C.c_void_p(ptr))
 
 
 class Chain:
@@ -220,6 +233,14 @@ class Handle:
         self._chk(self.L.dsrcgpu_compress_batch_device(self.h, n, C.c_void_p(d_in), a_offs, a_sizes, C.c_void_p(d_out),
                                                        C.c_uint64(out_cap), o_offs, o_sizes, raw, comp))
         return list(o_offs), list(o_sizes), list(raw), list(comp)
+
+    def submit_pinned(self, part_id: int, ptr: int, size: int) -> bool:
+        """dsrcgpu_submit_pinned: the chunk at `ptr` (page-locked memory from host_alloc) is read in place; False = the ring is full."""
+        rc = self.L.dsrcgpu_submit_pinned(self.h, C.c_int64(part_id), C.c_void_p(ptr), C.c_uint64(size))
+        if rc == -8:
+            return False
+        self._chk(rc)
+        return True
 
     def submit(self, part_id: int, data: bytes) -> bool:
         """False = all batches of the ring are in flight (DSRCGPU_E_BUSY): collect blocks, then submit again."""

@@ -107,6 +107,7 @@ struct QBatch
 {
 	enum State { Free, Filling, Queued, Done } state = Free;
 	std::vector<int64_t> ids; std::vector<u64> in_off, sizes;
+	std::vector<const u8*> ext;      // per chunk: the caller's page-locked memory (dsrcgpu_submit_pinned), or null = copied into `in`
 	u8* in = nullptr; u64 in_cap = 0, in_used = 0;
 	u8* out = nullptr; u64 out_cap = 0;
 	std::vector<u64> o_offs, o_sizes, raw, comp;
@@ -115,7 +116,9 @@ struct QBatch
 	uint64_t seq = 0;                // flush order: the batch's turn in the handle's internal chain (two lanes)
 	std::vector<u32> layout;         // dsrcgpu_set_record_layout at the time of the flush: it belongs to this batch, whichever lane runs it
 };
-#define DSRC_QUEUE_DEPTH 3
+#define DSRC_QUEUE_DEPTH 6                   // batches of the ring: one being filled + up to DSRC_QUEUE_LANES_MAX running / waiting
+#define DSRC_QUEUE_LANES_MAX 4
+#define DSRC_QUEUE_LANES_DEFAULT 3
 // HBM of the element slice: the streams of a batch go through k_part / k_model / k_place (or k_sort / k_replay) this many MiB of
 // elements at a time.  A stream handed back to k_sort needs two 8-byte buffers (16 B per symbol), so 1792 MiB are ~32 streams of an
 // 8 MiB chunk per launch group (rounds 1-4: 7 GiB = 128 streams, sized when every stream took that road; the bucketed path writes
@@ -160,6 +163,7 @@ struct dsrcgpu_handle
 	std::string err; mutable std::mutex err_m;   // written by whichever thread fails (caller, scheduler thread, collector): guarded
 	u8* last_d_out = nullptr;        // device address of the blocks the last run_batch assembled (valid until the arena is reused)
 	QBatch qb[DSRC_QUEUE_DEPTH]; u32 q_fill = 0, q_collect = 0;     // ring: batches are filled, run and collected in this order
+	u32 q_depth = 3;                                                 // slots of the ring in use: the lanes + 2 (decided at the first flush; 3 before)
 	u32 q_pending = 0;                                               // flushed batches that still have blocks to hand out
 	std::deque<u32> q_run;
 	std::mutex q_m; std::condition_variable q_cv;
@@ -167,7 +171,7 @@ struct dsrcgpu_handle
 	// Queue form, second lane: consecutive batches run on two scheduler lanes (this handle and `twin`, a handle of the same settings
 	// with its own arena and streams), so that the range coder of batch i -- 130 ms on a handful of CUs -- overlaps the copies and the
 	// front end of batch i + 1.  What DSRC carries from block to block goes from lane to lane through `q_chain`, in flush order.
-	dsrcgpu_handle* twin = nullptr; dsrcgpu_chain* q_chain = nullptr; std::thread q_thread2; uint64_t q_seq = 0; bool q_lanes_decided = false;
+	std::vector<dsrcgpu_handle*> twins; dsrcgpu_chain* q_chain = nullptr; std::vector<std::thread> q_threads2; uint64_t q_seq = 0; bool q_lanes_decided = false;
 	bool q_user_batch = false;       // (q_m) a batch call by the user has advanced h->fields_cap since the last flush: the next flush hands it to the lanes' chain
 	int q_rc = 0; std::string q_err;                                 // first failure of the scheduler thread (sticky)
 	float batch_ms = 0.f, rc_ms = 0.f, verify_ms = 0.f;
@@ -1686,12 +1690,13 @@ void dsrcgpu_destroy(dsrcgpu_handle* h)
 	{
 		{ std::lock_guard<std::mutex> g(h->q_m); h->q_stop = true; h->q_cv.notify_all(); }
 		h->q_thread.join();
-		if (h->q_thread2.joinable()) h->q_thread2.join();
+		for (std::thread& t : h->q_threads2) if (t.joinable()) t.join();
 	}
 	for (dsrcgpu_handle* c : h->subs) dsrcgpu_destroy(c);
 	h->subs.clear();
 	if (h->sub_chain) { dsrcgpu_chain_destroy(h->sub_chain); h->sub_chain = nullptr; }
-	if (h->twin) { dsrcgpu_destroy(h->twin); h->twin = nullptr; }
+	for (dsrcgpu_handle* t : h->twins) dsrcgpu_destroy(t);
+	h->twins.clear();
 	if (h->q_chain) { dsrcgpu_chain_destroy(h->q_chain); h->q_chain = nullptr; }
 	for (QBatch& b : h->qb) { if (b.in) hipHostFree(b.in); if (b.out) hipHostFree(b.out); }
 	if (h->arena.base) hipFree(h->arena.base);
@@ -1827,6 +1832,8 @@ int run_lanes(dsrcgpu_handle* h, const LanesIO& io, u32 sub, u32 lanes)
 	} sh;
 	const auto t0 = std::chrono::steady_clock::now();
 	std::vector<float> rc_ms(lanes, 0.f); std::vector<u32> rc_n(lanes, 0);
+	const bool verify_all = h->set.verify_after_compress && h->set.calculate_crc32 && io.d_out != nullptr;
+	std::vector<DecHint> hints(verify_all ? n : 0);
 	auto work = [&](u32 li)
 	{
 		dsrcgpu_handle* c = h->subs[li];
@@ -1854,9 +1861,13 @@ int run_lanes(dsrcgpu_handle* h, const LanesIO& io, u32 sub, u32 lanes)
 				}
 				BatchIO b{d_in, offs, io.sizes + lo, nk, nullptr, 0, nullptr, ~0ull, io.out_offs + lo, io.out_sizes + lo, io.raw + 4 * (size_t)lo, io.comp + 4 * (size_t)lo, &lay, io.host_in == nullptr};
 				const int r = run_batch(c, b);
-				if (r != DSRCGPU_OK || !c->set.verify_after_compress || !c->set.calculate_crc32) return r;
+				// -c: with device-resident output ONE verifying pass over all the call's blocks follows (below) -- a decoding pass is a chain
+				// per block and takes about as long for 2000 blocks as for 200; blocks that go down to the host are verified here, while
+				// they are still on the device
+				if (r != DSRCGPU_OK || !c->set.verify_after_compress || !c->set.calculate_crc32 || verify_all) return r;
 				return verify_blocks(c, nk, io.out_offs + lo, io.out_sizes + lo);
 			});
+			if (!rc && verify_all) std::copy(c->verify_hints.begin(), c->verify_hints.end(), hints.begin() + lo);
 			u64 total = 0;
 			if (!rc) { total = io.out_offs[hi - 1] + io.out_sizes[hi - 1]; rc_ms[li] += c->rc_ms; ++rc_n[li]; }
 			// the sub-batch's blocks go behind those of the sub-batches before it
@@ -1893,8 +1904,17 @@ int run_lanes(dsrcgpu_handle* h, const LanesIO& io, u32 sub, u32 lanes)
 	work(0);
 	for (std::thread& t : th) t.join();
 	if (sh.rc) return fail(h, sh.rc, "%s", sh.err.c_str());
+	const float compress_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	if (verify_all)
+	{	// the blocks are where the caller wanted them: decoded from there, all in one pass, on the handle's own lane
+		h->last_d_out = io.d_out; h->verify_hints.swap(hints);
+		const u32 saved = h->fields_cap;
+		const int rc = with_arena_retry_(h, estimate_decode_arena(h, n, io.out_sizes, true), [&]() { return verify_blocks(h, n, io.out_offs, io.out_sizes); });
+		h->fields_cap = saved;
+		if (rc) return rc;
+	}
 	{ std::lock_guard<std::mutex> g(h->sub_chain->m); h->fields_cap = h->sub_chain->fields_cap; }
-	h->batch_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	h->batch_ms = compress_ms;
 	float s_ms = 0.f; u32 s_n = 0; for (u32 li = 0; li < lanes; ++li) { s_ms += rc_ms[li]; s_n += rc_n[li]; }
 	h->rc_ms = s_n ? s_ms / s_n : 0.f; h->rc_launches = K;
 	h->sort_ms = h->replay_ms = 0.f;
@@ -1989,7 +2009,7 @@ int pinned_grow(u8*& p, u64& cap, u64 used, u64 need)
 // the handle's scheduler thread: runs queued batches in order through the synchronous batch entry point
 void queue_thread(dsrcgpu_handle* h, int lane)
 {
-	dsrcgpu_handle* L = lane ? h->twin : h;                   // the lane's arena, streams, error text
+	dsrcgpu_handle* L = lane ? h->twins[lane - 1] : h;         // the lane's arena, streams, error text
 	(void)hipSetDevice(h->device);
 	// (test hook, timing only: lane 0 starts late, so that the twin takes the first batches)
 	if (lane == 0) if (const long late_ms = hook_int("DSRC_GPU_HOOK_LANE0_DELAY_MS", 0)) std::this_thread::sleep_for(std::chrono::milliseconds(late_ms));
@@ -2005,9 +2025,10 @@ void queue_thread(dsrcgpu_handle* h, int lane)
 		QBatch& b = h->qb[k];
 		const u32 n = (u32)b.ids.size();
 		std::vector<const uint8_t*> ptrs(n);
-		for (u32 i = 0; i < n; ++i) ptrs[i] = b.in + b.in_off[i];
+		for (u32 i = 0; i < n; ++i) ptrs[i] = b.ext[i] ? b.ext[i] : b.in + b.in_off[i];
 		b.o_offs.assign(n, 0); b.o_sizes.assign(n, 0); b.raw.assign(4 * n, 0); b.comp.assign(4 * n, 0);
-		u64 cap = b.in_used * 2 / 5 + (u64)n * (1u << 16);       // typical ratio 0.2-0.33; the worst case once if that is short
+		u64 in_sum = 0; for (u32 i = 0; i < n; ++i) in_sum += b.sizes[i];
+		u64 cap = in_sum * 2 / 5 + (u64)n * (1u << 16);          // typical ratio 0.2-0.33; the worst case once if that is short
 		int rc = DSRCGPU_OK;
 		for (int attempt = 0; attempt < 2; ++attempt)
 		{
@@ -2018,7 +2039,7 @@ void queue_thread(dsrcgpu_handle* h, int lane)
 			rc = compress_batch_host(L, n, ptrs.data(), b.sizes.data(), b.out, b.out_cap, b.o_offs.data(), b.o_sizes.data(), b.raw.data(), b.comp.data(), b.layout);
 			tl_queue_lane = 0;
 			if (rc != DSRCGPU_E_CAPACITY) break;
-			cap = b.in_used + (u64)n * (1u << 16);
+			cap = in_sum + (u64)n * (1u << 16);
 		}
 		std::lock_guard<std::mutex> g(h->q_m);
 		if (h->q_chain && !rc)
@@ -2043,7 +2064,7 @@ int queue_collect(dsrcgpu_handle* h, bool wait, int64_t* part_id, uint8_t** bloc
 			const QBatch& c = h->qb[h->q_collect];
 			const bool spent = c.state == QBatch::Free || (c.state == QBatch::Done && !c.rc && c.next_collect == c.ids.size());
 			if (!spent) break;
-			h->q_collect = (h->q_collect + 1) % DSRC_QUEUE_DEPTH; --h->q_pending;
+			h->q_collect = (h->q_collect + 1) % h->q_depth; --h->q_pending;
 		}
 		if (!h->q_pending) return 0;                          // nothing flushed that has not been collected
 		QBatch& b = h->qb[h->q_collect];
@@ -2063,7 +2084,7 @@ int queue_collect(dsrcgpu_handle* h, bool wait, int64_t* part_id, uint8_t** bloc
 }
 } // namespace
 
-int dsrcgpu_submit(dsrcgpu_handle* h, int64_t part_id, const uint8_t* fastq, uint64_t size)
+static int queue_submit(dsrcgpu_handle* h, int64_t part_id, const uint8_t* fastq, uint64_t size, bool pinned)
 {
 	if (!h) return DSRCGPU_E_ARG;
 	if (!fastq || size == 0) return fail(h, DSRCGPU_E_ARG, "empty chunk");
@@ -2074,15 +2095,23 @@ int dsrcgpu_submit(dsrcgpu_handle* h, int64_t part_id, const uint8_t* fastq, uin
 	{	// a ring slot is free again once every block of the batch it held has been collected and released.  A caller that
 		// submits and collects on ONE thread would wait for itself here, so a full ring is reported, not waited for
 		if (b->state != QBatch::Free) return DSRCGPU_E_BUSY;
-		b->state = QBatch::Filling; b->ids.clear(); b->in_off.clear(); b->sizes.clear(); b->in_used = 0;
+		b->state = QBatch::Filling; b->ids.clear(); b->in_off.clear(); b->sizes.clear(); b->ext.clear(); b->in_used = 0;
+	}
+	if (pinned)
+	{	// the chunk stays where it is: the batch's copy to the device reads the caller's page-locked memory
+		b->ids.push_back(part_id); b->in_off.push_back(0); b->sizes.push_back(size); b->ext.push_back(fastq);
+		return DSRCGPU_OK;
 	}
 	const u64 at = (b->in_used + 255) & ~(u64)255;
 	if (pinned_grow(b->in, b->in_cap, b->in_used, at + size + 256) != DSRCGPU_OK) return fail(h, DSRCGPU_E_NOMEM, "cannot allocate page-locked staging memory");
 	g.unlock();
 	memcpy(b->in + at, fastq, size);                          // only the submitter touches a Filling batch
-	b->ids.push_back(part_id); b->in_off.push_back(at); b->sizes.push_back(size); b->in_used = at + size;
+	b->ids.push_back(part_id); b->in_off.push_back(at); b->sizes.push_back(size); b->ext.push_back(nullptr); b->in_used = at + size;
 	return DSRCGPU_OK;
 }
+
+int dsrcgpu_submit(dsrcgpu_handle* h, int64_t part_id, const uint8_t* fastq, uint64_t size) { return queue_submit(h, part_id, fastq, size, false); }
+int dsrcgpu_submit_pinned(dsrcgpu_handle* h, int64_t part_id, const uint8_t* fastq, uint64_t size) { return queue_submit(h, part_id, fastq, size, true); }
 
 int dsrcgpu_flush(dsrcgpu_handle* h)
 {
@@ -2095,18 +2124,25 @@ int dsrcgpu_flush(dsrcgpu_handle* h)
 	{	// second lane unless the caller hands the state over himself (dsrcgpu_set_chain) or DSRC_GPU_QUEUE_LANES=1
 		h->q_lanes_decided = true;
 		const bool want = !h->chain && !(getenv("DSRC_GPU_QUEUE_LANES") && atoi(getenv("DSRC_GPU_QUEUE_LANES")) <= 1);
-		if (want && dsrcgpu_chain_create(&h->q_chain) == DSRCGPU_OK)
+		u32 lanes = DSRC_QUEUE_LANES_DEFAULT;
+		if (const char* e = getenv("DSRC_GPU_QUEUE_LANES")) lanes = (u32)std::max(1, std::min(DSRC_QUEUE_LANES_MAX, atoi(e)));
+		if (want && lanes > 1 && dsrcgpu_chain_create(&h->q_chain) == DSRCGPU_OK)
 		{
-			dsrcgpu_handle* t = nullptr;
-			if (dsrcgpu_create(&h->set, &h->ds, h->device, 0, &t) == DSRCGPU_OK) { h->twin = t; (void)dsrcgpu_chain_seed(h->q_chain, h->fields_cap); h->q_user_batch = false; }
-			else { if (t) dsrcgpu_destroy(t); dsrcgpu_chain_destroy(h->q_chain); h->q_chain = nullptr; }
+			for (u32 k = 1; k < lanes; ++k)
+			{
+				dsrcgpu_handle* t = nullptr;
+				if (dsrcgpu_create(&h->set, &h->ds, h->device, 0, &t) == DSRCGPU_OK) { t->is_sub = true; h->twins.push_back(t); }
+				else { if (t) dsrcgpu_destroy(t); break; }
+			}
+			if (!h->twins.empty()) { (void)dsrcgpu_chain_seed(h->q_chain, h->fields_cap); h->q_user_batch = false; h->q_depth = std::min<u32>(DSRC_QUEUE_DEPTH, (u32)h->twins.size() + 3); }
+			else { dsrcgpu_chain_destroy(h->q_chain); h->q_chain = nullptr; }
 		}
 	}
 	if (!h->q_started)
 	{
 		h->q_started = true;
 		h->q_thread = std::thread(queue_thread, h, 0);
-		if (h->twin) h->q_thread2 = std::thread(queue_thread, h, 1);
+		for (u32 k = 0; k < h->twins.size(); ++k) h->q_threads2.emplace_back(queue_thread, h, (int)k + 1);
 	}
 	if (h->q_chain && h->q_user_batch)
 	{	// the user made batch calls on the handle since the last flush (only possible with the queue drained, and noted by those calls
@@ -2119,7 +2155,7 @@ int dsrcgpu_flush(dsrcgpu_handle* h)
 	b.layout.swap(h->rec_pending); h->rec_pending.clear();
 	b.state = QBatch::Queued; ++h->q_pending;
 	h->q_run.push_back(h->q_fill);
-	h->q_fill = (h->q_fill + 1) % DSRC_QUEUE_DEPTH;
+	h->q_fill = (h->q_fill + 1) % h->q_depth;
 	h->q_cv.notify_all();
 	return DSRCGPU_OK;
 }
@@ -2322,7 +2358,8 @@ int dsrcgpu_release_memory(dsrcgpu_handle* h)
 	if (h->dec_tables) { HIPCHK(hipFree(h->dec_tables)); h->dec_tables = nullptr; h->dec_tables_cap = 0; }
 	h->last_d_out = nullptr;
 	for (dsrcgpu_handle* c : h->subs) { const int rc = dsrcgpu_release_memory(c); if (rc) return rc; }
-	return h->twin ? dsrcgpu_release_memory(h->twin) : DSRCGPU_OK;
+	for (dsrcgpu_handle* t : h->twins) { const int rc = dsrcgpu_release_memory(t); if (rc) return rc; }
+	return DSRCGPU_OK;
 }
 
 int dsrcgpu_reserve_memory(dsrcgpu_handle* h, uint64_t arena_bytes, uint64_t table_bytes)

@@ -133,8 +133,9 @@ int dsrcgpu_decompress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d
  *   fastqQueue.Pop(partId, chunk)            -> dsrcgpu_submit(partId, chunk)      (bytes are copied into page-locked staging)
  *   ... Store ... dsrcQueue.Push(partId, blk) -> dsrcgpu_collect(&partId, &blk, ...)
  *   dsrcPool.Release(blk)                    -> dsrcgpu_release(blk)
- * Asynchronous: dsrcgpu_flush hands everything submitted since the last flush to the handle's scheduler thread as one
- * batch and returns; up to two batches run / wait while a third is being filled.  When all three are busy
+ * Asynchronous: dsrcgpu_flush hands everything submitted since the last flush to the handle's scheduler lanes as one
+ * batch and returns; the ring holds as many batches as the handle has scheduler lanes, plus two: one being filled, the others running,
+ * waiting or being collected.  When all are busy
  * dsrcgpu_submit returns DSRCGPU_E_BUSY without copying anything (it does not wait: the caller may be the thread that has
  * to collect): take blocks with dsrcgpu_collect, release them, submit again -- a slot is free once every block of the
  * oldest batch has been released.  Blocks come back in submission order:
@@ -143,15 +144,20 @@ int dsrcgpu_decompress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d
  * collected; dsrcgpu_try_collect never waits (0 = nothing ready right now).  A batch that failed makes the next call
  * return its error.  One submitter thread and one collector thread may use a handle concurrently; the batch calls above
  * must not be mixed in while batches are in flight.  Block-to-block state follows submission order (`dsrc c -t1`).
- * Since round 4 the two batches that run at a time run on TWO scheduler lanes inside the handle -- the handle and a twin with its own
- * arena and streams, created at the first flush -- so that the range coder of one batch (0.13 s on a few CUs, whatever the batch's
- * size) overlaps the copies and the front end of the next; the block-to-block state goes from lane to lane in flush order through an
- * internal chain.  One handle: 7.4 -> 11.9 GB/s with host-resident chunks of 8 MiB, 192 per flush.  The second lane doubles the
- * handle's HBM; it is left out when the caller has given the handle a chain of his own (dsrcgpu_set_chain) or with
+ * The batches that run at a time run on scheduler lanes inside the handle (round 4: two, round 6: DSRC_GPU_QUEUE_LANES, default 3,
+ * at most 4) -- the handle and twins with their own arenas and streams, created at the first flush -- so that the range coder of one
+ * batch (~0.08 s on a few CUs, whatever the batch's size) overlaps the copies and the front ends of the next ones; the block-to-block
+ * state goes from lane to lane in flush order through an internal chain.  Every lane adds an arena (about 7.5 x a batch's chunks + 1.75
+ * GiB) to the handle's HBM; the twins are left out when the caller has given the handle a chain of his own (dsrcgpu_set_chain) or with
  * DSRC_GPU_QUEUE_LANES=1.  dsrcgpu_set_fields_capacity counts before the first flush and between flushes once the queue has drained
  * (DSRCGPU_E_STATE while batches are in flight); dsrcgpu_set_record_layout belongs to whichever comes first, the next flush or the
  * next batch call, and travels with that batch: it may be set for the next flush while earlier batches are still running. */
 int dsrcgpu_submit(dsrcgpu_handle* h, int64_t part_id, const uint8_t* fastq, uint64_t size);
+/* The same without the copy (round 6): `fastq` is page-locked memory of the caller's (dsrcgpu_host_alloc) and stays as it is until
+ * every block of its batch has been collected -- the batch's copy to the device reads it in place.  A submitter that copies 8 MiB chunks
+ * into the ring moves ~10 GB/s; the reader threads of a host pipeline can fill page-locked buffers directly instead.  Both forms
+ * may be mixed in one batch. */
+int dsrcgpu_submit_pinned(dsrcgpu_handle* h, int64_t part_id, const uint8_t* fastq, uint64_t size);
 int dsrcgpu_flush(dsrcgpu_handle* h);
 int dsrcgpu_collect(dsrcgpu_handle* h, int64_t* part_id, uint8_t** block, uint64_t* block_size,
 					uint64_t raw_sizes[4], uint64_t comp_sizes[4]);

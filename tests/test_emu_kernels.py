@@ -193,35 +193,48 @@ def test_scheduler_lanes_inside_a_handle(emu, oracle, lanes, sub):
 
 
 def test_queue_form_is_asynchronous_and_ordered(emu, oracle):
-    """submit / flush / collect / release: several batches flushed before anything is collected (the ring holds three), blocks
+    """submit / flush / collect / release: several batches flushed before anything is collected (the ring holds the lanes + 2), blocks
     come back in submission order with the state carried across batches, try_collect never blocks, and a ring slot is
-    reused only after its blocks were released."""
+    reused only after its blocks were released.  Every other chunk goes in through dsrcgpu_submit_pinned: read where it lies."""
     import ctypes as C
-    chunks = [synth.illumina_fastq(30, first=1 + 30 * k)[:-1] for k in range(7)]
+    chunks = [synth.illumina_fastq(30, first=1 + 30 * k)[:-1] for k in range(10)]
     cfg = Config.from_levels(0, 1)
     want = oracle.compress_blocks_state(cfg, chunks)
     h = emu.Handle(cfg.dna_order, cfg.quality_order)
     assert h.collect(wait=False) is None
-    for lo, hi in ((0, 2), (2, 3), (3, 5)):                     # three batches in flight
+    pinned = emu.host_alloc(sum(len(c) for c in chunks) + 4096)
+    at = 0
+
+    def put(i):
+        nonlocal at
+        if i % 2:
+            return h.submit(100 + i, chunks[i])
+        C.memmove(pinned + at, chunks[i], len(chunks[i]))
+        ok = h.submit_pinned(100 + i, pinned + at, len(chunks[i]))
+        if ok:
+            at += len(chunks[i]) + 64
+        return ok
+    for lo, hi in ((0, 2), (2, 4), (4, 5), (5, 7), (7, 8)):           # five batches in flight: three lanes + 2
         for i in range(lo, hi):
-            assert h.submit(100 + i, chunks[i])
+            assert put(i)
         h.flush()
-    assert h.submit(105, chunks[5]) is False                    # ring full: reported, not waited for (the caller is the collector)
+    assert put(8) is False                                      # ring full: reported, not waited for (the caller is the collector)
     got = []
     while True:
         r = h.collect()
         if r is None:
             break
         got.append(r)
-    for i in (5, 6):                                            # the ring slots are free again: a fourth and fifth batch
-        assert h.submit(100 + i, chunks[i]); h.flush()
+    for i in (8, 9):                                            # the ring slots are free again
+        assert put(i); h.flush()
     while True:
         r = h.collect()
         if r is None:
             break
         got.append(r)
     h.close()
-    assert [g[0] for g in got] == [100 + i for i in range(7)]
+    emu.host_free(pinned)
+    assert [g[0] for g in got] == [100 + i for i in range(10)]
     assert [(g[1], g[2], g[3]) for g in got] == want
 
 

@@ -30,7 +30,10 @@ def main():
         chunks.append(text[pos:end - 1]); pos = end
     for nh in (1, 2):
         r = bench.measure_queue_form(cfg, 0, chunks, nh, batches=batches, per_batch=per_batch)
-        print(f"{nh} handle(s), {per_batch} chunks per flush: {r}")
+        print(f"{nh} handle(s), {per_batch} chunks per flush: {r}", flush=True)
+    for pb in (per_batch, 96):
+        r = bench.measure_queue_form(cfg, 0, chunks, 1, batches=batches * 2, per_batch=pb, pinned=True)
+        print(f"1 handle, dsrcgpu_submit_pinned, {pb} chunks per flush: {r}", flush=True)
 
 
 if __name__ == "__main__":
