@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 BUF = 8 << 20                     # -b8 (reference default, src/Common.h:156)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 RECS_PER_BLOCK = 22300
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_final.json")   # written by tools/r05_pmc.sh from rocprofv3 --pmc passes of the library it names
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_final.json")   # written by tools/r06_pmc.sh from rocprofv3 --pmc passes of the library it names
 MAX_RESIDENT = 3                  # distinct input shards kept in HBM per scheduler instance (2 when N > 1: rank 0 also holds the gathered streams)
 MAX_RESIDENT_BOX = [MAX_RESIDENT]   # ... lowered by main() when the device has less free HBM than the run would take
 
@@ -57,7 +57,7 @@ def load_pmc():
     except (OSError, ValueError):
         return None, f"{os.path.relpath(PMC_FILE, ROOT)} missing"
     if pmc.get("csrc_sha") != csrc_sha():
-        return None, f"{os.path.relpath(PMC_FILE, ROOT)} is stale (measured on kernel sources {pmc.get('csrc_sha')}, commit {pmc.get('commit')}; these are {csrc_sha()}): run tools/r05_pmc.sh"
+        return None, f"{os.path.relpath(PMC_FILE, ROOT)} is stale (measured on kernel sources {pmc.get('csrc_sha')}, commit {pmc.get('commit')}; these are {csrc_sha()}): run tools/r06_pmc.sh"
     return pmc, f"{os.path.relpath(PMC_FILE, ROOT)} (commit {pmc.get('commit')})"
 
 
@@ -311,7 +311,7 @@ def measure_decode(lanes, cfg, n_blocks, last_step, pmc, n_inst=int(os.environ.g
                          "achieved": round(alg / dt / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(alg / dt / 1e9 / HBM_PEAK_GBS, 6), "pass_ms": round(pass_ms, 1), "launch_bytes": int(text_bytes + sum(szs)),
                          "traffic": int(pmc["decode"]["bytes_per_block"] * n_blocks) if pmc and pmc.get("decode") and cfg.dna_order == 9 and cfg.quality_order == 2 else None,
-                         "note": "algorithmic bytes = block bytes in + text bytes out of a pass; a decoded stream is a chain of dependent model-row accesses, one 64-byte row fetched and written back per symbol (traffic: rocprofv3 FETCH_SIZE + WRITE_SIZE of every decoding kernel per block, profiles/r05_pmc_final.json), and the kernels are bound by latency x blocks in flight and instruction issue, not by bandwidth (DESIGN section 7)"}}
+                         "note": "algorithmic bytes = block bytes in + text bytes out of a pass; a decoded stream is a chain of dependent model-row accesses, one 64-byte row fetched and written back per symbol (traffic: rocprofv3 FETCH_SIZE + WRITE_SIZE of every decoding kernel per block, profiles/r06_pmc_final.json), and the kernels are bound by latency x blocks in flight and instruction issue, not by bandwidth (DESIGN section 7)"}}
 
 
 def measure_queue_form(cfg, device, chunks, n_handles, batches=4, per_batch=192, pinned=False):
@@ -850,7 +850,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          # L2<->fabric bytes of one k_rc launch: FETCH_SIZE x 2 (gfx950 counts 16 B/lane streaming reads at half) + WRITE_SIZE,
-                         # separate rocprofv3 --pmc passes of a 512-block batch (profiles/r05_pmc_final.json; null when that file is not of this library)
+                         # separate rocprofv3 --pmc passes of a 512-block batch (profiles/r06_pmc_final.json; null when that file is not of this library)
                          "traffic": int(pc["k_rc_bytes_per_block"] * sub_blocks) if pc else None,
                          "kernel": "k_rc (range-coder arithmetic, one lane per stream; its loader waves turn the per-symbol codes into the stream bytes)",
                          "kernel_ms": round(rc_ms, 2), "launch_bytes": int(alg), "batch_ms": round(batch_ms, 2),

@@ -437,8 +437,19 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 // then 0.35/d < 1): trunc(p) == floor(Q).  The quotient is exact only for powers of two.
 __device__ __forceinline__ u64 recip48(u32 d)
 {
-	const double inv = (1.0 / (double)d) * (1.0 + 0x1p-50);
-	const double p = inv * 0x1p48;
+	// 1 / d from the hardware's estimate and two Newton steps (relative error <= 2^-52 either way; the factor 1 + 2^-50 then puts the
+	// result at or above 1 / d, by less than 2^-49 of it: floor(p) = floor(2^48 / d) for every d <= 2^16, k_selftest tries them all on
+	// the device).  The IEEE division -- v_div_scale x 2, v_rcp, 6 fma, v_div_fmas, v_div_fixup -- was a third of a loader wave's
+	// f64 instructions in k_rcs, and those waves are what its period waits for with 32 streams per workgroup.
+#ifdef DSRC_EMU_BUILD
+	const double y = 1.0 / (double)d;
+#else
+	const double x = (double)d;
+	double y = __builtin_amdgcn_rcp(x);
+	y = __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+	y = __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+#endif
+	const double p = y * ((1.0 + 0x1p-50) * 0x1p48);
 	const u32 hi = (u32)(p * 0x1p-32);                         // p < 2^47: hi < 2^15
 	const u32 lo = (u32)(p - (double)hi * 0x1p32);             // the subtraction is exact (p < 2^47 keeps >= 6 fraction bits); the cast truncates
 	const u64 q = ((u64)hi << 32) | lo;
