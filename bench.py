@@ -441,6 +441,42 @@ def measure_verify(cfg, ln, n_inst, blocks=None):
     return round(sum(done) / dt / 1e6, 1), blocks or len(ln.shard(0)[1])
 
 
+def measure_one_handle(cfg, device, blocks, lanes=4, steps=3):
+    """What ONE handle does by itself (task 2): the step of the headline -- `blocks` consecutive chunks, device-resident
+    -- as one dsrcgpu_compress_batch_device call on one handle, the scheduler lanes inside it (dsrcgpu_set_lanes: the library's default
+    sub-batches of about 1.75 GiB).  HBM: what the device has less free while the call's lanes hold their arenas (inputs and output
+    buffer not counted).  The last block of the last call is compared with the oracle."""
+    import ctypes as C
+    from dsrc_amd._lib import load
+
+    def alloc_out(h, cap):
+        return h.dev_alloc(cap), None
+    L = load()
+
+    def free_hbm():
+        fr = C.c_uint64(); tot = C.c_uint64()
+        return fr.value if L.dsrcgpu_device_memory(device, C.byref(fr), C.byref(tot)) == 0 else 0
+    ln = Lane(cfg, device, blocks, steps + 1, 0, 0, 1, alloc_out, lanes=(lanes, 0))
+    try:
+        before = free_hbm()
+        ln.run(0)                                          # arenas of the lanes
+        held = before - free_hbm()
+        t0 = time.perf_counter()
+        for s_ in range(1, steps + 1):
+            ln.run(s_)
+        wall = time.perf_counter() - t0
+        in_bytes = sum(sum(ln.shard(s_)[2]) + len(ln.shard(s_)[2]) for s_ in range(1, steps + 1))
+        from tests._oracle import Oracle
+        d_in, starts, sizes = ln.shard(steps); o_offs, o_sizes, _, _ = ln.results[steps]
+        i = len(starts) - 1
+        assert ln.h.dev_download(ln.outs[0][0] + o_offs[i], o_sizes[i]) == Oracle().compress_block(cfg, ln.h.dev_download(d_in + starts[i], sizes[i]))[0], "bench parity check failed (one handle, lanes inside)"
+        return {"value": round(in_bytes / wall / 1e6, 1), "unit": "MB/s", "blocks_per_call": blocks, "lanes": lanes, "calls": steps, "ms_per_call": round(wall / steps * 1e3, 1),
+                "hbm_held_GB": round(held / 1e9, 1), "k_rc_ms": round(sum(t[1] for t in ln.timing[1:]) / max(1, len(ln.timing) - 1), 1), "parity_checked_blocks": 1,
+                "what": "ONE handle, one dsrcgpu_compress_batch_device call per step of the headline's size, inputs and outputs in HBM: the call is cut into sub-batches (~1.75 GiB of chunks) that run on scheduler lanes inside the handle, the block-to-block state handed from one to the next (include/dsrc_gpu.h dsrcgpu_set_lanes)"}
+    finally:
+        ln.free()
+
+
 def measure_binned(cfg, device, sub_blocks, P, steps=3):
     """Second line (task 5): the same workload with the qualities quantised to four levels, as current instruments
     write them (flavour 1 of dsrcgpu_synth_fastq): a third of a quality stream then lies in one context.  Same scheduler instances,
@@ -852,7 +888,7 @@ def main():
                          # L2<->fabric bytes of one k_rc launch: FETCH_SIZE x 2 (gfx950 counts 16 B/lane streaming reads at half) + WRITE_SIZE,
                          # separate rocprofv3 --pmc passes of a 512-block batch (profiles/r06_pmc_final.json; null when that file is not of this library)
                          "traffic": int(pc["k_rc_bytes_per_block"] * sub_blocks) if pc else None,
-                         "kernel": "k_rc (range-coder arithmetic, one lane per stream; its loader waves turn the per-symbol codes into the stream bytes)",
+                         "kernel": "k_rcs (range coder: one lane per stream, the range recurrence and the low recurrence on two waves of a workgroup; loader waves turn records into the waves' rows and the per-symbol codes into the stream bytes)",
                          "kernel_ms": round(rc_ms, 2), "launch_bytes": int(alg), "batch_ms": round(batch_ms, 2),
                          # what bounds the RUN, not the longest launch: algorithmic bytes of a step over the step's time, and what the kernels really move
                          "step_frac": round(step_frac, 5), "step_achieved": round(step_frac * HBM_PEAK_GBS, 2),
@@ -900,13 +936,14 @@ def main():
             # ---- the forms a user calls (task 6): verify, queue form, the CLI end to end -------------------
             if not os.environ.get("DSRC_BENCH_NO_FORMS"):
                 try:
-                    ln.h.release_memory()                    # the decoding passes left ~100 GB of arena and model tables with instance 0
+                    for l2 in lanes:
+                        l2.h.release_memory()                # the headline's arenas (4 x 37 GB), the decoding passes' arena and model tables
                     v1, nb = measure_verify(cfg, ln, 1)
                     v4, _ = measure_verify(cfg, ln, 4)
-                    big = None                       # (two instances with calls of 900 blocks: 3.66 GB/s, profiles/r05_bench_default_first.json; DSRC_BENCH_VERIFY_LARGE=1)
-                    if os.environ.get("DSRC_BENCH_VERIFY_LARGE") and sub_blocks * 2 * 2 * 8.4e6 * 11 < 230e9:
-                        vb, nbb = measure_verify(cfg, ln, 2, blocks=2 * sub_blocks)
-                        big = {"value": vb, "unit": "MB/s", "blocks_per_call": nbb, "instances": 2}
+                    # round 6: one handle, one call of the step's size: the lanes inside the handle compress, then ONE verifying pass decodes all
+                    # the call's blocks (a pass is a chain per block: about as long for 1800 blocks as for 450)
+                    vb, nbb = measure_verify(cfg, ln, 1, blocks=P * sub_blocks)
+                    big = {"value": vb, "unit": "MB/s", "blocks_per_call": nbb, "instances": 1}
                     line["verify"] = {"value": v4, "unit": "MB/s", "blocks_per_call": nb, "instances": 4, "one_instance": v1, "larger_calls": big,
                                       "what": "-d3 -q2 -c: dsrcgpu_compress_batch_device with calculate_crc32 + verify_after_compress (the blocks are decoded on the device and the three CRC-32 compared), inputs and outputs in HBM",
                                       "cpu_baseline": crc_cpu}
@@ -920,13 +957,14 @@ def main():
                     mbs, nbytes, dt = measure_queue_form(cfg, ln.h.device, chunks, 1, batches=8, pinned=True)
                     q["handles_1_pinned"] = {"value": mbs, "unit": "MB/s", "bytes": nbytes, "s": round(dt, 2),
                                              "what": "the same with dsrcgpu_submit_pinned: the chunks lie in page-locked memory of the caller's and are not copied into the ring"}
-                    q["what"] = "dsrcgpu_submit / flush / collect / release with host-resident 8 MiB chunks, 192 chunks per flush, one submitting and one collecting thread per handle; host copy into the page-locked ring, PCIe both ways and the compression inside; a handle runs consecutive batches on two scheduler lanes of its own (round 4)"
+                    q["what"] = "dsrcgpu_submit / flush / collect / release with host-resident 8 MiB chunks, 192 chunks per flush, one submitting and one collecting thread per handle; host copy into the page-locked ring, PCIe both ways and the compression inside; a handle runs consecutive batches on three scheduler lanes of its own (DSRC_GPU_QUEUE_LANES)"
                     line["queue_form"] = q
                     del chunks
                     # every GPU resource of the headline run is released; the same step on four-level qualities
                     dev0 = ln.h.device
                     for l2 in lanes:
                         l2.free()
+                    line["one_handle"] = measure_one_handle(cfg, dev0, P * sub_blocks)
                     line["binned"] = measure_binned(cfg, dev0, sub_blocks, P)
                     # the CLI on configs[2]'s own 37.7 GB file in tmpfs
                     import tempfile

@@ -45,7 +45,7 @@ for what, fsub, wsub, blocks in (("compress", "cf", "cw", 512), ("decode", "df",
     if what == "compress":
         is_dec = lambda k: k.startswith("k_dec") or k.startswith("k_selftest") or k.startswith("k_lds_order")
         sec["all_bytes_per_block"] = tot(lambda k: not is_dec(k))
-        sec["k_rc_bytes_per_block"] = tot(lambda k: k == "k_rc")
+        sec["k_rc_bytes_per_block"] = tot(lambda k: k == "k_rc" or k.startswith("k_rcs"))      # the range coder: k_rcs<16/32> (k_rc: the redo list, normally empty)
         sec["k_part_bytes_per_block"] = tot(lambda k: k == "k_part")
         sec["model_bytes_per_block"] = tot(lambda k: k.startswith("k_model") or k in ("k_binoff", "k_place"))
         sec["text_bytes_per_block"] = tot(lambda k: k in ("k_count_lines", "k_scan_tiles", "k_index_lines", "k_records", "k_prep_stats", "k_prep_write", "k_rec_offsets") or k.startswith("k_tag"))
