@@ -399,6 +399,9 @@ def measure_verify(cfg, ln, n_inst, blocks=None):
     for 450, so its rate is the number of blocks in flight over the chain's length."""
     from dsrc_amd._lib import Handle
     hs = [Handle(cfg.dna_order, cfg.quality_order, crc=True, quality_offset=33, device=ln.h.device, verify=True) for _ in range(n_inst)]
+    if n_inst > 1:
+        for h in hs:
+            h.set_lanes(1)            # several handles side by side are the lanes (as in rounds 3-5); one handle alone cuts its calls itself
     own = []
     if blocks:
         recs = int(blocks * RECS_PER_BLOCK * 1.02) + 1000
@@ -937,7 +940,8 @@ def main():
             if not os.environ.get("DSRC_BENCH_NO_FORMS"):
                 try:
                     for l2 in lanes:
-                        l2.h.release_memory()                # the headline's arenas (4 x 37 GB), the decoding passes' arena and model tables
+                        if getattr(l2.h, "h", None):
+                            l2.h.release_memory()            # the headline's arenas (4 x 37 GB), the decoding passes' arena and model tables
                     v1, nb = measure_verify(cfg, ln, 1)
                     v4, _ = measure_verify(cfg, ln, 4)
                     # round 6: one handle, one call of the step's size: the lanes inside the handle compress, then ONE verifying pass decodes all

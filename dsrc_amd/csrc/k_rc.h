@@ -1364,6 +1364,7 @@ __device__ __attribute__((noinline)) bool rcs_chunk_clamps(u64 low, const LDS_AS
 // chunk q + 2.  res: [0,1] low after chunk q, [2] range after chunk q, [3] range after chunk q + 1, [4] 0 = done, 1 = the bytes do
 // not fit the chunk's slots (the stream goes to the redo list instead).  Not inlined: rare, and the serial wave's loop stays short.
 #define RCS_RXB 200
+#define RCS_FIX_SLOTS 8                 // recoveries a workgroup can have under way at a time
 __device__ __attribute__((noinline)) void rcs_recover(const RcPack* chain, u32 q, u64 low, u32 range, u32 n_full, LDS_AS u32* crow, LDS_AS u32* fixrow, u8* xb, LDS_AS u32* res)
 {
 	const u32 t0 = q * RC_CHUNK;
@@ -1561,7 +1562,7 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 	{
 		u64 low = 0, low_end = 0;
 		u32 range_fix_end = 0;                                                 // the range at the chain's last full group, if a recovery passed over it
-		bool fix_mine = false; u32 fix_start = 0;                              // this lane's words of the chunk come from the fix row; the range that chunk starts from
+		bool fix_mine = false; u32 fix_start = 0, slot = 0;                    // this lane's words of the chunk come from fix row `slot`; the range that chunk starts from
 		__syncthreads();
 		u32 i3 = 2;                                                            // (p - 1) mod 3
 		for (u32 p = 0; p < n_chunks + 2u; ++p)
@@ -1570,7 +1571,7 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 			{
 				const u32 q = p - 1u;
 				const LDS_AS U4* fcrow = s_l + i3 * RCS_LROW_U4 + rowi * (RC_CODE_PITCH / 4);
-				const LDS_AS U4* krow = fix_mine ? (const LDS_AS U4*)S.fixrow : s_k + (q & 1u) * RCS_KROW_U4 + rowi * (RC_CODE_PITCH / 4);
+				const LDS_AS U4* krow = fix_mine ? (const LDS_AS U4*)(S.fixrow + slot * RC_CODE_PITCH) : s_k + (q & 1u) * RCS_KROW_U4 + rowi * (RC_CODE_PITCH / 4);
 				LDS_AS U4* crow = s_c + (q & 1u) * RCS_KROW_U4 + rowo * (RC_CODE_PITCH / 4);
 				// a group's words are requested while the group before it is coded (two sets of registers)
 				constexpr u32 GQ = RC_GROUP / 4, NG = RC_CHUNK / RC_GROUP;
@@ -1610,34 +1611,39 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 					const bool forced = c.force_exact == 2u || (c.force_exact == 3u && (q + lane) % 5u == 2u);
 					if (look && (forced || rcs_chunk_clamps(snap, (const LDS_AS u32*)krow, (const LDS_AS u32*)fcrow, count)))
 					{
-						// one recovery at a time per workgroup (the fix row): a second lane in the same two periods, and anything rcs_recover
-						// cannot express, goes to the redo list -- k_rc codes the stream again (what this launch still writes for it is overwritten)
+						// RCS_FIX_SLOTS recoveries at a time per workgroup (a fix row each; with skewed symbols -- four-level qualities -- low keeps its
+						// ones for many chunks and a lane holds its row as long): a lane that finds none free, and anything rcs_recover cannot
+						// express, goes to the redo list -- k_rc codes the stream again (what this launch still writes for it is overwritten)
 						bool mine = had_fix;
-						if (!mine && c.force_exact != 2u) mine = atomicCAS((u32*)S.owner, 0u, lane + 1u) == 0u;
+						u32 why = c.force_exact == 2u ? 3u : 1u;                   // (the list's top bits, for DSRC_GPU_DEBUG: 1 no fix row free, 2 rcs_recover refused, 3 forced)
+						if (!mine && c.force_exact != 2u)
+							for (u32 k = 0; k < RCS_FIX_SLOTS && !mine; ++k)
+								if (atomicCAS((u32*)(S.owner + k), 0u, lane + 1u) == 0u) { mine = true; slot = k; }
 						if (mine)
 						{
 							const u32 r0 = had_fix ? fix_start : S.rstart[(q & 1u) * 64u + lane];
-							rcs_recover(rec_pool + c.trip, q, snap, r0, n_full, (LDS_AS u32*)crow, S.fixrow, S.rxb, S.res);
-							if (S.res[4] == 0u)
+							LDS_AS u32* res = S.res + slot * 8u;
+							rcs_recover(rec_pool + c.trip, q, snap, r0, n_full, (LDS_AS u32*)crow, S.fixrow + slot * RC_CODE_PITCH, S.rxb + slot * (RCS_RXB + 8), res);
+							if (res[4] == 0u)
 							{
-								low = (u64)S.res[0] | ((u64)S.res[1] << 32);
-								const u32 rq = S.res[2], rq1 = S.res[3], end_q = (q + 1u) * RC_CHUNK;
+								low = (u64)res[0] | ((u64)res[1] << 32);
+								const u32 rq = res[2], rq1 = res[3], end_q = (q + 1u) * RC_CHUNK;
 								if (n_full <= end_q) { low_end = low; range_fix_end = rq; }
 								else if (n_full <= end_q + RC_CHUNK) range_fix_end = rq1;
 								fix_mine = true; fix_start = rq; recovered = true;
 								S.fix[2 * lane] = q + 2u; S.fix[2 * lane + 1] = rq1;       // R takes it at the start of chunk q + 2
 							}
-							else { mine = false; if (!had_fix) *S.owner = 0u; }
+							else { mine = false; why = 2u; if (!had_fix) S.owner[slot] = 0u; }
 						}
 						if (!mine)
 						{
 							dead = true;
-							if (!(RCS_PROBE & 64)) { const u32 at = atomicAdd(&redo[0], 1u); redo[1 + at] = id; }
+							if (!(RCS_PROBE & 64)) { const u32 at = atomicAdd(&redo[0], 1u); redo[1 + at] = id | (why << 28); }
 						}
 					}
 				}
 				// the fix row has been read; unless a recovery has just filled it again for the next chunk, it is free
-				if (had_fix && !recovered) { fix_mine = false; *S.owner = 0u; }
+				if (had_fix && !recovered) { fix_mine = false; S.owner[slot] = 0u; }
 			}
 			i3 = i3 == 2u ? 0u : i3 + 1u;
 			__syncthreads();
@@ -1662,15 +1668,15 @@ template <int LANES> __global__ void __launch_bounds__(64 * RCS_WG_WAVES) k_rcs(
 	__shared__ u8 s_xb[64 * RC_XB];
 	__shared__ u32 s_rstart[2 * 64];
 	__shared__ u32 s_fix[2 * 64];
-	__shared__ u32 s_fixrow[RC_CODE_PITCH];
-	__shared__ u32 s_res[8];
-	__shared__ u8 s_rxb[RCS_RXB + 8];
-	__shared__ u32 s_owner;
+	__shared__ u32 s_fixrow[RCS_FIX_SLOTS * RC_CODE_PITCH];
+	__shared__ u32 s_res[RCS_FIX_SLOTS * 8];
+	__shared__ u8 s_rxb[RCS_FIX_SLOTS * (RCS_RXB + 8)];
+	__shared__ u32 s_owner[RCS_FIX_SLOTS];
 	if (threadIdx.x < 128) s_fix[threadIdx.x] = 0xFFFFFFFFu;                  // no chunk has this number
-	if (threadIdx.x == 0) s_owner = 0;
+	if (threadIdx.x < RCS_FIX_SLOTS) s_owner[threadIdx.x] = 0;
 	RcsLds S;
 	S.r = (LDS_AS U4*)s_r; S.l = (LDS_AS U4*)s_l; S.k = (LDS_AS U4*)s_k; S.c = (LDS_AS U4*)s_c; S.xb = s_xb; S.pos = (LDS_AS u32*)s_pos; S.range = (LDS_AS u32*)s_range;
-	S.rstart = (LDS_AS u32*)s_rstart; S.fix = (LDS_AS u32*)s_fix; S.fixrow = (LDS_AS u32*)s_fixrow; S.res = (LDS_AS u32*)s_res; S.rxb = s_rxb; S.owner = (LDS_AS u32*)&s_owner;
+	S.rstart = (LDS_AS u32*)s_rstart; S.fix = (LDS_AS u32*)s_fix; S.fixrow = (LDS_AS u32*)s_fixrow; S.res = (LDS_AS u32*)s_res; S.rxb = s_rxb; S.owner = (LDS_AS u32*)s_owner;
 	if (blockIdx.x * LANES + LANES <= n_chains) rcs_workgroup<true, LANES>(chains, n_chains, rec_pool, word_pool, st, bk, redo, S);
 	else rcs_workgroup<false, LANES>(chains, n_chains, rec_pool, word_pool, st, bk, redo, S);
 }
