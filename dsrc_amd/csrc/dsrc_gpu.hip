@@ -751,7 +751,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			j.jid = i;
 			const u32 n_bins = (j.n + BK_BIN - 1) >> BK_TB;
 			j.bk_binned = bk_binned ? 1u : 0u;
-			j.bk_on = (j.n >= bk_min && n_bins <= BK_MAX_BINS && j.key_bits <= BK_MAX_HB + BK_MAX_LB) ? 1u : 0u;
+			j.bk_on = (j.n >= bk_min && n_bins <= (u32)hook_int("DSRC_GPU_BUCKET_MAX_BINS", BK_MAX_BINS_WIDE) && j.key_bits <= BK_MAX_HB + BK_MAX_LB) ? 1u : 0u;
 			// bucket digit: ~2048 elements per bucket on average, at most 1024 buckets, at most BK_MAX_LB key bits left for the LDS sort
 			const u64 per_bucket = j.is_dna ? bk_elems_dna : bk_elems_qua;
 			u32 hb = 0; while (hb < BK_MAX_HB && (per_bucket << hb) < j.n) ++hb;
@@ -760,6 +760,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 			j.bk_hb = hb; j.bk_lb = j.key_bits - hb;
 			j.bk_mul = BK_HASH_MUL; j.bk_kmask = (u32)((1ull << j.key_bits) - 1ull);
 			j.bk_limit = bk_limit; j.bk_big = bk_big;
+			j.bk_narrow_bins = (u32)std::min<long>(BK_MAX_BINS, hook_int("DSRC_GPU_BUCKET_NARROW_BINS", BK_MAX_BINS));
 		}
 		bk_zero_words = cur;
 		o_bk = A.alloc(((size_t)cur + 2 + 128) * 4 + 64);            // + 64 records' worth of nowhere (k_model: the lanes of a short window store there)

@@ -38,7 +38,8 @@
 #endif                                 // (64 KB: with 14 bits and 128 KB a k_place workgroup needs a CU nearly to itself -- 1.5 ms alone, 6.9 ms next to three other instances)
 #define BK_BIN (1u << BK_TB)
 static_assert(BK_TB == RC6_TB, "a time bin is the unit of k_rc's record layout (rc6_chunk_off)");
-#define BK_MAX_BINS 512                // streams of up to 4 M symbols
+#define BK_MAX_BINS 512                // streams of up to 4 M symbols keep their tiles' offsets and counts of a bucket in k_model's LDS;
+#define BK_MAX_BINS_WIDE 65536         // longer ones (-b64, -b256: 27 M / 107 M symbols per stream) read them from the count table 64 tiles at a time
 #define BK_HASH_MUL 0x9E3779B1u
 
 // the `bk` pool (u32): [0 .. NJ) fallback flag per job | fallback lists, one per launch group: count, then job ids; zeroed per
@@ -465,15 +466,24 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 	map_t* map = s_map[w]; u32* rows = (u32*)s_rows[w]; u16* off = s_off[w]; u16* num = s_num[w]; u8* head = s_head[w];
 	const u32 n_bins = (j.n + BK_BIN - 1) >> BK_TB;
 
-	// where this bucket's elements lie inside every tile (k_binoff: the offsets of the tile's buckets), and how many
-	u32 nb = 0;
-	for (u32 b = lane; b < n_bins; b += 64)
+	// where this bucket's elements lie inside every tile (k_binoff: the offsets of the tile's buckets), and how many.  A stream of more
+	// tiles than the LDS arrays hold (`wide`: the reference's -m1 / -m2 buffer sizes; rounds 4-5 sent those through k_sort / k_replay,
+	// 560 of a batch's 900 ms at -b64) only counts here and reads a group's 64 tiles again when it gets there
+	const bool wide = n_bins > j.bk_narrow_bins;
+	auto tile_info = [&](u32 b, u32* o_out) -> u32
 	{
 		const u16* row = bcnt + (u64)j.bk_cnt + (u64)b * buckets;
 		const u32 o = row[bucket];
 		const u32 tile_n = j.n - (b << BK_TB) < BK_BIN ? j.n - (b << BK_TB) : BK_BIN;
-		const u32 c = (bucket + 1 < buckets ? (u32)row[bucket + 1] : tile_n) - o;
-		off[b] = (u16)o; num[b] = (u16)c;
+		*o_out = o;
+		return (bucket + 1 < buckets ? (u32)row[bucket + 1] : tile_n) - o;
+	};
+	u32 nb = 0;
+	for (u32 b = lane; b < n_bins; b += 64)
+	{
+		u32 o;
+		const u32 c = tile_info(b, &o);
+		if (!wide) { off[b] = (u16)o; num[b] = (u16)c; }
 		nb += c;
 	}
 	head[lane] = 0xFFu;
@@ -492,11 +502,12 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 	// (or goes on) inside it leave their number at head[position], and a position finds its tile at the nearest head at or below
 	// it.  The last window of a group is short.  -> index into the element array (= into the record array), or MD_NONE
 	u32 g_bin = 0, g_pos = 0, g_tot = 0, left = nb;        // wave-uniform
-	u32 g_inc = 0, g_f = 0;
+	u32 g_inc = 0, g_f = 0, g_off = 0;                    // (g_off: wide streams -- the offset of tile g_bin + lane)
 	auto load_group = [&]()
 	{
 		const u32 b = g_bin + lane;
-		const u32 c = b < n_bins ? (u32)num[b] : 0u;
+		u32 c = 0;
+		if (b < n_bins) { if (wide) c = tile_info(b, &g_off); else c = (u32)num[b]; }
 		g_inc = wave_incl_scan_dpp(c); g_f = g_inc - c;
 		g_tot = wave_last(g_inc); g_pos = 0;
 	};
@@ -520,7 +531,8 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 			{
 				const u32 f0 = (u32)__builtin_amdgcn_readlane((int)g_f, (int)k0);
 				const u32 bin = g_bin + k0;
-				const u32 idx = (bin << BK_TB) + (u32)off[bin & (BK_MAX_BINS - 1u)] + (g_pos - f0) + lane;
+				const u32 o0 = wide ? (u32)__builtin_amdgcn_readlane((int)g_off, (int)k0) : (u32)off[bin & (BK_MAX_BINS - 1u)];
+				const u32 idx = (bin << BK_TB) + o0 + (g_pos - f0) + lane;
 				g_pos += 64u; left -= 64u;
 				return idx;
 			}
@@ -540,7 +552,8 @@ __global__ void __launch_bounds__(64 * MD_WAVES_FOR(ROW_BYTES)) k_model(const Ct
 		const u32 r = lane - hl + (hl == 0 ? g_pos - f0 : 0u);
 		const u32 avail = g_tot - g_pos < 64 ? g_tot - g_pos : 64u;
 		const u32 bin = g_bin + k;
-		const u32 idx = lane < avail ? (bin << BK_TB) + (u32)off[bin & (BK_MAX_BINS - 1u)] + r : MD_NONE;
+		const u32 ok = wide ? (u32)__shfl((int)g_off, (int)k) : (u32)off[bin & (BK_MAX_BINS - 1u)];
+		const u32 idx = lane < avail ? (bin << BK_TB) + ok + r : MD_NONE;
 		g_pos += avail; left -= avail;
 		return idx;
 	};

@@ -79,7 +79,7 @@ struct CtxJob     // one (block, stream)
 	u32 bk_fb;          // bk index of the fallback list of the stream's launch group: count, then job ids
 	u32 bk_cnt;         // index (u16 units) of the stream's per-tile bucket counts / per-bin bucket offsets (k_part, k_binoff)
 	u32 bk_limit;       // largest bucket a wave of k_model may walk (BK_LIMIT; tests lower it)
-	u32 pad1;
+	u32 bk_narrow_bins; // streams of up to this many tiles keep their tile table in k_model's LDS (BK_MAX_BINS; tests lower it)
 };
 
 typedef u64 __attribute__((aligned(1))) u64_unaligned;

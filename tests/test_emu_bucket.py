@@ -35,6 +35,17 @@ def test_dna_with_eight_symbols_and_lossy_orders(emu, oracle):
     check(emu, oracle, data, [(3, 2, True), (1, 1, True)])
 
 
+def test_long_streams_read_their_tile_table_by_groups(emu, oracle, monkeypatch):
+    """Streams of more tiles than k_model keeps in LDS (512: 4 M symbols; the reference's -m1 / -m2 buffers give 27 M / 107 M per stream)
+    read a bucket's tile offsets and counts from the count table 64 tiles at a time.  DSRC_GPU_BUCKET_NARROW_BINS=2 puts every stream
+    of more than two tiles on that road: ordinary data, hot contexts (the windows inside one tile's run), several alphabets."""
+    monkeypatch.setenv("DSRC_GPU_BUCKET_NARROW_BINS", "2")
+    check(emu, oracle, synth.illumina_fastq(600)[:-1], [(3, 2, False), (2, 1, True)])
+    check(emu, oracle, alphabet_fastq(40, n_rec=420, L=100), [(2, 2, False), (1, 1, False)])
+    monkeypatch.setenv("DSRC_GPU_BUCKET_BIG", "256")
+    check(emu, oracle, _hot(260), [(1, 2, False)])
+
+
 def test_model_runs_out_of_rows(emu, oracle, capfd, monkeypatch):
     """Independent uniform qualities: nearly every symbol of a bucket has a context of its own, k_model runs out of counter rows and
     hands the stream back to k_sort / k_replay (their launches follow k_model's in the same batch)."""

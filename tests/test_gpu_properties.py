@@ -91,6 +91,37 @@ def test_full_size_blocks(gpu, oracle, d, q, binned):
     h.dev_free(d_in); h.dev_free(d_out); h.close()
 
 
+@pytest.mark.parametrize("binned", [False, True])
+def test_full_size_blocks_b64(gpu, oracle, binned):
+    """Two 64 MiB chunks (`-b64`, the reference's -m1 preset, src/main.cpp:195-219): 27 M symbols per stream, 3260 tiles -- k_model reads a
+    bucket's tile table from the count table 64 tiles at a time (round 6; until then such streams went through k_sort / k_replay).
+    With four-level qualities the hot buckets outgrow what one wave may walk: those streams are handed back on the device and coded by
+    the redo list's kernels.  Both blocks against the oracle, the state carried."""
+    bench = _bench_helpers()
+    cfg = Config.from_levels(3, 2)
+    h = gpu.Handle(cfg.dna_order, cfg.quality_order)
+    per = bench.RECS_PER_BLOCK * 8
+    recs = int(2 * per * 1.02) + 1000
+    cap = recs * 384
+    d_in = h.dev_alloc(cap); d_out = h.dev_alloc(cap // 2)
+    first = 4242
+    nbytes = h.synth_illumina(first, recs, d_in, cap, binned=binned)
+    off = bench.record_offsets(first, recs)
+    assert off[-1] == nbytes
+    cuts = [0, per, 2 * per]
+    starts = [int(off[a]) for a in cuts[:-1]]; sizes = [int(off[b] - off[a] - 1) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert min(sizes) > 60 << 20
+    o_offs, o_sizes, raw, comp = h.compress_batch_device(d_in, starts, sizes, d_out, cap // 2)
+    blob = h.dev_download(d_out, o_offs[-1] + o_sizes[-1])
+    capst = C.c_uint32(0); c = _orc_cfg(cfg)
+    for i in range(2):
+        ch = h.dev_download(d_in + starts[i], sizes[i])
+        out = (C.c_uint8 * (len(ch) + 65536))(); osz = C.c_uint64(); r4 = (C.c_uint64 * 4)(); c4 = (C.c_uint64 * 4)()
+        assert oracle.lib.orc_compress_block_state(C.byref(c), C.byref(capst), ch, C.c_uint64(len(ch)), out, C.c_uint64(len(out)), C.byref(osz), r4, c4) == 0
+        assert blob[o_offs[i]: o_offs[i] + o_sizes[i]] == bytes(out[:osz.value]), f"chunk {i} ({sizes[i]} bytes)"
+    h.dev_free(d_in); h.dev_free(d_out); h.close()
+
+
 def test_large_chunks_and_mixed_sizes(gpu, oracle):
     """Chunk sizes other than the default 8 MiB in one batch (a 40 MB chunk = `-b40`, a 1 MB one, a 300-byte one):
     the range-coder stage lays the streams of a wave out with the longest stream's pitch."""
