@@ -1579,7 +1579,10 @@ int check_settings(dsrcgpu_handle* h, const dsrcgpu_settings* s, const dsrcgpu_d
 	if (s->tag_preserve_flags & ~0x7FFFFFFEull) return fail(h, DSRCGPU_E_ARG, "tag field filter (-f): field numbers 1..30 only (the reference shifts a 32-bit int)");
 	if (d->quality_offset < 33 || d->quality_offset > 64) return fail(h, DSRCGPU_E_ARG, "quality offset %u outside [33,64]", d->quality_offset);
 	if (s->dna_order > 9) return fail(h, DSRCGPU_E_ARG, "dna_order %u > 9", s->dna_order);
-	if (!s->lossy && s->quality_order > 2) return fail(h, DSRCGPU_E_ARG, "lossless quality_order %u > 2", s->quality_order);
+	// lossless: 0, 1, 2 (the command line's -q levels) and 3, 6 -- what wrap::DsrcArchive makes of levels 1 and 2 (qualityOrder = 3 * level,
+	// src/DsrcArchive.cpp:42): the reference's lossless proxy treats every order but 1 as order 2 and takes the "F" schemes at order 2
+	// only (src/QualityModelerProxy.h:225-283); the order byte goes into the archive's footer as it is
+	if (!s->lossy && s->quality_order > 2 && s->quality_order != 3 && s->quality_order != 6) return fail(h, DSRCGPU_E_ARG, "lossless quality_order %u (0, 1, 2, or the record API's 3 and 6)", s->quality_order);
 	if (s->lossy && s->quality_order > 6) return fail(h, DSRCGPU_E_ARG, "lossy quality_order %u > 6", s->quality_order);
 	return 0;
 }

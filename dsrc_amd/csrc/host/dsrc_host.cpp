@@ -1407,8 +1407,8 @@ void DsrcArchive::StartCompress(const std::string& filename_)
 	impl->type.colorSpace = colorSpace;
 	impl->bufferSize = (uint64)params.fastqBufferSizeMB << 20;
 	if (colorSpace) throw DsrcException("DsrcArchive: colour-space records are not supported by the record-level API on the GPU path (use DsrcModule::Compress)");
-	if (!impl->settings.lossy && impl->settings.qualityOrder != 0)
-		throw DsrcException("DsrcArchive: lossless quality levels 1-2 are undefined in the reference's archive API (qualityOrder = 3 * level, src/DsrcArchive.cpp:42); use level 0 or lossy mode");
+	// (lossless quality levels 1 and 2 arrive as qualityOrder 3 and 6, as in the reference: the order-2 models without the "F" schemes,
+	// the order byte in the footer as it is; the reference's DsrcArchive reads them back, tests/golden/make_records_golden.py)
 	if (impl->type.qualityOffset == 0)
 		throw DsrcException("DsrcArchive: set the quality offset (33 or 64); the archive API does not analyse the data");
 	comp::InputParameters args = params;

@@ -26,8 +26,10 @@ FILES = {
     "illumina3200": lambda: synth.illumina_fastq(3200, first=501),
     "iontorrent6000": lambda: synth.iontorrent_fastq(6000),
 }
-# (dna level, quality level, lossy); lossless quality levels 1-2 are undefined in this API (src/DsrcArchive.cpp:42)
-LEVELS = [(0, 0, 0), (1, 0, 0), (3, 0, 0), (2, 1, 1), (3, 2, 1), (0, 2, 1)]
+# (dna level, quality level, lossy).  Lossless quality levels 1-2 become qualityOrder 3 / 6 in this API (src/DsrcArchive.cpp:42: level * 3,
+# whatever `lossy` says): the lossless proxy treats every order but 1 as order 2 without the "F" schemes (src/QualityModelerProxy.h:
+# 225-283), writes that order into the footer, and the reference's DsrcArchive reads such archives back -- checked below.
+LEVELS = [(0, 0, 0), (1, 0, 0), (3, 0, 0), (2, 1, 1), (3, 2, 1), (0, 2, 1), (2, 1, 0), (0, 2, 0), (3, 2, 0)]
 
 
 def block_table(arc: bytes):
@@ -50,6 +52,10 @@ def main():
                     dst = os.path.join(td, "o.dsrc")
                     subprocess.check_call([REF, p, dst, str(d), str(q), str(lossy), str(buf), "33"], stderr=subprocess.DEVNULL)
                     arc = open(dst, "rb").read()
+                    if q and not lossy:          # the reference reads its own archive back (DsrcArchive::ReadNextRecord): the level is defined by what it does
+                        back = os.path.join(td, "back.fastq")
+                        subprocess.check_call([REF, "-x", dst, back], stderr=subprocess.DEVNULL)
+                        assert open(back, "rb").read() == data, (name, d, q)
                     g["archives"].append({"name": name, "in_sha256": hashlib.sha256(data).hexdigest(), "levels": [d, q, lossy], "buf_mb": buf,
                                           "quality_offset": 33, "size": len(arc), "sha256": hashlib.sha256(arc).hexdigest(),
                                           "block_sizes": block_table(arc)})

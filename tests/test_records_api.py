@@ -92,8 +92,12 @@ def test_host_archive_on_emulator(inputs):
     subprocess.check_call([EMU_HOST, paths["illumina3200"], out, "0", "0", "0", "1", "33"], stderr=subprocess.DEVNULL)
     arc = open(out, "rb").read()
     assert (len(arc), sha(arc)) == (e["size"], e["sha256"])
-    # refusals: lossless quality level 1 is undefined in the reference's archive API; offset must be given
-    assert subprocess.run([EMU_HOST, paths["illumina3200"], out, "0", "1", "0", "1", "33"], capture_output=True).returncode == 1
+    # lossless quality level 1 = qualityOrder 3 in this API, as in the reference (src/DsrcArchive.cpp:42): the reference's archive
+    e = next(x for x in G["archives"] if x["name"] == "illumina3200" and x["levels"] == [0, 2, 0])
+    subprocess.check_call([EMU_HOST, paths["illumina3200"], out, "0", "2", "0", "1", "33"], stderr=subprocess.DEVNULL)
+    arc = open(out, "rb").read()
+    assert (len(arc), sha(arc)) == (e["size"], e["sha256"])
+    # the offset must be given
     assert subprocess.run([EMU_HOST, paths["illumina3200"], out, "0", "0", "0", "1", "0"], capture_output=True).returncode == 1
 
 
