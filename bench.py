@@ -447,7 +447,7 @@ def measure_verify(cfg, ln, n_inst, blocks=None):
 def measure_one_handle(cfg, device, blocks, lanes=4, steps=3):
     """What ONE handle does by itself (task 2): the step of the headline -- `blocks` consecutive chunks, device-resident
     -- as one dsrcgpu_compress_batch_device call on one handle, the scheduler lanes inside it (dsrcgpu_set_lanes: the library's default
-    sub-batches of about 1.75 GiB).  HBM: what the device has less free while the call's lanes hold their arenas (inputs and output
+    sub-batches of about 1.9 GB).  HBM: what the device has less free while the call's lanes hold their arenas (inputs and output
     buffer not counted).  The last block of the last call is compared with the oracle."""
     import ctypes as C
     from dsrc_amd._lib import load
@@ -475,7 +475,7 @@ def measure_one_handle(cfg, device, blocks, lanes=4, steps=3):
         assert ln.h.dev_download(ln.outs[0][0] + o_offs[i], o_sizes[i]) == Oracle().compress_block(cfg, ln.h.dev_download(d_in + starts[i], sizes[i]))[0], "bench parity check failed (one handle, lanes inside)"
         return {"value": round(in_bytes / wall / 1e6, 1), "unit": "MB/s", "blocks_per_call": blocks, "lanes": lanes, "calls": steps, "ms_per_call": round(wall / steps * 1e3, 1),
                 "hbm_held_GB": round(held / 1e9, 1), "k_rc_ms": round(sum(t[1] for t in ln.timing[1:]) / max(1, len(ln.timing) - 1), 1), "parity_checked_blocks": 1,
-                "what": "ONE handle, one dsrcgpu_compress_batch_device call per step of the headline's size, inputs and outputs in HBM: the call is cut into sub-batches (~1.75 GiB of chunks) that run on scheduler lanes inside the handle, the block-to-block state handed from one to the next (include/dsrc_gpu.h dsrcgpu_set_lanes)"}
+                "what": "ONE handle, one dsrcgpu_compress_batch_device call per step of the headline's size, inputs and outputs in HBM: the call is cut into sub-batches (~1.9 GB of chunks) that run on scheduler lanes inside the handle, the block-to-block state handed from one to the next (include/dsrc_gpu.h dsrcgpu_set_lanes)"}
     finally:
         ln.free()
 

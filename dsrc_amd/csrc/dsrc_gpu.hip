@@ -1796,7 +1796,7 @@ int compress_batch_host(dsrcgpu_handle* h, uint32_t n, const uint8_t* const* fas
 // through a chain, so the blocks are those of one handle fed in order.  A sub-batch assembles its blocks in its own arena; when every
 // earlier sub-batch has put its blocks down it copies them behind theirs (device to device, or down to the host).
 #define DSRC_LANES_DEFAULT 4
-#define DSRC_SUB_BYTES_DEFAULT ((size_t)1792 << 20)
+#define DSRC_SUB_BYTES_DEFAULT ((size_t)1900000000)      // (225 chunks of 8 MiB: a call of 1800 is two rounds of four lanes -- 44 GB/s; three rounds of 150: 36)
 
 // how a batch would be cut: 0 = not at all (run_batch on the handle itself)
 u32 lanes_sub_chunks(const dsrcgpu_handle* h, u32 n, const u64* sizes, u32* lanes_out)

@@ -96,11 +96,11 @@ int dsrcgpu_compress_batch_device(dsrcgpu_handle* h, uint32_t n, const void* d_f
 
 /* Scheduler lanes inside a handle (round 6).  The reference needs one DsrcCompressorMT for a file (src/DsrcOperator.cpp:295-340);
  * a batch call on ONE handle now fills the GPU by itself: a batch of more than one sub-batch's worth of chunks is cut into
- * consecutive sub-batches (default: about 1.75 GiB of chunks each) that run on up to `lanes` (default 4) scheduler lanes inside the
+ * consecutive sub-batches (default: about 1.9 GB of chunks each) that run on up to `lanes` (default 4) scheduler lanes inside the
  * handle -- own arena and streams each, one host thread per lane for the duration of the call -- so that the serial range coder
  * of one sub-batch runs beside the front ends of the others.  The block-to-block state goes from sub-batch to sub-batch through an
  * internal chain: the blocks, their order and the state left behind are those of the same call on one lane.  HBM: an arena per
- * lane, sized for a sub-batch (about 9 x its chunks + 1.75 GiB), instead of one sized for the batch.
+ * lane, sized for a sub-batch (about 7.5 x its chunks + 1.75 GiB), instead of one sized for the batch.
  * dsrcgpu_set_lanes(h, lanes, sub_batch_chunks): 0 = the default for either; lanes = 1 keeps a batch on the handle's own lane.
  * A handle that has been given a chain (dsrcgpu_set_chain) or a fixed arena (dsrcgpu_create's arena_bytes) is the caller's own
  * lane and is never cut; nor are the batches of the queue form's lanes. */
