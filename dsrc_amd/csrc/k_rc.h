@@ -1300,7 +1300,7 @@ __global__ void __launch_bounds__(64 * RC_WG_WAVES) k_rc(const RcChain* chains, 
 }
 
 // ---- k_rcs: the two recurrences on two waves ---------------------------------------------------------------------------------------
-// LDS of a workgroup: R rows (a, b, freq: 12 B per symbol) x 2, L rows (freq | cum << 16) x 3, R's words x 2, code rows x 2 -- the
+// LDS of a workgroup: R rows (a, b, freq: 12 B per symbol) x 2, L rows (freq | cum << 16) x 2, R's words x 2, code rows x 2 -- the
 // chunk of period p is converted in period p - 1, coded by R in p, by L in p + 1 and turned into bytes in p + 2.
 #define RCS_RROW_U4 (LANES * RC_ROW_U4)
 #define RCS_LROW_U4 (LANES * RC_CODE_PITCH / 4)
@@ -1456,11 +1456,23 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 		RcFetch r[RCS_DEPTH][ROWS];
 #pragma unroll
 		for (u32 d = 0; d < RCS_DEPTH; ++d) rc_fetch(r[d], rb, d, lw, n_live);
-		// a chunk's R rows are in buffer (chunk & 1), its L rows in buffer (chunk % 3)
-		auto convert = [&](const RcFetch* f, u32 r2, u32 l3)
+		// a chunk's R rows and L rows are in buffers (chunk & 1).  The R rows are written a period before R codes the chunk; the L rows
+		// -- a copy of the fetched dwords, read by L a period after R -- in R's period, just before the chunk's register set is refilled
+		// (written with the R rows they needed three buffers: 8.7 KB of the workgroup's LDS, which with the rest kept a k_part workgroup
+		// from sharing the CU)
+		auto lrows = [&](const RcFetch* f, u32 l2)
+		{
+			LDS_AS u32* lbuf = (LDS_AS u32*)(s_l + l2 * RCS_LROW_U4);
+#pragma unroll
+			for (u32 k = 0; k < (u32)ROWS; ++k)
+			{
+				const u32 j = lw + k * RC_LOADERS;
+				if (j < n_live) lbuf[j * RC_CODE_PITCH + lane_id()] = f[k].fc;
+			}
+		};
+		auto convert = [&](const RcFetch* f, u32 r2)
 		{
 			LDS_AS U4* rbuf = s_r + r2 * RCS_RROW_U4;
-			LDS_AS u32* lbuf = (LDS_AS u32*)(s_l + l3 * RCS_LROW_U4);
 #pragma unroll
 			for (u32 k = 0; k < (u32)ROWS; ++k)
 			{
@@ -1470,11 +1482,10 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 					const u64 m = recip48(f[k].tot);                          // < 2^47: m << 16 fits
 					LDS_AS u32* d = (LDS_AS u32*)(rbuf + j * RC_ROW_U4) + 3u * lane_id();
 					d[0] = (u32)(m >> 16); d[1] = (u32)m << 16; d[2] = f[k].fc & 0xFFFFu;
-					lbuf[j * RC_CODE_PITCH + lane_id()] = f[k].fc;
 				}
 			}
 		};
-		convert(r[0], 0, 0);
+		convert(r[0], 0);
 		__syncthreads();                                                       // chunk 0 is there
 		// periods 0 .. n_chunks + 1: R is in chunk p, L in p - 1, the bytes of p - 2 are written, p + 1 is converted.  Unrolled over
 		// the register sets: every set and buffer is known statically (a rolled loop that picks the sets with a switch makes the
@@ -1488,8 +1499,9 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 			{
 				const u32 p = q + k;                                           // p mod 2 = k mod 2, p mod 3 = k mod 3
 				if (p >= n_per) break;
+				lrows(r[k], k & 1u);
 				rc_fetch(r[k], rb, p + RCS_DEPTH, lw, n_live);
-				if (!(RCS_PROBE & 8)) convert(r[(k + 1) % RCS_DEPTH], (k + 1) & 1u, (k + 1) % 3u);
+				if (!(RCS_PROBE & 8)) convert(r[(k + 1) % RCS_DEPTH], (k + 1) & 1u);
 				if (p >= 2u && !(RCS_PROBE & 1)) rc_emit_chunk((const LDS_AS u32*)(s_c + (k & 1u) * RCS_KROW_U4), R, p - 2u, lw, n_live, &over);      // (p - 2) mod 2
 				__syncthreads();
 			}
@@ -1564,13 +1576,12 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 		u32 range_fix_end = 0;                                                 // the range at the chain's last full group, if a recovery passed over it
 		bool fix_mine = false; u32 fix_start = 0, slot = 0;                    // this lane's words of the chunk come from fix row `slot`; the range that chunk starts from
 		__syncthreads();
-		u32 i3 = 2;                                                            // (p - 1) mod 3
 		for (u32 p = 0; p < n_chunks + 2u; ++p)
 		{
 			if (p >= 1u && p <= n_chunks && !(RCS_PROBE & 2))
 			{
 				const u32 q = p - 1u;
-				const LDS_AS U4* fcrow = s_l + i3 * RCS_LROW_U4 + rowi * (RC_CODE_PITCH / 4);
+				const LDS_AS U4* fcrow = s_l + (q & 1u) * RCS_LROW_U4 + rowi * (RC_CODE_PITCH / 4);
 				const LDS_AS U4* krow = fix_mine ? (const LDS_AS U4*)(S.fixrow + slot * RC_CODE_PITCH) : s_k + (q & 1u) * RCS_KROW_U4 + rowi * (RC_CODE_PITCH / 4);
 				LDS_AS U4* crow = s_c + (q & 1u) * RCS_KROW_U4 + rowo * (RC_CODE_PITCH / 4);
 				// a group's words are requested while the group before it is coded (two sets of registers)
@@ -1645,7 +1656,6 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 				// the fix row has been read; unless a recovery has just filled it again for the next chunk, it is free
 				if (had_fix && !recovered) { fix_mine = false; S.owner[slot] = 0u; }
 			}
-			i3 = i3 == 2u ? 0u : i3 + 1u;
 			__syncthreads();
 		}
 		__syncthreads();                                                       // the loaders have turned the last chunk's codes into bytes
@@ -1660,12 +1670,11 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 template <int LANES> __global__ void __launch_bounds__(64 * RCS_WG_WAVES) k_rcs(const RcChain* chains, u32 n_chains, RcPack* rec_pool, u32* word_pool, BlkState* st, const u32* bk, u32* redo)
 {
 	__shared__ U4 s_r[2 * RCS_RROW_U4];
-	__shared__ U4 s_l[3 * RCS_LROW_U4];
+	__shared__ U4 s_l[2 * RCS_LROW_U4];
 	__shared__ U4 s_k[2 * RCS_KROW_U4];
 	__shared__ U4 s_c[2 * RCS_KROW_U4];
 	__shared__ u32 s_pos[LANES];
 	__shared__ u32 s_range[64];
-	__shared__ u8 s_xb[64 * RC_XB];
 	__shared__ u32 s_rstart[2 * 64];
 	__shared__ u32 s_fix[2 * 64];
 	__shared__ u32 s_fixrow[RCS_FIX_SLOTS * RC_CODE_PITCH];
@@ -1675,7 +1684,7 @@ template <int LANES> __global__ void __launch_bounds__(64 * RCS_WG_WAVES) k_rcs(
 	if (threadIdx.x < 128) s_fix[threadIdx.x] = 0xFFFFFFFFu;                  // no chunk has this number
 	if (threadIdx.x < RCS_FIX_SLOTS) s_owner[threadIdx.x] = 0;
 	RcsLds S;
-	S.r = (LDS_AS U4*)s_r; S.l = (LDS_AS U4*)s_l; S.k = (LDS_AS U4*)s_k; S.c = (LDS_AS U4*)s_c; S.xb = s_xb; S.pos = (LDS_AS u32*)s_pos; S.range = (LDS_AS u32*)s_range;
+	S.r = (LDS_AS U4*)s_r; S.l = (LDS_AS U4*)s_l; S.k = (LDS_AS U4*)s_k; S.c = (LDS_AS U4*)s_c; S.xb = (u8*)s_r;         /* the tails' byte buffers: the R rows are free by then */ S.pos = (LDS_AS u32*)s_pos; S.range = (LDS_AS u32*)s_range;
 	S.rstart = (LDS_AS u32*)s_rstart; S.fix = (LDS_AS u32*)s_fix; S.fixrow = (LDS_AS u32*)s_fixrow; S.res = (LDS_AS u32*)s_res; S.rxb = s_rxb; S.owner = (LDS_AS u32*)s_owner;
 	if (blockIdx.x * LANES + LANES <= n_chains) rcs_workgroup<true, LANES>(chains, n_chains, rec_pool, word_pool, st, bk, redo, S);
 	else rcs_workgroup<false, LANES>(chains, n_chains, rec_pool, word_pool, st, bk, redo, S);
