@@ -11,6 +11,26 @@ __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ u32 wave_id() { return threadIdx.x >> 6; }
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
+// acc + the number of lanes below this one whose bit is set in a wave-uniform mask (v_mbcnt_lo / v_mbcnt_hi: the mask stays in
+// scalar registers -- a prefix sum over one-bit values without the six dependent DPP steps of a scan)
+__device__ __forceinline__ u32 wave_count_below(u64 mask, u32 acc)
+{
+#ifdef DSRC_EMU_BUILD
+	return acc + (u32)__builtin_popcountll(mask & lanemask_lt());
+#else
+	return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, acc));
+#endif
+}
+// this lane's bit of a wave-uniform mask as a condition: the mask becomes the execution mask, no vector instruction
+__device__ __forceinline__ bool wave_lane_in(u64 mask)
+{
+#ifdef DSRC_EMU_BUILD
+	return ((mask >> lane_id()) & 1ull) != 0;
+#else
+	return __builtin_amdgcn_inverse_ballot_w64(mask);
+#endif
+}
+
 __device__ __forceinline__ u32 wave_incl_scan(u32 v)
 {
 	const u32 l = lane_id();

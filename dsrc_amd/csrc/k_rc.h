@@ -430,17 +430,17 @@ __global__ void __launch_bounds__(SORT_WG) __attribute__((amdgpu_waves_per_eu(SO
 	}
 }
 
-// ceil(2^48 / d) for 2 <= d < 2^16 without a 64-bit integer division (a ~100-instruction sequence on this machine):
-// with inv = fl(fl(1/d) * (1 + 2^-50)), p = 2^48 * inv = Q * (1 + e), Q = 2^48/d, 0.6 * 2^-50 < e < 1.4 * 2^-50
-// (three roundings of 2^-53 each around the 2^-50 bias; the multiplication by 2^48 is exact).  So p > Q, and
-// p - Q < 1.4 * 2^-50 * 2^48 / d = 0.35 / d <= the distance from Q to the next integer (>= 1/d unless Q is one, and
-// then 0.35/d < 1): trunc(p) == floor(Q).  The quotient is exact only for powers of two.
-__device__ __forceinline__ u64 recip48(u32 d)
+// ceil(2^48 / d) for 2 <= d < 2^16 without a 64-bit integer division (a ~100-instruction sequence on this machine), as the low 52
+// bits of a double.  y = 1 / d to within 2^-52 of it either way (the hardware's estimate and two Newton steps; the IEEE division --
+// v_div_scale x 2, v_rcp, 6 fma, v_div_fmas, v_div_fixup -- was a third of a loader wave's f64 instructions in k_rcs).  With
+// K = 2^48 * (1 - 2^-50) the product y * K = Q * (1 - e), Q = 2^48 / d, 0.6 * 2^-50 < e < 1.4 * 2^-50: below Q by less than
+// 0.35 / d.  Q is an integer (d a power of two) or at least 1 / d away from one, so floor(y * K) = ceil(Q) - 1 either way, and
+// t = y * K + 0.5 (one fma: the product is not rounded on its own; t's rounding is below 0.04 / d) lies strictly between
+// ceil(Q) - 0.5 + 0.6 / d and ceil(Q) + 0.5 - 0.9 / d: t + 2^52 rounds to 2^52 + ceil(Q), whose mantissa field is the result.
+// Round 6 took the integer apart with two conversions, a multiplication and an fma and added one unless d was a power of two: 19
+// instructions per record against 10 with the packing, and k_rcs's period waited for the loader waves.  k_selftest tries every d on the device.
+__device__ __forceinline__ u64 recip48_bits(u32 d)
 {
-	// 1 / d from the hardware's estimate and two Newton steps (relative error <= 2^-52 either way; the factor 1 + 2^-50 then puts the
-	// result at or above 1 / d, by less than 2^-49 of it: floor(p) = floor(2^48 / d) for every d <= 2^16, k_selftest tries them all on
-	// the device).  The IEEE division -- v_div_scale x 2, v_rcp, 6 fma, v_div_fmas, v_div_fixup -- was a third of a loader wave's
-	// f64 instructions in k_rcs, and those waves are what its period waits for with 32 streams per workgroup.
 #ifdef DSRC_EMU_BUILD
 	const double y = 1.0 / (double)d;
 #else
@@ -449,11 +449,19 @@ __device__ __forceinline__ u64 recip48(u32 d)
 	y = __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
 	y = __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
 #endif
-	const double p = y * ((1.0 + 0x1p-50) * 0x1p48);
-	const u32 hi = (u32)(p * 0x1p-32);                         // p < 2^47: hi < 2^15
-	const u32 lo = (u32)(p - (double)hi * 0x1p32);             // the subtraction is exact (p < 2^47 keeps >= 6 fraction bits); the cast truncates
-	const u64 q = ((u64)hi << 32) | lo;
-	return q + ((d & (d - 1u)) ? 1ull : 0ull);
+	const double t = __builtin_fma(y, (1.0 - 0x1p-50) * 0x1p48, 0.5);
+	const double r = t + 0x1p52;
+	u64 bits;
+	__builtin_memcpy(&bits, &r, 8);
+	return bits;                                               // 0x433 << 52 | ceil(2^48 / d)
+}
+__device__ __forceinline__ u64 recip48(u32 d) { return recip48_bits(d) & 0xFFFFFFFFFFFFFull; }
+// the two words wave R multiplies by: the top 32 bits of m << 16 and its low 32 bits (m < 2^47; the alignbit drops the exponent field)
+__device__ __forceinline__ void recip48_ab(u32 d, u32* a, u32* b)
+{
+	const u64 bits = recip48_bits(d);
+	*a = __builtin_amdgcn_alignbit((u32)(bits >> 32), (u32)bits, 16);
+	*b = (u32)bits << 16;
 }
 
 // Is the order in which the LDS applies the lanes of ONE ds_add_rtn instruction to one word the lane order?  k_sort<.., true>
@@ -1055,15 +1063,17 @@ struct RcFetch { u32 fc, tot; };
 template <int ROWS> struct RcRowBases { const u8* p[ROWS]; };       // the arrays of a loader's rows (wave-uniform: scalar registers)
 template <int ROWS> __device__ __forceinline__ void rc_fetch(RcFetch* r, const RcRowBases<ROWS>& rb, u32 chunk, u32 lw, u32 n_live)
 {
-	const u32 off = rc6_chunk_off(chunk);
+	// the row's array in scalar registers + a 32-bit offset per lane, the same for every row (the address as a 64-bit sum per lane and
+	// row: two v_lshl_add_u64 per row and period on waves that k_rcs's period waits for)
+	const u32 o4 = rc6_chunk_off(chunk) + 4u * lane_id(), o2 = rc6_chunk_off(chunk) + 256u + 2u * lane_id();
 #pragma unroll
 	for (u32 k = 0; k < (u32)ROWS; ++k)
 	{
 		const bool live = lw + k * RC_LOADERS < n_live;                    // n_live: constant RC_LANES in full workgroups
-		const u8* sp = rb.p[k] + off;
+		const GLOBAL_AS u8* sp = (const GLOBAL_AS u8*)rb.p[k];
 		// global, not flat: a flat access orders itself against the LDS traffic
-		r[k].fc = live ? *(const GLOBAL_AS u32*)(sp + 4u * lane_id()) : 0u;
-		r[k].tot = live ? (u32)*(const GLOBAL_AS u16*)(sp + 256u + 2u * lane_id()) : 0u;
+		r[k].fc = live ? *(const GLOBAL_AS u32*)(sp + o4) : 0u;
+		r[k].tot = live ? (u32)*(const GLOBAL_AS u16*)(sp + o2) : 0u;
 	}
 }
 
@@ -1105,35 +1115,38 @@ __device__ __forceinline__ void rc_chunk(RcState& s, LDS_AS u32* c, RcRegs& r0, 
 // scalar registers -- nothing the byte stores need comes from memory, a load here would wait behind the record fetches in flight).
 template <int ROWS> struct RcEmitRows { GLOBAL_AS u8* out[ROWS]; u32 limit[ROWS], n_full[ROWS], pos[ROWS]; };
 
-// Loader wave `lw`, rows lw, lw + RC_LOADERS, ...: the 64 codes of chunk `chunk` of each row -> bytes at the row's running position
-// (lane l takes code l: scan of the byte counts, up to three byte stores).
+// Loader wave `lw`, rows lw, lw + RC_LOADERS, ...: the 64 codes of chunk `chunk` of each row -> bytes at the row's running position.
+// Lane l takes code l (up to three bytes).  A code's byte count is two bits: where a lane's bytes go is a count of the lanes below it
+// in two ballots (four v_mbcnt), the row's total two scalar popcounts, and which lanes store comes from the same masks -- a scan over
+// the counts was eight DPP steps with their wait states, a readlane and three compares per row on waves that k_rcs's period waits for.
 template <int ROWS> __device__ __forceinline__ void rc_emit_chunk(const LDS_AS u32* codes, RcEmitRows<ROWS>& R, u32 chunk, u32 lw, u32 n_live, u32* over)
 {
 	const u32 lane = lane_id();
-	const u32 t = chunk * RC_CHUNK + lane;
-	u32 v[ROWS], kb[ROWS], inc[ROWS];
-	// the rows' scans are independent chains of DPP steps: kept apart from the stores so that they interleave
+	const u32 t0 = chunk * RC_CHUNK;
+	u32 v[ROWS];
 #pragma unroll
 	for (u32 k = 0; k < (u32)ROWS; ++k)
 	{
 		const u32 j = lw + k * RC_LOADERS;
 		v[k] = codes[(j < n_live ? j : 0u) * RC_CODE_PITCH + lane];
-		kb[k] = j < n_live && t < R.n_full[k] ? (v[k] >> 3) & 3u : 0u;      // the code's low byte is 8 * bytes
 	}
-#pragma unroll
-	for (u32 k = 0; k < (u32)ROWS; ++k) inc[k] = wave_incl_scan_dpp(kb[k]);
 #pragma unroll
 	for (u32 k = 0; k < (u32)ROWS; ++k)
 	{
-		const u32 total = wave_last(inc[k]);
-		const u32 at = R.pos[k] + inc[k] - kb[k];
+		const u32 j = lw + k * RC_LOADERS;
+		// the row's symbols in this chunk are its first n_ok (all scalar: n_full is a multiple of 16)
+		const u32 n_ok = j < n_live && R.n_full[k] > t0 ? (R.n_full[k] - t0 < RC_CHUNK ? R.n_full[k] - t0 : (u32)RC_CHUNK) : 0u;
+		const u64 okm = n_ok >= 64u ? ~0ull : (1ull << n_ok) - 1ull;
+		const u64 b0 = __ballot((v[k] & 8u) != 0u) & okm, b1 = __ballot((v[k] & 16u) != 0u) & okm;      // the code's low byte is 8 * bytes
+		const u32 total = (u32)__popcll(b0) + 2u * (u32)__popcll(b1);
+		const u32 at = wave_count_below(b0, R.pos[k] + 2u * wave_count_below(b1, 0u));
 		if (R.pos[k] + total > R.limit[k]) *over |= 1u << k;
 		else
 		{
 			GLOBAL_AS u8* out = R.out[k];
-			if (kb[k] >= 1) out[at] = (u8)(v[k] >> 24);
-			if (kb[k] >= 2) out[at + 1] = (u8)(v[k] >> 16);
-			if (kb[k] >= 3) out[at + 2] = (u8)(v[k] >> 8);
+			if (wave_lane_in(b0 | b1)) out[at] = (u8)(v[k] >> 24);
+			if (wave_lane_in(b1)) out[at + 1] = (u8)(v[k] >> 16);
+			if (wave_lane_in(b0 & b1)) out[at + 2] = (u8)(v[k] >> 8);
 		}
 		R.pos[k] += total;
 	}
@@ -1479,9 +1492,10 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 				const u32 j = lw + k * RC_LOADERS;
 				if (j < n_live)
 				{
-					const u64 m = recip48(f[k].tot);                          // < 2^47: m << 16 fits
+					u32 ma, mb;
+					recip48_ab(f[k].tot, &ma, &mb);
 					LDS_AS u32* d = (LDS_AS u32*)(rbuf + j * RC_ROW_U4) + 3u * lane_id();
-					d[0] = (u32)(m >> 16); d[1] = (u32)m << 16; d[2] = f[k].fc & 0xFFFFu;
+					d[0] = ma; d[1] = mb; d[2] = f[k].fc & 0xFFFFu;
 				}
 			}
 		};
@@ -1669,6 +1683,7 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 
 template <int LANES> __global__ void __launch_bounds__(64 * RCS_WG_WAVES) k_rcs(const RcChain* chains, u32 n_chains, RcPack* rec_pool, u32* word_pool, BlkState* st, const u32* bk, u32* redo)
 {
+	if (RCS_PROBE & 128) return;                                               // (experiments: the front end alone)
 	__shared__ U4 s_r[2 * RCS_RROW_U4];
 	__shared__ U4 s_l[2 * RCS_LROW_U4];
 	__shared__ U4 s_k[2 * RCS_KROW_U4];
