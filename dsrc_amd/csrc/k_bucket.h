@@ -38,7 +38,9 @@
 #endif                                 // (64 KB: with 14 bits and 128 KB a k_place workgroup needs a CU nearly to itself -- 1.5 ms alone, 6.9 ms next to three other instances)
 #define BK_BIN (1u << BK_TB)
 static_assert(BK_TB == RC6_TB, "a time bin is the unit of k_rc's record layout (rc6_chunk_off)");
+#ifndef BK_MAX_BINS
 #define BK_MAX_BINS 512                // streams of up to 4 M symbols keep their tiles' offsets and counts of a bucket in k_model's LDS;
+#endif
 #define BK_MAX_BINS_WIDE 65536         // longer ones (-b64, -b256: 27 M / 107 M symbols per stream) read them from the count table 64 tiles at a time
 #define BK_HASH_MUL 0x9E3779B1u
 

@@ -9,6 +9,7 @@
 
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ u32 wave_id() { return threadIdx.x >> 6; }
+__device__ __forceinline__ u32 min_u32(u32 a, u32 b) { return a < b ? a : b; }
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
 // acc + the number of lanes below this one whose bit is set in a wave-uniform mask (v_mbcnt_lo / v_mbcnt_hi: the mask stays in

@@ -347,11 +347,15 @@ __global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* 
 	auto request = [&](u64 g)
 	{
 		n_len = rp.len[g]; n_so = rp.seq_off[g]; n_qo = rp.qual_off[g]; n_tl = rp.title_len[g];
+		const u32 last = n_len ? n_len - 1u : 0u;
 #pragma unroll
 		for (u32 k = 0; k < PS_AHEAD; ++k)
 		{
-			const u32 j = 64u * k + lane; const bool have = j < n_len;         // (without one: the chunk's first byte)
-			n_b[k] = p[have ? n_so + j : 0u]; n_q[k] = p[have ? n_qo + j : 0u];
+			// (a lane past the end of the read asks for the read's last character: an index clamped with v_min.  Written as a choice
+			// between two addresses -- `have ? n_so + j : 0` -- the compiler turned the request into branches around two loads and a
+			// copy behind `s_waitcnt vmcnt(0)`: three memory round trips per record in the one place meant to hide them)
+			const u32 j = min_u32(64u * k + lane, last);
+			n_b[k] = p[n_so + j]; n_q[k] = p[n_qo + j];
 		}
 	};
 	if (wave_id() < n_recs) request((u64)d.rec_base + wave_id());
@@ -404,8 +408,8 @@ __global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* 
 		for (u32 k = 0; k < PS_AHEAD; ++k) if (64u * k < len) chunk(64u * k, c_b[k], c_q[k]);
 		for (u32 j0 = 64u * PS_AHEAD; j0 < len; j0 += 64)
 		{
-			const u32 j = j0 + lane; const bool have = j < len;
-			chunk(j0, (u32)p[have ? so + j : 0u], (u32)p[have ? qo + j : 0u]);
+			const u32 j = min_u32(j0 + lane, len - 1u);
+			chunk(j0, (u32)p[so + j], (u32)p[qo + j]);
 		}
 		if (len > 0 && lastq == 2 && rle > 0) rle -= 1;     // per-record decrement (Appendix B.13)
 		if (lane == 0)
@@ -539,8 +543,8 @@ __global__ void __launch_bounds__(WG) k_prep_write(const u8* in, const BlkDesc* 
 #pragma unroll
 		for (u32 k = 0; k < PW_AHEAD; ++k)
 		{
-			const u32 j = 64u * k + lane; const bool have = j < len;           // (without one: the chunk's first byte)
-			c_b[k] = p[have ? so + j : 0u]; c_q[k] = p[have ? qo + j : 0u];
+			const u32 j = min_u32(64u * k + lane, len ? len - 1u : 0u);           // (past the end of the read: its last character -- see k_prep_stats)
+			c_b[k] = p[so + j]; c_q[k] = p[qo + j];
 		}
 		if (r + waves_total < n_recs) request(g + waves_total);
 		u32 run = 0;
@@ -568,8 +572,8 @@ __global__ void __launch_bounds__(WG) k_prep_write(const u8* in, const BlkDesc* 
 		for (u32 k = 0; k < PW_AHEAD; ++k) if (64u * k < len) chunk(64u * k, c_b[k], c_q[k]);
 		for (u32 j0 = 64u * PW_AHEAD; j0 < len; j0 += 64)
 		{
-			const u32 j = j0 + lane; const bool have = j < len;
-			chunk(j0, (u32)p[have ? so + j : 0u], (u32)p[have ? qo + j : 0u]);
+			const u32 j = min_u32(j0 + lane, len - 1u);
+			chunk(j0, (u32)p[so + j], (u32)p[qo + j]);
 		}
 	}
 }
