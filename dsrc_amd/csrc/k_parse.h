@@ -322,6 +322,8 @@ __global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* 
 	__shared__ u32 s_qf[256];
 	__shared__ u32 s_df[20];
 	__shared__ u32 s_acc[8];      // rle, th, raw(qual), min, max, raw_tag, raw_dna, bad_base
+	__shared__ u8 s_dna[256];
+	dna_index_table(s_dna);       // (the barrier below)
 	const u32 b = blockIdx.x;
 	const BlkDesc d = desc[b];
 	const u8* p = in + d.in_off;
@@ -376,7 +378,7 @@ __global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* 
 			{	// the transform on every lane, `in_r` applied afterwards: the form k_prep_write needed on gfx950 (see there); lanes past the
 				// end of the read take a harmless stand-in
 				const u32 cb = in_r ? cb_in : (u32)'A', cq = in_r ? cq_in : prm.quality_offset + 40u;
-				const u32 qq = transform_base<FAST_STATS>(cb, cq, prm.quality_offset, prm.lossy, &sidx, &keep);
+				const u32 qq = transform_base_s((u32)s_dna[cb & 255u], cq, prm.quality_offset, prm.lossy, &sidx, &keep);      // (the table: one LDS read for ~20 selects)
 				if (in_r) q = qq; else { keep = false; sidx = 0; }
 			}
 			const bool k2 = in_r && keep;
