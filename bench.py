@@ -586,7 +586,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)  # 10 x 1800 blocks of 8 MiB = 4 passes over the 100 M-read set (~4500 blocks); inputs stay resident in HBM
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--blocks", type=int, default=int(os.environ.get("DSRC_BENCH_BLOCKS", "1800")), help="8 MiB chunks per step per GPU")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DSRC_BENCH_PIPELINE", "4")), help="scheduler instances per GPU (round 4: four batches of 450 blocks: 39-40 GB/s; five of 300: 35-37)")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("DSRC_BENCH_PIPELINE", "4")), help="scheduler instances per GPU (round 6, batches of 450 blocks: three 63.7, four 68.1 GB/s holding 204 GB, five 70.1 - 71.3 holding 255 GB -- which leaves rank 0 of an 8-GPU run no room for the streams it gathers --, six 67.0; five batches of 360: 64.0)")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("DSRC_BENCH_LANES", "1")), help="scheduler lanes INSIDE every handle (dsrcgpu_set_lanes; 0 = the library's default, 1 = none)")
     ap.add_argument("--sub-blocks", type=int, default=int(os.environ.get("DSRC_BENCH_SUB_BLOCKS", "0")), help="chunks per sub-batch of a handle's lanes (0 = the library's default, about 1 GiB)")
     ap.add_argument("--buf-mb", type=int, default=8, help="chunk size (the reference's -b; 8 = BASELINE's configurations; -m1 / -m2 of the reference's command line are 64 / 256)")
@@ -647,10 +647,10 @@ def main():
     def hbm_need(sb, n_res):
         chunks = sb * RECS_PER_BLOCK * 1.02 * 384
         if args.lanes == 1:
-            arena = chunks * 9.0 + (7.5e9 if chunks >= 2.5e9 else 1.9e9)
+            arena = chunks * 7.5 + (7.6e9 if chunks >= 2.5e9 else 1.9e9) + sb * 1.05e6      # dsrc_gpu.hip estimate_arena: 15/2 x the chunks + the element slice + 1 MB per chunk
         else:                       # lanes inside the handle: an arena per lane, sized for a sub-batch (about 1 GiB of chunks unless told otherwise)
             sub = min(chunks, (args.sub_blocks * BUF * 1.0) if args.sub_blocks else 1.9e9)
-            arena = (args.lanes or 4) * (sub * 9.0 + 1.9e9)
+            arena = (args.lanes or 4) * (sub * 7.5 + 1.9e9 + sub / BUF * 1.05e6)
         per_lane = arena + n_res * chunks + (2 if dist is not None else 1) * chunks / 2
         return P * per_lane + (P * (world - 1) * chunks / 2 if dist is not None and rank == 0 and not host_payload else 0)
     try:
@@ -723,6 +723,13 @@ def main():
         gather_step(s)
     for ln in lanes:
         ln.timing.clear()
+    hbm_held = None
+    try:        # what this process holds of the device once every instance has its arena (rank 0 of N > 1: the receive buffers too)
+        fr = _C.c_uint64(); tot_ = _C.c_uint64()
+        if _load().dsrcgpu_device_memory(local, _C.byref(fr), _C.byref(tot_)) == 0:
+            hbm_held = round((tot_.value - fr.value) / 1e9, 1)
+    except (OSError, NameError):
+        pass
 
     # ---- timed region: K steps, lanes a fraction of a period apart ------------------------------------------
     first = args.warmup
@@ -881,7 +888,7 @@ def main():
             "data": f"synthetic (counter-based generator, in HBM; {lanes[0].n_res} distinct ~{sub_blocks * 8.4 / 1e3:.1f} GB shards per scheduler instance = {P * lanes[0].n_res * sub_blocks * 8.4 / 1e3:.1f} GB of distinct records per GPU, cycled)",
             "config": {"workload": f"Synthetic Illumina 150 bp FASTQ, 100M-read data set shape (BASELINE configs[2]), -d{args.dna} -q{args.qua} -b{args.buf_mb}; "
                                    f"step = {args.blocks} consecutive {args.buf_mb} MiB chunks per GPU, device-resident, {P} scheduler instances per GPU",
-                       "blocks_per_step": args.blocks, "pipeline": P,
+                       "blocks_per_step": args.blocks, "pipeline": P, "hbm_held_GB": hbm_held,
                        "parallelism": (f"{world} process(es), one per GPU ({dist.get_world_size()} ranks in the {group_name}; a gather thread and a group per scheduler instance): contiguous partId ranges, no data-path collective; per step the block sizes are all-gathered and "
                                        f"every rank's block stream goes to rank 0 by point-to-point send (RCCL), overlapped with the next step") if dist is not None else "1 GPU",
                        **({"per_rank_MB_per_s": per_rank, "gather_verified": gather_verified} if dist is not None else {}),
@@ -958,7 +965,7 @@ def main():
                     for nh in (1, 2):
                         mbs, nbytes, dt = measure_queue_form(cfg, ln.h.device, chunks, nh)
                         q[f"handles_{nh}"] = {"value": mbs, "unit": "MB/s", "bytes": nbytes, "s": round(dt, 2)}
-                    mbs, nbytes, dt = measure_queue_form(cfg, ln.h.device, chunks, 1, batches=8, pinned=True)
+                    mbs, nbytes, dt = measure_queue_form(cfg, ln.h.device, chunks, 1, batches=12, pinned=True)
                     q["handles_1_pinned"] = {"value": mbs, "unit": "MB/s", "bytes": nbytes, "s": round(dt, 2),
                                              "what": "the same with dsrcgpu_submit_pinned: the chunks lie in page-locked memory of the caller's and are not copied into the ring"}
                     q["what"] = "dsrcgpu_submit / flush / collect / release with host-resident 8 MiB chunks, 192 chunks per flush, one submitting and one collecting thread per handle; host copy into the page-locked ring, PCIe both ways and the compression inside; a handle runs consecutive batches on three scheduler lanes of its own (DSRC_GPU_QUEUE_LANES)"

@@ -30,6 +30,9 @@
 #include "../../include/dsrc_gpu.h"
 #include "dsrc_types.h"
 #include "k_common.h"
+#ifndef RCS_WIDE
+#define RCS_WIDE 32                    // streams per k_rcs workgroup in launches of more than 640 streams (16 below)
+#endif
 #include "k_parse.h"
 #include "k_rc.h"
 #include "k_bucket.h"
@@ -1020,7 +1023,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		if (rc_one_lane) hipLaunchKernelGGL(k_rc, dim3((NJ + RC_LANES - 1) / RC_LANES), dim3(64 * RC_WG_WAVES), 0, h->rc_stream, d_chains, NJ, (const u32*)nullptr, AP<RcPack>(h, 0), wpool, d_state);
 		// 32 streams per workgroup where the launch is large (fewer CUs under the serial waves: 61.3 against 59.1 GB/s with four instances
 		// of 900 streams), 16 where it is small and its time is what the caller waits for (76 against 101 ms per launch)
-		else if (NJ > (u32)hook_int("DSRC_GPU_RC_WIDE_FROM", 640)) hipLaunchKernelGGL(k_rcs<32>, dim3((NJ + 31) / 32), dim3(64 * RCS_WG_WAVES), 0, h->rc_stream, d_chains, NJ, AP<RcPack>(h, 0), wpool, d_state, (const u32*)d_bk, d_redo);
+		else if (NJ > (u32)hook_int("DSRC_GPU_RC_WIDE_FROM", 640)) hipLaunchKernelGGL(k_rcs<RCS_WIDE>, dim3((NJ + RCS_WIDE - 1) / RCS_WIDE), dim3(64 * RCS_WG_WAVES), 0, h->rc_stream, d_chains, NJ, AP<RcPack>(h, 0), wpool, d_state, (const u32*)d_bk, d_redo);
 		else hipLaunchKernelGGL(k_rcs<16>, dim3((NJ + 15) / 16), dim3(64 * RCS_WG_WAVES), 0, h->rc_stream, d_chains, NJ, AP<RcPack>(h, 0), wpool, d_state, (const u32*)d_bk, d_redo);
 		KCHK();
 		HIPCHK(hipEventRecord(h->ev[3], h->rc_stream));
