@@ -963,9 +963,9 @@ def main():
                     chunks = [ln.h.dev_download(d_in + starts[i], sizes[i]) for i in range(n_host)]
                     q = {}
                     for nh in (1, 2):
-                        mbs, nbytes, dt = measure_queue_form(cfg, ln.h.device, chunks, nh)
+                        mbs, nbytes, dt = measure_queue_form(cfg, ln.h.device, chunks, nh, batches=12)
                         q[f"handles_{nh}"] = {"value": mbs, "unit": "MB/s", "bytes": nbytes, "s": round(dt, 2)}
-                    mbs, nbytes, dt = measure_queue_form(cfg, ln.h.device, chunks, 1, batches=12, pinned=True)
+                    mbs, nbytes, dt = measure_queue_form(cfg, ln.h.device, chunks, 1, batches=24, pinned=True)
                     q["handles_1_pinned"] = {"value": mbs, "unit": "MB/s", "bytes": nbytes, "s": round(dt, 2),
                                              "what": "the same with dsrcgpu_submit_pinned: the chunks lie in page-locked memory of the caller's and are not copied into the ring"}
                     q["what"] = "dsrcgpu_submit / flush / collect / release with host-resident 8 MiB chunks, 192 chunks per flush, one submitting and one collecting thread per handle; host copy into the page-locked ring, PCIe both ways and the compression inside; a handle runs consecutive batches on three scheduler lanes of its own (DSRC_GPU_QUEUE_LANES)"
