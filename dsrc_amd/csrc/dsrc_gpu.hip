@@ -390,7 +390,9 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 		if (crc) { hipLaunchKernelGGL(k_crc, dim3(B, 3), dim3(WG), 0, s, d_in, d_desc, d_state, rp, h->d_crc_tab, prm); KCHK(); }
 		hipLaunchKernelGGL(k_cs_decode, dim3(rec_gx, B), dim3(WG), 0, s, const_cast<u8*>(d_in), d_desc, d_state, rp); KCHK();
 	}
-	hipLaunchKernelGGL(k_prep_stats, dim3(B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, prm); KCHK();
+	// a batch of few, large blocks (-b64, -b256): several workgroups per block (k_prep_stats 21 ms per 56 blocks of 64 MiB with one)
+	const u32 stats_parts = (u32)hook_int("DSRC_GPU_HOOK_STATS_PARTS", B >= 192 ? 1 : std::min<long>(16, std::max<long>(2, 512 / B)));
+	hipLaunchKernelGGL(k_prep_stats, dim3(stats_parts, B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, prm); KCHK();
 	if (prm.color_space) { hipLaunchKernelGGL(k_cs_reduce, dim3((max_rec_cap + WG - 1) / WG, B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, prm); KCHK(); }
 	hipLaunchKernelGGL(k_rec_offsets, dim3(B), dim3(WG), 0, s, d_desc, d_state, rp); KCHK();
 	const u32 prep_gx = std::max(1u, std::min(64u, (max_rec_cap + 4 * WAVES - 1) / (4 * WAVES)));

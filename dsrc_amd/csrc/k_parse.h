@@ -316,15 +316,21 @@ __global__ void __launch_bounds__(WG) k_cs_decode(u8* in, const BlkDesc* desc, B
 	}
 }
 
-// ---- pass 5: statistics, one workgroup per block, one wave per record ------------------------
+// ---- pass 5: statistics, one wave per record ---------------------------------------------------
+// Grid: x = part, y = block.  With many blocks in a batch a block is one workgroup's (gridDim.x = 1); a batch of few, large blocks (the
+// reference's -m1 / -m2: 56 or 14 blocks of 64 / 256 MiB) gives every block to several workgroups, each taking every gridDim.x-th group of
+// records: their sums meet in the block's state through atomics (zeroed with the state; min_len starts at ~0: k_init_state) and the
+// workgroup that arrives last (a counter in scratch[7]) does what follows from them.
+#define STATS_PARTS_SLOT 7
 __global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* desc, BlkState* st, RecPools rp, DsrcParams prm)
 {
 	__shared__ u32 s_qf[256];
 	__shared__ u32 s_df[20];
 	__shared__ u32 s_acc[8];      // rle, th, raw(qual), min, max, raw_tag, raw_dna, bad_base
 	__shared__ u8 s_dna[256];
+	__shared__ u32 s_last;
 	dna_index_table(s_dna);       // (the barrier below)
-	const u32 b = blockIdx.x;
+	const u32 b = blockIdx.y, parts = gridDim.x;
 	const BlkDesc d = desc[b];
 	const u8* p = in + d.in_off;
 	const u32 n_recs = block_rec_count(st[b], d);
@@ -342,7 +348,7 @@ __global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* 
 	// cost three memory round trips (round 5).  Every lane asks (past the end of the read for the chunk's first byte): a request
 	// under a branch cannot be counted on by a later wait.
 	constexpr u32 PS_AHEAD = 3;
-	const u32 wstep = blockDim.x >> 6;
+	const u32 wstep = (blockDim.x >> 6) * parts, w0 = blockIdx.x * (blockDim.x >> 6) + wave_id();
 	u32 n_len = 0, n_so = 0, n_qo = 0, n_tl = 0, n_b[PS_AHEAD], n_q[PS_AHEAD];
 #pragma unroll
 	for (u32 k = 0; k < PS_AHEAD; ++k) { n_b[k] = 'A'; n_q[k] = 0; }
@@ -360,8 +366,8 @@ __global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* 
 			n_b[k] = p[n_so + j]; n_q[k] = p[n_qo + j];
 		}
 	};
-	if (wave_id() < n_recs) request((u64)d.rec_base + wave_id());
-	for (u32 r = wave_id(); r < n_recs; r += wstep)
+	if (w0 < n_recs) request((u64)d.rec_base + w0);
+	for (u32 r = w0; r < n_recs; r += wstep)
 	{
 		const u64 g = (u64)d.rec_base + r;
 		const u32 len = n_len, so = n_so, qo = n_qo, tl = n_tl;
@@ -431,8 +437,39 @@ __global__ void __launch_bounds__(WG) k_prep_stats(const u8* in, const BlkDesc* 
 	__syncthreads();
 
 	BlkState* S = &st[b];
-	for (u32 i = threadIdx.x; i < 256; i += blockDim.x) S->q_freq[i] = s_qf[i];
-	if (threadIdx.x < 20) S->d_freq[threadIdx.x] = s_df[threadIdx.x];
+	if (parts > 1)
+	{	// this part's sums into the block's; the last part to arrive takes the totals back into its LDS and goes on as the only one would
+		for (u32 i = threadIdx.x; i < 256; i += blockDim.x) if (s_qf[i]) atomicAdd(&S->q_freq[i], s_qf[i]);
+		if (threadIdx.x < 20 && s_df[threadIdx.x]) atomicAdd(&S->d_freq[threadIdx.x], s_df[threadIdx.x]);
+		if (threadIdx.x == 0)
+		{
+			atomicAdd(&S->rle_len, s_acc[0]); atomicAdd(&S->th_len, s_acc[1]); atomicAdd(&S->raw_len, s_acc[2]);
+			atomicMin(&S->min_len, s_acc[3]); atomicMax(&S->max_len, s_acc[4]); atomicAdd(&S->raw_tag, s_acc[5]);
+			if (s_acc[7]) atomicOr(&S->err, (u32)DSRC_ERR_BAD_BASE);
+		}
+		__threadfence();
+		__syncthreads();
+		if (threadIdx.x == 0) s_last = atomicAdd(&S->scratch[STATS_PARTS_SLOT], 1u) == parts - 1u ? 1u : 0u;
+		__syncthreads();
+		if (!s_last) return;
+		__threadfence();
+		// (read where the atomics were applied, not through this CU's vector cache)
+		for (u32 i = threadIdx.x; i < 256; i += blockDim.x) s_qf[i] = atomicAdd(&S->q_freq[i], 0u);
+		if (threadIdx.x < 20) s_df[threadIdx.x] = atomicAdd(&S->d_freq[threadIdx.x], 0u);
+		if (threadIdx.x == 0)
+		{
+			s_acc[0] = atomicAdd(&S->rle_len, 0u); s_acc[1] = atomicAdd(&S->th_len, 0u); s_acc[2] = atomicAdd(&S->raw_len, 0u);
+			s_acc[3] = atomicAdd(&S->min_len, 0u); s_acc[4] = atomicAdd(&S->max_len, 0u); s_acc[5] = atomicAdd(&S->raw_tag, 0u);
+			s_acc[7] = 0;                                                        // (already in S->err)
+			S->scratch[STATS_PARTS_SLOT] = 0;
+		}
+		__syncthreads();
+	}
+	else
+	{
+		for (u32 i = threadIdx.x; i < 256; i += blockDim.x) S->q_freq[i] = s_qf[i];
+		if (threadIdx.x < 20) S->d_freq[threadIdx.x] = s_df[threadIdx.x];
+	}
 	if (threadIdx.x == 0)
 	{
 		S->n_recs = n_recs;

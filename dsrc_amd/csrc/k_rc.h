@@ -1887,5 +1887,5 @@ __global__ void __launch_bounds__(64) k_dna_none(const BlkDesc* desc, BlkState* 
 __global__ void __launch_bounds__(64) k_init_state(BlkState* st, u32 n_blocks)
 {
 	const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
-	if (b < n_blocks) st[b].first_bad = 0xFFFFFFFFu;
+	if (b < n_blocks) { st[b].first_bad = 0xFFFFFFFFu; st[b].min_len = 0xFFFFFFFFu; }      // (min_len: k_prep_stats in several parts folds with atomicMin)
 }

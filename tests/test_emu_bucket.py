@@ -8,7 +8,7 @@ import pytest
 
 from dsrc_amd import synth
 from tests._oracle import Config
-from tests.cases import alphabet_fastq
+from tests.cases import alphabet_fastq, fuzz_fastq
 from tests.test_emu_kernels import emu, run  # noqa: F401  (fixture)
 
 
@@ -44,6 +44,18 @@ def test_long_streams_read_their_tile_table_by_groups(emu, oracle, monkeypatch):
     check(emu, oracle, alphabet_fastq(40, n_rec=420, L=100), [(2, 2, False), (1, 1, False)])
     monkeypatch.setenv("DSRC_GPU_BUCKET_BIG", "256")
     check(emu, oracle, _hot(260), [(1, 2, False)])
+
+
+def test_statistics_in_several_workgroups_per_block(emu, oracle, monkeypatch):
+    """A batch of few, large blocks gives every block's statistics (k_prep_stats) to several workgroups whose sums meet in the block's
+    state; DSRC_GPU_HOOK_STATS_PARTS forces that for small blocks: reads of one and of several lengths, ambiguity codes (the rare symbols'
+    counters), lossy qualities, more parts than a block has groups of records."""
+    for parts in ("3", "16"):
+        monkeypatch.setenv("DSRC_GPU_HOOK_STATS_PARTS", parts)
+        check(emu, oracle, synth.illumina_fastq(300)[:-1], [(3, 2, False), (2, 1, True)])
+        check(emu, oracle, alphabet_fastq(20, n_rec=150, L=100, iupac=True), [(3, 2, False), (0, 0, False)])
+    monkeypatch.setenv("DSRC_GPU_HOOK_STATS_PARTS", "5")
+    check(emu, oracle, fuzz_fastq(77)[0], [(1, 1, False), (3, 2, True)])
 
 
 def test_model_runs_out_of_rows(emu, oracle, capfd, monkeypatch):
