@@ -528,7 +528,7 @@ int run_batch(dsrcgpu_handle* h, BatchIO io)
 	HIPCHK(hipMemcpyAsync(d_desc, desc.data(), sizeof(BlkDesc) * B, hipMemcpyHostToDevice, s));
 	HIPCHK(hipMemcpyAsync(d_tplan, tplan.data(), sizeof(TagPlan) * B, hipMemcpyHostToDevice, s));
 	if (!streams_early) { hipLaunchKernelGGL(k_prep_write, dim3(prep_gx, B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, d_q, d_qp, d_d, prm); KCHK(); }
-	hipLaunchKernelGGL(k_tag_scan, dim3(B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, wpool, d_tplan); KCHK();
+	hipLaunchKernelGGL(k_tag_scan, dim3(stats_parts, B), dim3(WG), 0, s, d_in, d_desc, d_state, rp, wpool, d_tplan); KCHK();      // (several workgroups per block in batches of few, large blocks: see k_prep_stats)
 	hipLaunchKernelGGL(k_tag_numeric, dim3(B), dim3(WG), 0, s, d_desc, d_state, wpool, spool, d_tplan); KCHK();
 	hipLaunchKernelGGL(k_tag_finalize, dim3(B), dim3(64), 0, s, d_state); KCHK();
 

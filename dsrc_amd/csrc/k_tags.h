@@ -185,6 +185,9 @@ __global__ void __launch_bounds__(64) k_tag_template(const u8* in, const BlkDesc
 }
 
 // ---- all records vs the template (UpdateFieldsStats) ----------------------------------------------
+// Grid: x = part, y = block.  In a batch of few, large blocks (-b64, -b256) several workgroups take a block's records (every gridDim.x-th
+// group of blockDim.x); what they find is minima, maxima and flags, which meet in the block's state through atomics (k_tag_template
+// has set their starting values) -- no workgroup has to come last.
 __global__ void __launch_bounds__(WG) k_tag_scan(const u8* in, const BlkDesc* desc, BlkState* st, RecPools rp, u32* val_pool, const TagPlan* plans)
 {
 	__shared__ u32 s_minlen[DSRC_MAX_FIELDS], s_maxlen[DSRC_MAX_FIELDS];
@@ -194,7 +197,7 @@ __global__ void __launch_bounds__(WG) k_tag_scan(const u8* in, const BlkDesc* de
 	__shared__ u32 s_start0[DSRC_MAX_FIELDS], s_len0[DSRC_MAX_FIELDS];
 	__shared__ u32 s_tmin, s_tmax, s_fmix;
 	__shared__ u8 s_t0[256];                // head of record 0's title (the field template's text)
-	const u32 b = blockIdx.x;
+	const u32 b = blockIdx.y, parts = gridDim.x;
 	BlkState* S = &st[b];
 	const BlkDesc d = desc[b];
 	const u32 nf = S->n_fields, n = S->n_recs;
@@ -213,7 +216,7 @@ __global__ void __launch_bounds__(WG) k_tag_scan(const u8* in, const BlkDesc* de
 	u32* val_arr = val_pool + plans[b].val;
 	for (u32 i = threadIdx.x; i < 256; i += blockDim.x) s_t0[i] = i < rp.title_len[d.rec_base] ? t0[i] : 0;
 	__syncthreads();
-	for (u32 r = threadIdx.x; r < n; r += blockDim.x)
+	for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += blockDim.x * parts)
 	{
 		const u64 g = (u64)d.rec_base + r;
 		const u32 toff = rp.title_off[g];
@@ -257,6 +260,24 @@ __global__ void __launch_bounds__(WG) k_tag_scan(const u8* in, const BlkDesc* de
 		if (c != nf || k != tl + 1) atomicMin(&s_fmix, r);
 	}
 	__syncthreads();
+	if (parts > 1)
+	{
+		for (u32 i = threadIdx.x; i < nf; i += blockDim.x)
+		{
+			TagField* f = &S->fld[i];
+			atomicMin(&f->min_len, s_minlen[i]); atomicMax(&f->max_len, s_maxlen[i]);
+			if (s_nc[i]) atomicOr(&f->not_const, 1u);
+			if (s_nlc[i]) atomicOr(&f->not_lenconst, 1u);
+			if (s_nn[i]) atomicOr(&f->not_numeric, 1u);
+			atomicMin(&f->min_value, s_minv[i]); atomicMax(&f->max_value, s_maxv[i]);
+		}
+		if (threadIdx.x == 0)
+		{
+			atomicMin(&S->min_title, s_tmin); atomicMax(&S->max_title, s_tmax);
+			if (s_fmix != 0xFFFFFFFFu) { atomicMin(&S->first_mixed, s_fmix); atomicOr(&S->mixed, 1u); atomicOr(&S->flags, 4u); }
+		}
+		return;
+	}
 	for (u32 i = threadIdx.x; i < nf; i += blockDim.x)
 	{
 		TagField* f = &S->fld[i];

@@ -47,15 +47,17 @@ def test_long_streams_read_their_tile_table_by_groups(emu, oracle, monkeypatch):
 
 
 def test_statistics_in_several_workgroups_per_block(emu, oracle, monkeypatch):
-    """A batch of few, large blocks gives every block's statistics (k_prep_stats) to several workgroups whose sums meet in the block's
-    state; DSRC_GPU_HOOK_STATS_PARTS forces that for small blocks: reads of one and of several lengths, ambiguity codes (the rare symbols'
+    """A batch of few, large blocks gives every block's statistics (k_prep_stats, k_tag_scan) to several workgroups whose sums meet in the
+    block's state; DSRC_GPU_HOOK_STATS_PARTS forces that for small blocks: reads of one and of several lengths, ambiguity codes (the rare symbols'
     counters), lossy qualities, more parts than a block has groups of records."""
     for parts in ("3", "16"):
         monkeypatch.setenv("DSRC_GPU_HOOK_STATS_PARTS", parts)
         check(emu, oracle, synth.illumina_fastq(300)[:-1], [(3, 2, False), (2, 1, True)])
         check(emu, oracle, alphabet_fastq(20, n_rec=150, L=100, iupac=True), [(3, 2, False), (0, 0, False)])
+    # ... and the titles' (k_tag_scan: minima, maxima and flags per field; titles of mixed formatting)
     monkeypatch.setenv("DSRC_GPU_HOOK_STATS_PARTS", "5")
-    check(emu, oracle, fuzz_fastq(77)[0], [(1, 1, False), (3, 2, True)])
+    for seed in (74, 75, 61, 64, 63, 90, 123):
+        check(emu, oracle, fuzz_fastq(seed)[0], [(1, 1, False), (3, 2, True)])
 
 
 def test_model_runs_out_of_rows(emu, oracle, capfd, monkeypatch):
