@@ -1069,11 +1069,14 @@ template <int ROWS> __device__ __forceinline__ void rc_fetch(RcFetch* r, const R
 #pragma unroll
 	for (u32 k = 0; k < (u32)ROWS; ++k)
 	{
-		const bool live = lw + k * RC_LOADERS < n_live;                    // n_live: constant RC_LANES in full workgroups
+		// Every row is requested, also the ones a partial workgroup (the last of a launch) does not have: rc_rows_setup gives those the
+		// workgroup's first chain's array, nobody uses what comes back.  Skipping them (`live ? load : 0`, a wave-uniform condition
+		// known only at run time) made the compiler put every request of the partial workgroup under a branch with its own wait: with
+		// 9 ... 31 chains in it the launch took 97-101 ms instead of 77 (660 or 720 streams; 900 leave 4, which hid it).
 		const GLOBAL_AS u8* sp = (const GLOBAL_AS u8*)rb.p[k];
 		// global, not flat: a flat access orders itself against the LDS traffic
-		r[k].fc = live ? *(const GLOBAL_AS u32*)(sp + o4) : 0u;
-		r[k].tot = live ? (u32)*(const GLOBAL_AS u16*)(sp + o2) : 0u;
+		r[k].fc = *(const GLOBAL_AS u32*)(sp + o4);
+		r[k].tot = (u32)*(const GLOBAL_AS u16*)(sp + o2);
 	}
 }
 
@@ -1458,11 +1461,16 @@ __device__ __forceinline__ void rcs_workgroup(const RcChain* chains, u32 n_chain
 #else
 	const u32 loader_id = w - 2u;
 #endif
-	const bool have0 = lane < (u32)LANES && (FULL || id < n_chains);
+	const bool have0 = lane < (u32)LANES && id < n_chains;
 	const RcChain c = chains[have0 ? id : n_chains - 1];                       // idle lanes shadow a real chain's values and code nothing
 	// a stream the device handed back to k_sort / k_replay has no records yet: the redo launch codes it
 	const bool have = have0 && !(c.bk_on && bk && bk[c.jid]);
-	const u32 n_live = FULL ? (u32)LANES : n_chains - first_chain;
+	// The loader waves feed all LANES rows, also the ones a partial workgroup (the last of a launch) has no chain for: such a row shadows
+	// the launch's last chain (above), its lane codes nothing (n = 0), no byte of it is written (n_full = 0).  A second instantiation
+	// of this body that knew its rows only at run time cost the partial workgroup -- and so the launch -- 10-25 ms (its masks and byte
+	// positions no longer stayed in scalar registers): 660 / 720 streams 101 / 97 ms against 77 for 800 or 1024.
+	const u32 n_live = (u32)LANES;
+	(void)FULL;
 	const u32 n = have ? c.n : 0;
 	const u32 n_full = n & ~(u32)(RC_GROUP - 1);
 	const u32 wave_full = (u32)__builtin_amdgcn_readfirstlane((int)wave_max(n_full));      // same value in every wave
@@ -1711,8 +1719,7 @@ template <int LANES> __global__ void __launch_bounds__(64 * RCS_WG_WAVES) k_rcs(
 	RcsLds S;
 	S.r = (LDS_AS U4*)s_r; S.l = (LDS_AS U4*)s_l; S.k = (LDS_AS U4*)s_k; S.c = (LDS_AS U4*)s_c; S.xb = (u8*)s_r;         /* the tails' byte buffers: the R rows are free by then */ S.pos = (LDS_AS u32*)s_pos; S.range = (LDS_AS u32*)s_range;
 	S.rstart = (LDS_AS u32*)s_rstart; S.fix = (LDS_AS u32*)s_fix; S.fixrow = (LDS_AS u32*)s_fixrow; S.res = (LDS_AS u32*)s_res; S.rxb = s_rxb; S.owner = (LDS_AS u32*)s_owner;
-	if (blockIdx.x * LANES + LANES <= n_chains) rcs_workgroup<true, LANES>(chains, n_chains, rec_pool, word_pool, st, bk, redo, S);
-	else rcs_workgroup<false, LANES>(chains, n_chains, rec_pool, word_pool, st, bk, redo, S);
+	rcs_workgroup<true, LANES>(chains, n_chains, rec_pool, word_pool, st, bk, redo, S);
 }
 
 // ---- device self-test of the split coder (dsrcgpu_selftest) --------------------------------------------------------------------------
